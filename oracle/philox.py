@@ -1,0 +1,132 @@
+"""Philox4x32-10 counter-based RNG and the (seed, env, step, agent) -> uniform map.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is imported by the product
+package; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may use it (as the checker, never as the thing shipped).
+
+The reference (gym_mapf/envs/mapf_env.py:139, :255) draws one
+``RandomState.rand()`` per agent per non-terminal step.  north_star replaces
+that stream by a counter-based generator so that thousands of envs can draw
+independently on the GPU; this file is the CPU definition of that generator.
+The HIP kernel (gym-mapf_amd/csrc/mapf_kernels.hip: philox4x32_10 /
+slip_uniform53) must reproduce these words bit for bit.
+
+Algorithm: Salmon et al., "Parallel Random Numbers: As Easy as 1, 2, 3"
+(SC'11), Philox-4x32 with 10 rounds; pinned by the Random123 known-answer
+vectors in tests/test_philox.py.
+
+Stream layout (shared with include/mapf_hip.h):
+
+    key  = (seed & 0xffffffff, seed >> 32)
+    ctr  = (env_id & 0xffffffff,
+            env_id >> 32,
+            t & 0xffffffff,
+            ((t >> 32) & 0x00ffffff) | ((agent >> 1) << 24))
+    w    = philox4x32_10(ctr, key)
+    (a, b) = (w[0], w[1]) if agent is even else (w[2], w[3])
+    u    = ((a >> 5) * 2**26 + (b >> 6)) / 2**53          # 53-bit, in [0, 1)
+
+``t`` is the handle-global step index (number of ``step`` calls so far), so a
+terminal-state step simply leaves its counters unused -- equivalent to the
+reference's "no draw on terminal steps" because nothing downstream depends on
+how many words an env has consumed.
+"""
+import numpy as np
+
+PHILOX_M0 = 0xD2511F53
+PHILOX_M1 = 0xCD9E8D57
+PHILOX_W0 = 0x9E3779B9
+PHILOX_W1 = 0xBB67AE85
+MASK32 = 0xFFFFFFFF
+
+ACTION_STREAM_KEY_OFFSET = 1  # actions use key = seed + 1
+
+
+def philox4x32_10(ctr, key):
+    """Scalar Philox4x32-10.  ctr: 4 ints, key: 2 ints -> tuple of 4 uint32."""
+    c0, c1, c2, c3 = (int(x) & MASK32 for x in ctr)
+    k0, k1 = (int(x) & MASK32 for x in key)
+    for r in range(10):
+        p0 = PHILOX_M0 * c0
+        p1 = PHILOX_M1 * c2
+        hi0, lo0 = p0 >> 32, p0 & MASK32
+        hi1, lo1 = p1 >> 32, p1 & MASK32
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ k0) & MASK32, lo1, (hi0 ^ c3 ^ k1) & MASK32, lo0
+        k0 = (k0 + PHILOX_W0) & MASK32
+        k1 = (k1 + PHILOX_W1) & MASK32
+    return c0, c1, c2, c3
+
+
+def philox4x32_10_np(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10 on uint64-held 32-bit lanes (numpy arrays)."""
+    c0 = np.asarray(c0, dtype=np.uint64) & np.uint64(MASK32)
+    c1 = np.asarray(c1, dtype=np.uint64) & np.uint64(MASK32)
+    c2 = np.asarray(c2, dtype=np.uint64) & np.uint64(MASK32)
+    c3 = np.asarray(c3, dtype=np.uint64) & np.uint64(MASK32)
+    c0, c1, c2, c3 = np.broadcast_arrays(c0, c1, c2, c3)
+    k0 = np.uint64(int(k0) & MASK32)
+    k1 = np.uint64(int(k1) & MASK32)
+    m32 = np.uint64(MASK32)
+    s32 = np.uint64(32)
+    for r in range(10):
+        p0 = np.uint64(PHILOX_M0) * c0
+        p1 = np.uint64(PHILOX_M1) * c2
+        hi0, lo0 = p0 >> s32, p0 & m32
+        hi1, lo1 = p1 >> s32, p1 & m32
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ k0) & m32, lo1, (hi0 ^ c3 ^ k1) & m32, lo0
+        k0 = (k0 + np.uint64(PHILOX_W0)) & m32
+        k1 = (k1 + np.uint64(PHILOX_W1)) & m32
+    return c0, c1, c2, c3
+
+
+def _ctr_words(env_id, t, agent):
+    c0 = env_id & MASK32
+    c1 = (env_id >> 32) & MASK32
+    c2 = t & MASK32
+    c3 = ((t >> 32) & 0x00FFFFFF) | (((agent >> 1) & 0xFF) << 24)
+    return c0, c1, c2, c3
+
+
+def slip_uniform(seed, env_id, t, agent):
+    """The 53-bit uniform the slip model of (env_id, step t, agent) consumes."""
+    w = philox4x32_10(_ctr_words(int(env_id), int(t), int(agent)),
+                      (seed & MASK32, (seed >> 32) & MASK32))
+    a, b = (w[0], w[1]) if (agent & 1) == 0 else (w[2], w[3])
+    return ((a >> 5) * 67108864 + (b >> 6)) / 9007199254740992.0
+
+
+def slip_uniforms_np(seed, env_ids, t, n_agents):
+    """u[E, A] float64 for global env ids ``env_ids`` at step ``t``."""
+    env_ids = np.asarray(env_ids, dtype=np.uint64).reshape(-1, 1)
+    pairs = (np.arange(n_agents, dtype=np.uint64) >> np.uint64(1)).reshape(1, -1)
+    t = int(t)
+    c0 = env_ids & np.uint64(MASK32)
+    c1 = env_ids >> np.uint64(32)
+    c2 = np.uint64(t & MASK32)
+    c3 = np.uint64((t >> 32) & 0x00FFFFFF) | (pairs << np.uint64(24))
+    w0, w1, w2, w3 = philox4x32_10_np(c0, c1, c2, c3, seed & MASK32, (seed >> 32) & MASK32)
+    odd = (np.arange(n_agents) & 1).astype(bool).reshape(1, -1)
+    a = np.where(odd, w2, w0)
+    b = np.where(odd, w3, w1)
+    mant = (a >> np.uint64(5)) * np.uint64(67108864) + (b >> np.uint64(6))
+    return mant.astype(np.float64) / 9007199254740992.0
+
+
+def random_actions_np(seed, env_ids, t, n_agents):
+    """Synthetic policy used by bench/rollout: actions u8[E, A] uniform in 0..4.
+
+    Stream: key = seed + 1; ctr = (env_lo, env_hi, t_lo, (t_hi & 0xffffff) |
+    ((agent >> 2) << 24)); word j = agent & 3; action = (word * 5) >> 32.
+    """
+    seed = (int(seed) + ACTION_STREAM_KEY_OFFSET) & 0xFFFFFFFFFFFFFFFF
+    env_ids = np.asarray(env_ids, dtype=np.uint64).reshape(-1, 1)
+    quads = (np.arange(n_agents, dtype=np.uint64) >> np.uint64(2)).reshape(1, -1)
+    t = int(t)
+    c0 = env_ids & np.uint64(MASK32)
+    c1 = env_ids >> np.uint64(32)
+    c2 = np.uint64(t & MASK32)
+    c3 = np.uint64((t >> 32) & 0x00FFFFFF) | (quads << np.uint64(24))
+    w = philox4x32_10_np(c0, c1, c2, c3, seed & MASK32, (seed >> 32) & MASK32)
+    sel = (np.arange(n_agents) & 3).reshape(1, -1)
+    word = np.choose(sel, w)
+    return ((word * np.uint64(5)) >> np.uint64(32)).astype(np.uint8)

@@ -1,0 +1,91 @@
+"""Pin the CPU oracle (oracle/mapf_oracle.py) to the reference's recorded outputs.
+
+Every file under tests/golden/ was produced by the unmodified reference
+(tests/golden/make_golden.py); the oracle must reproduce all of it bit for bit.
+"""
+import numpy as np
+
+import mapf_oracle as mo
+import philox
+from conftest import load_json
+
+CRIT = {'Makespan': mo.MAKESPAN, 'SoC': mo.SOC}
+
+
+def _bits(x):
+    return np.asarray(x, np.float64).view(np.uint64)
+
+
+def test_scripted_cases_match_reference():
+    for case in load_json('scripted_cases.json'):
+        env = mo.OracleEnv(case['lines'], len(case['starts']), case['starts'], case['goals'],
+                           case['fail_prob'], case['r_clash'], case['r_goal'], case['r_living'],
+                           CRIT[case['criteria']])
+        for k, st in enumerate(case['steps']):
+            if st.get('reset'):
+                env.reset()
+                continue
+            nxt, r, done, coll, prob, was_term = env.step(st['actions'], st['uniforms'])
+            tag = '%s step %d' % (case['name'], k)
+            assert list(nxt) == st['next_local'], tag
+            assert _bits(r) == _bits(st['reward']), tag
+            assert done == st['done'], tag
+            assert _bits(prob) == _bits(st['prob']), tag
+            assert (None if was_term else coll) == st['collision'], tag
+            assert st['draws'] == (0 if was_term else len(st['actions'])), tag
+            assert str(env.s) == st['s'], tag
+
+
+def test_transition_tables_match_reference():
+    for tab in load_json('transition_tables.json'):
+        env = mo.OracleEnv(tab['lines'], len(tab['starts']), tab['starts'], tab['goals'],
+                           tab['fail_prob'], tab['r_clash'], tab['r_goal'], tab['r_living'],
+                           CRIT[tab['criteria']])
+        for row in tab['rows']:
+            got = env.transitions(tuple(row['local']), row['actions'])
+            assert len(got) == len(row['transitions']), tab['name']
+            for ((p, c), nxt, r, d), exp in zip(got, row['transitions']):
+                assert _bits(p) == _bits(exp['prob'])
+                assert c == exp['collision'] and d == exp['done']
+                assert list(nxt) == exp['next_local']
+                assert _bits(r) == _bits(exp['reward'])
+                assert str(mo.encode_mixed_radix(nxt, env.V)) == exp['s']
+
+
+def test_trajectories_match_reference(trajectory_set):
+    meta, g = trajectory_set
+    A, T = meta['n_agents'], meta['T']
+    crit = CRIT[meta['criteria']]
+    # tables first: cell numbering, neighbour table and merged slip distributions
+    rows, cells = mo.free_cells_column_major(meta['lines'])
+    assert np.array_equal(np.asarray(cells, np.int32), g['valid_locations'])
+    nbr = mo.neighbour_table(meta['lines'])
+    for v in range(len(cells)):
+        for a in range(5):
+            dist = mo.slip_distribution(nbr[v], a, meta['fail_prob'])
+            n = int(g['mv_n'][v, a])
+            assert len(dist) == n
+            assert [c for c, _ in dist] == list(g['mv_next'][v, a, :n])
+            assert np.array_equal(_bits([p for _, p in dist]), _bits(g['mv_prob'][v, a, :n]))
+    for j, env_id in enumerate(g['env_ids']):
+        env = mo.OracleEnv(meta['lines'], A, g['start_loc'][j].tolist(), g['goal_loc'][j].tolist(),
+                           meta['fail_prob'], meta['r_clash'], meta['r_goal'], meta['r_living'], crit)
+        assert list(env.start) == list(g['start_local'][j])
+        assert list(env.goal) == list(g['goal_local'][j])
+        us = np.stack([philox.slip_uniforms_np(meta['seed'], [env_id], t, A)[0] for t in range(T)])
+        nu = g['uniforms'].shape[0]
+        assert np.array_equal(_bits(us[:nu]), _bits(g['uniforms'][:, j]))
+        acts = np.stack([philox.random_actions_np(meta['seed'], [env_id], t, A)[0] for t in range(T)])
+        assert np.array_equal(acts, g['actions'][:, j])
+        for t in range(T):
+            nxt, r, done, coll, prob, was_term = env.step(acts[t].tolist(), us[t].tolist())
+            tag = '%s env %d t %d' % (meta['name'], int(env_id), t)
+            assert list(nxt) == list(g['next_local'][t, j]), tag
+            assert _bits(r) == _bits(g['reward'][t, j]), tag
+            assert _bits(prob) == _bits(g['prob'][t, j]), tag
+            assert done == bool(g['done'][t, j]) and coll == bool(g['collision'][t, j]), tag
+            assert was_term == bool(g['was_terminal'][t, j]), tag
+            if t < 4:
+                assert str(env.s) == meta['joint_state_first_steps'][j][t], tag
+            if done and meta['auto_reset']:
+                env.reset()
