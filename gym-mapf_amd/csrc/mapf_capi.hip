@@ -1,0 +1,415 @@
+// C ABI of libmapf_hip.so (declared in include/mapf_hip.h): handle management, host<->device
+// staging for the host-pointer mode, argument validation, and the launches.
+#include "mapf_hip.h"
+#include "mapf_kernels.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string &msg) {
+    g_last_error = msg;
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    return fail(MAPF_EHIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                        \
+    do {                                                     \
+        hipError_t _e = (expr);                              \
+        if (_e != hipSuccess) return hip_fail(_e, #expr);    \
+    } while (0)
+
+// Scratch device buffer that grows on demand (host-pointer mode staging).
+struct DeviceBuf {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&ptr, bytes);
+        if (e == hipSuccess) cap = bytes;
+        return e;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct mapf_handle_s {
+    int device = 0;
+    uint32_t V = 0, A = 0, flags = 0;
+    uint64_t E = 0, env_id_offset = 0, t = 0;
+    mapf::EnvConsts c{};
+    bool start_broadcast = false, goal_broadcast = false, device_ptrs = false, own_stream = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    uint2 *nbr4 = nullptr;
+    uint16_t *state = nullptr, *start = nullptr, *goal = nullptr;
+    // host-pointer mode staging
+    DeviceBuf s_actions, s_uniforms, s_local, s_reward, s_prob, s_done, s_coll, s_term, s_mask, s_ret, s_epi, s_ncoll;
+};
+
+namespace {
+
+int check_handle(mapf_handle_t h) {
+    if (!h) return fail(MAPF_EINVAL, "null handle");
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    return MAPF_OK;
+}
+
+bool misaligned(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) != 0; }
+
+// stage a host input on the device (host mode) or pass the device pointer through
+template <typename T>
+int stage_in(mapf_handle_t h, DeviceBuf &buf, const T *src, size_t count, const T **out, const char *name) {
+    if (!src) { *out = nullptr; return MAPF_OK; }
+    if (h->device_ptrs) {
+        if (misaligned(src)) return fail(MAPF_EINVAL, std::string(name) + ": device pointer must be 16-byte aligned");
+        *out = src;
+        return MAPF_OK;
+    }
+    HIP_TRY(buf.reserve(count * sizeof(T)));
+    HIP_TRY(hipMemcpyAsync(buf.ptr, src, count * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    *out = static_cast<const T *>(buf.ptr);
+    return MAPF_OK;
+}
+
+template <typename T>
+int stage_out(mapf_handle_t h, DeviceBuf &buf, T *dst, size_t count, T **out, const char *name) {
+    if (!dst) { *out = nullptr; return MAPF_OK; }
+    if (h->device_ptrs) {
+        if (misaligned(dst)) return fail(MAPF_EINVAL, std::string(name) + ": device pointer must be 16-byte aligned");
+        *out = dst;
+        return MAPF_OK;
+    }
+    HIP_TRY(buf.reserve(count * sizeof(T)));
+    *out = static_cast<T *>(buf.ptr);
+    return MAPF_OK;
+}
+
+template <typename T>
+int fetch_out(mapf_handle_t h, const T *dev, T *dst, size_t count) {
+    if (!dst || h->device_ptrs) return MAPF_OK;
+    HIP_TRY(hipMemcpyAsync(dst, dev, count * sizeof(T), hipMemcpyDeviceToHost, h->stream));
+    return MAPF_OK;
+}
+
+void destroy_impl(mapf_handle_t h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (DeviceBuf *b : {&h->s_actions, &h->s_uniforms, &h->s_local, &h->s_reward, &h->s_prob, &h->s_done,
+                         &h->s_coll, &h->s_term, &h->s_mask, &h->s_ret, &h->s_epi, &h->s_ncoll})
+        b->release();
+    if (h->nbr4) (void)hipFree(h->nbr4);
+    if (h->state) (void)hipFree(h->state);
+    if (h->start) (void)hipFree(h->start);
+    if (h->goal) (void)hipFree(h->goal);
+    if (h->ev_begin) (void)hipEventDestroy(h->ev_begin);
+    if (h->ev_end) (void)hipEventDestroy(h->ev_end);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mapf_last_error(void) { return g_last_error.c_str(); }
+
+const char *mapf_version(void) { return "mapf_hip 0.1.0 (abi 1, gfx950)"; }
+
+int mapf_device_count(int *out_count) {
+    if (!out_count) return fail(MAPF_EINVAL, "out_count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *out_count = 0; (void)hipGetLastError(); return fail(MAPF_ENODEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e)); }
+    *out_count = n;
+    return MAPF_OK;
+}
+
+int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
+    if (!d || !out_handle) return fail(MAPF_EINVAL, "null descriptor or output");
+    *out_handle = nullptr;
+    if (d->struct_size != sizeof(mapf_desc)) return fail(MAPF_EINVAL, "mapf_desc.struct_size does not match this library");
+    if (d->n_cells == 0 || d->n_cells > 65536u) return fail(MAPF_EINVAL, "n_cells must be in 1..65536 (uint16 local ids)");
+    if (d->n_agents == 0) return fail(MAPF_EINVAL, "n_agents must be >= 1");
+    if (d->n_agents > MAPF_MAX_AGENTS) return fail(MAPF_EUNSUPPORTED, "n_agents beyond MAPF_MAX_AGENTS (32)");
+    if (d->criteria > MAPF_SOC) return fail(MAPF_EINVAL, "criteria must be MAPF_MAKESPAN or MAPF_SOC");
+    if (!d->nbr || !d->start || !d->goal) return fail(MAPF_EINVAL, "nbr/start/goal must be non-null host pointers");
+    if (!std::isfinite(d->fail_prob) || !std::isfinite(d->r_clash) || !std::isfinite(d->r_goal) || !std::isfinite(d->r_living))
+        return fail(MAPF_EINVAL, "fail_prob and rewards must be finite");
+    if (d->n_envs > (uint64_t(1) << 31)) return fail(MAPF_EINVAL, "n_envs too large for one handle");
+
+    const uint32_t V = d->n_cells, A = d->n_agents;
+    const uint64_t E = d->n_envs;
+    const bool sb = d->flags & MAPF_FLAG_START_BROADCAST, gb = d->flags & MAPF_FLAG_GOAL_BROADCAST;
+    for (uint64_t i = 0; i < uint64_t(V) * 5; ++i)
+        if (d->nbr[i] >= V) return fail(MAPF_EINVAL, "nbr entry out of range");
+    for (uint32_t v = 0; v < V; ++v)
+        if (d->nbr[uint64_t(v) * 5] != v) return fail(MAPF_EINVAL, "nbr[v][STAY] must be v");
+    const uint64_t n_start = (sb ? 1 : E) * A, n_goal = (gb ? 1 : E) * A;
+    for (uint64_t i = 0; i < n_start; ++i)
+        if (d->start[i] >= V) return fail(MAPF_EINVAL, "start cell out of range");
+    for (uint64_t i = 0; i < n_goal; ++i)
+        if (d->goal[i] >= V) return fail(MAPF_EINVAL, "goal cell out of range");
+
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        (void)hipGetLastError();
+        return fail(MAPF_ENODEVICE, std::string("no HIP device available (") + hipGetErrorString(e) +
+                                        "); this library has no CPU fallback");
+    }
+    if (d->device < 0 || d->device >= n_dev) return fail(MAPF_EINVAL, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(d->device));
+
+    mapf_handle_t h = new (std::nothrow) mapf_handle_s();
+    if (!h) return fail(MAPF_EHIP, "out of host memory");
+    h->device = d->device; h->V = V; h->A = A; h->E = E; h->flags = d->flags;
+    h->env_id_offset = d->env_id_offset; h->t = 0;
+    h->start_broadcast = sb; h->goal_broadcast = gb;
+    h->device_ptrs = d->flags & MAPF_FLAG_DEVICE_PTRS;
+
+    // mapf_env.py:131-132 and :167-169, evaluated left to right in IEEE double like CPython
+    const double rf = d->fail_prob / 2, lf = d->fail_prob / 2;
+    const double p0 = (1 - rf) - lf;
+    h->c.p0 = p0; h->c.rf = rf; h->c.lf = lf;
+    h->c.keep = (p0 > 0 ? 1u : 0u) | (rf > 0 ? 2u : 0u) | (lf > 0 ? 4u : 0u);
+    h->c.r_clash = d->r_clash; h->c.r_goal = d->r_goal; h->c.r_living = d->r_living;
+    h->c.criteria = d->criteria; h->c.n_cells = V;
+    h->c.seed_lo = uint32_t(d->seed); h->c.seed_hi = uint32_t(d->seed >> 32);
+    const uint64_t pol = d->seed + 1;
+    h->c.pol_lo = uint32_t(pol); h->c.pol_hi = uint32_t(pol >> 32);
+
+#define CREATE_TRY(expr)                                                   \
+    do {                                                                   \
+        hipError_t _e = (expr);                                            \
+        if (_e != hipSuccess) { destroy_impl(h); return hip_fail(_e, #expr); } \
+    } while (0)
+
+    if (d->stream) { h->stream = static_cast<hipStream_t>(d->stream); h->own_stream = false; }
+    else { CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking)); h->own_stream = true; }
+    CREATE_TRY(hipEventCreate(&h->ev_begin));
+    CREATE_TRY(hipEventCreate(&h->ev_end));
+
+    // pack nbr[V][5] into {up | right << 16, down | left << 16}
+    std::vector<uint2> packed(V);
+    for (uint32_t v = 0; v < V; ++v) {
+        const uint16_t *r = d->nbr + uint64_t(v) * 5;
+        packed[v] = make_uint2(uint32_t(r[1]) | (uint32_t(r[2]) << 16), uint32_t(r[3]) | (uint32_t(r[4]) << 16));
+    }
+    const size_t row = size_t(A) * sizeof(uint16_t);
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->nbr4), size_t(V) * sizeof(uint2)));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->state), (E ? E : 1) * row));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->start), (sb ? 1 : (E ? E : 1)) * row));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->goal), (gb ? 1 : (E ? E : 1)) * row));
+    CREATE_TRY(hipMemcpy(h->nbr4, packed.data(), size_t(V) * sizeof(uint2), hipMemcpyHostToDevice));
+    if (n_start) CREATE_TRY(hipMemcpy(h->start, d->start, n_start * sizeof(uint16_t), hipMemcpyHostToDevice));
+    if (n_goal) CREATE_TRY(hipMemcpy(h->goal, d->goal, n_goal * sizeof(uint16_t), hipMemcpyHostToDevice));
+    CREATE_TRY(mapf::launch_reset(int(A), h->state, h->start, sb, nullptr, E, h->stream));
+    CREATE_TRY(hipStreamSynchronize(h->stream));
+#undef CREATE_TRY
+    *out_handle = h;
+    return MAPF_OK;
+}
+
+int mapf_destroy(mapf_handle_t h) {
+    if (!h) return fail(MAPF_EINVAL, "null handle");
+    destroy_impl(h);
+    return MAPF_OK;
+}
+
+int mapf_sync(mapf_handle_t h) {
+    if (int rc = check_handle(h)) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MAPF_OK;
+}
+
+int mapf_get_stream(mapf_handle_t h, void **out_stream) {
+    if (!h || !out_stream) return fail(MAPF_EINVAL, "null handle or output");
+    *out_stream = static_cast<void *>(h->stream);
+    return MAPF_OK;
+}
+
+int mapf_timer_begin(mapf_handle_t h) {
+    if (int rc = check_handle(h)) return rc;
+    HIP_TRY(hipEventRecord(h->ev_begin, h->stream));
+    return MAPF_OK;
+}
+
+int mapf_timer_end(mapf_handle_t h, double *out_ms) {
+    if (int rc = check_handle(h)) return rc;
+    if (!out_ms) return fail(MAPF_EINVAL, "out_ms is null");
+    HIP_TRY(hipEventRecord(h->ev_end, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev_end));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev_begin, h->ev_end));
+    *out_ms = double(ms);
+    return MAPF_OK;
+}
+
+int mapf_reset(mapf_handle_t h, const uint8_t *mask) {
+    if (int rc = check_handle(h)) return rc;
+    const uint8_t *d_mask = nullptr;
+    if (int rc = stage_in(h, h->s_mask, mask, size_t(h->E), &d_mask, "mask")) return rc;
+    HIP_TRY(mapf::launch_reset(int(h->A), h->state, h->start, h->start_broadcast, d_mask, h->E, h->stream));
+    if (!h->device_ptrs) HIP_TRY(hipStreamSynchronize(h->stream));
+    return MAPF_OK;
+}
+
+int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, uint16_t *out_local,
+              double *out_reward, uint8_t *out_done, uint8_t *out_collision, double *out_prob,
+              uint8_t *out_was_terminal, uint32_t step_flags) {
+    if (int rc = check_handle(h)) return rc;
+    if (!actions) return fail(MAPF_EINVAL, "actions is null");
+    if (step_flags & ~MAPF_STEP_AUTO_RESET) return fail(MAPF_EINVAL, "unknown step flag");
+    const size_t E = size_t(h->E), EA = E * h->A;
+    mapf::StepArgs a{};
+    a.c = h->c; a.nbr4 = h->nbr4; a.state = h->state; a.start = h->start; a.goal = h->goal;
+    a.n_envs = h->E; a.env_id_offset = h->env_id_offset; a.t = h->t;
+    a.start_broadcast = h->start_broadcast; a.goal_broadcast = h->goal_broadcast;
+    a.auto_reset = step_flags & MAPF_STEP_AUTO_RESET;
+    if (int rc = stage_in(h, h->s_actions, actions, EA, &a.actions, "actions")) return rc;
+    if (int rc = stage_in(h, h->s_uniforms, uniforms, EA, &a.uniforms, "uniforms")) return rc;
+    if (int rc = stage_out(h, h->s_local, out_local, EA, &a.out_local, "out_local")) return rc;
+    if (int rc = stage_out(h, h->s_reward, out_reward, E, &a.out_reward, "out_reward")) return rc;
+    if (int rc = stage_out(h, h->s_prob, out_prob, E, &a.out_prob, "out_prob")) return rc;
+    if (int rc = stage_out(h, h->s_done, out_done, E, &a.out_done, "out_done")) return rc;
+    if (int rc = stage_out(h, h->s_coll, out_collision, E, &a.out_collision, "out_collision")) return rc;
+    if (int rc = stage_out(h, h->s_term, out_was_terminal, E, &a.out_was_terminal, "out_was_terminal")) return rc;
+    HIP_TRY(mapf::launch_step(int(h->A), a, h->stream));
+    h->t += 1;
+    if (!h->device_ptrs) {
+        if (int rc = fetch_out(h, a.out_local, out_local, EA)) return rc;
+        if (int rc = fetch_out(h, a.out_reward, out_reward, E)) return rc;
+        if (int rc = fetch_out(h, a.out_prob, out_prob, E)) return rc;
+        if (int rc = fetch_out(h, a.out_done, out_done, E)) return rc;
+        if (int rc = fetch_out(h, a.out_collision, out_collision, E)) return rc;
+        if (int rc = fetch_out(h, a.out_was_terminal, out_was_terminal, E)) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return MAPF_OK;
+}
+
+int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
+    if (int rc = check_handle(h)) return rc;
+    if (!io || io->struct_size != sizeof(mapf_rollout_io)) return fail(MAPF_EINVAL, "bad mapf_rollout_io");
+    if (io->step_flags & ~MAPF_STEP_AUTO_RESET) return fail(MAPF_EINVAL, "unknown step flag");
+    const size_t E = size_t(h->E), T = io->n_steps, TE = T * E, TEA = TE * h->A;
+    mapf::RolloutArgs a{};
+    a.c = h->c; a.nbr4 = h->nbr4; a.state = h->state; a.start = h->start; a.goal = h->goal;
+    a.n_envs = h->E; a.env_id_offset = h->env_id_offset; a.t = h->t; a.n_steps = io->n_steps;
+    a.start_broadcast = h->start_broadcast; a.goal_broadcast = h->goal_broadcast;
+    a.auto_reset = io->step_flags & MAPF_STEP_AUTO_RESET;
+    a.accumulate = io->accumulate != 0;
+    if (h->device_ptrs) {
+        for (const void *p : {(const void *)io->actions, (const void *)io->out_returns, (const void *)io->out_episodes,
+                              (const void *)io->out_collisions, (const void *)io->rec_local, (const void *)io->rec_reward,
+                              (const void *)io->rec_done, (const void *)io->rec_collision, (const void *)io->rec_prob})
+            if (p && misaligned(p)) return fail(MAPF_EINVAL, "rollout: device pointers must be 16-byte aligned");
+        a.actions = io->actions; a.out_returns = io->out_returns; a.out_episodes = io->out_episodes;
+        a.out_collisions = io->out_collisions; a.rec_local = io->rec_local; a.rec_reward = io->rec_reward;
+        a.rec_done = io->rec_done; a.rec_collision = io->rec_collision; a.rec_prob = io->rec_prob;
+        HIP_TRY(mapf::launch_rollout(int(h->A), a, h->stream));
+        h->t += io->n_steps;
+        return MAPF_OK;
+    }
+    // host-pointer mode: stage everything through device scratch
+    if (int rc = stage_in(h, h->s_actions, io->actions, TEA, &a.actions, "actions")) return rc;
+    if (io->out_returns) {
+        HIP_TRY(h->s_ret.reserve(E * sizeof(double)));
+        a.out_returns = static_cast<double *>(h->s_ret.ptr);
+        if (a.accumulate) HIP_TRY(hipMemcpyAsync(a.out_returns, io->out_returns, E * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    }
+    if (io->out_episodes) {
+        HIP_TRY(h->s_epi.reserve(E * sizeof(uint32_t)));
+        a.out_episodes = static_cast<uint32_t *>(h->s_epi.ptr);
+        if (a.accumulate) HIP_TRY(hipMemcpyAsync(a.out_episodes, io->out_episodes, E * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    }
+    if (io->out_collisions) {
+        HIP_TRY(h->s_ncoll.reserve(E * sizeof(uint32_t)));
+        a.out_collisions = static_cast<uint32_t *>(h->s_ncoll.ptr);
+        if (a.accumulate) HIP_TRY(hipMemcpyAsync(a.out_collisions, io->out_collisions, E * sizeof(uint32_t), hipMemcpyHostToDevice, h->stream));
+    }
+    if (int rc = stage_out(h, h->s_local, io->rec_local, TEA, &a.rec_local, "rec_local")) return rc;
+    if (int rc = stage_out(h, h->s_reward, io->rec_reward, TE, &a.rec_reward, "rec_reward")) return rc;
+    if (int rc = stage_out(h, h->s_prob, io->rec_prob, TE, &a.rec_prob, "rec_prob")) return rc;
+    if (int rc = stage_out(h, h->s_done, io->rec_done, TE, &a.rec_done, "rec_done")) return rc;
+    if (int rc = stage_out(h, h->s_coll, io->rec_collision, TE, &a.rec_collision, "rec_collision")) return rc;
+    HIP_TRY(mapf::launch_rollout(int(h->A), a, h->stream));
+    h->t += io->n_steps;
+    if (int rc = fetch_out(h, a.out_returns, io->out_returns, E)) return rc;
+    if (int rc = fetch_out(h, a.out_episodes, io->out_episodes, E)) return rc;
+    if (int rc = fetch_out(h, a.out_collisions, io->out_collisions, E)) return rc;
+    if (int rc = fetch_out(h, a.rec_local, io->rec_local, TEA)) return rc;
+    if (int rc = fetch_out(h, a.rec_reward, io->rec_reward, TE)) return rc;
+    if (int rc = fetch_out(h, a.rec_prob, io->rec_prob, TE)) return rc;
+    if (int rc = fetch_out(h, a.rec_done, io->rec_done, TE)) return rc;
+    if (int rc = fetch_out(h, a.rec_collision, io->rec_collision, TE)) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return MAPF_OK;
+}
+
+int mapf_fill_random_actions(mapf_handle_t h, uint8_t *actions, uint64_t t0, uint32_t n_steps) {
+    if (int rc = check_handle(h)) return rc;
+    if (!actions) return fail(MAPF_EINVAL, "actions is null");
+    const size_t n = size_t(n_steps) * size_t(h->E) * h->A;
+    uint8_t *d_actions = nullptr;
+    if (int rc = stage_out(h, h->s_actions, actions, n, &d_actions, "actions")) return rc;
+    HIP_TRY(mapf::launch_fill_actions(int(h->A), d_actions, h->c, h->env_id_offset, h->E, t0, n_steps, h->stream));
+    if (int rc = fetch_out(h, d_actions, actions, n)) return rc;
+    if (!h->device_ptrs) HIP_TRY(hipStreamSynchronize(h->stream));
+    return MAPF_OK;
+}
+
+int mapf_query_terminal(mapf_handle_t h, uint8_t *out_terminal) {
+    if (int rc = check_handle(h)) return rc;
+    if (!out_terminal) return fail(MAPF_EINVAL, "out_terminal is null");
+    uint8_t *d_out = nullptr;
+    if (int rc = stage_out(h, h->s_term, out_terminal, size_t(h->E), &d_out, "out_terminal")) return rc;
+    HIP_TRY(mapf::launch_query_terminal(int(h->A), h->state, h->goal, h->goal_broadcast, d_out, h->E, h->stream));
+    if (int rc = fetch_out(h, d_out, out_terminal, size_t(h->E))) return rc;
+    if (!h->device_ptrs) HIP_TRY(hipStreamSynchronize(h->stream));
+    return MAPF_OK;
+}
+
+int mapf_get_state(mapf_handle_t h, uint16_t *local, uint64_t *t) {
+    if (int rc = check_handle(h)) return rc;
+    if (t) *t = h->t;
+    if (local) {
+        const size_t bytes = size_t(h->E) * h->A * sizeof(uint16_t);
+        HIP_TRY(hipMemcpyAsync(local, h->state, bytes, h->device_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, h->stream));
+        if (!h->device_ptrs) HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return MAPF_OK;
+}
+
+int mapf_set_state(mapf_handle_t h, const uint16_t *local, uint64_t t) {
+    if (int rc = check_handle(h)) return rc;
+    if (local) {
+        const size_t n = size_t(h->E) * h->A;
+        if (!h->device_ptrs) {
+            for (size_t i = 0; i < n; ++i)
+                if (local[i] >= h->V) return fail(MAPF_EINVAL, "set_state: cell out of range");
+        }
+        HIP_TRY(hipMemcpyAsync(h->state, local, n * sizeof(uint16_t),
+                               h->device_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+        if (!h->device_ptrs) HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    h->t = t;
+    return MAPF_OK;
+}
+
+}  // extern "C"

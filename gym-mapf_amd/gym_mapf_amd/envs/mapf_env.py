@@ -1,0 +1,230 @@
+"""MapfEnv -- the reference's scalar gym environment, stepped on the GPU.
+
+Same constructor, attributes and ``reset()/step()/render()`` surface as the reference's
+``gym_mapf/envs/mapf_env.py`` (:115-322): joint states and actions are Python ints in
+mixed radix (agent 0 least significant; base V for states, base 5 for actions), locations
+are ``(row, col)``.  ``step()`` decodes the joint action, draws one uniform per agent from
+``self.np_random`` in agent order (as the reference does at :253-257) and hands both to a
+one-env ``VecMapfEnv`` -- the transition itself (slip, collision, reward, done) is computed
+by the HIP kernel.  For throughput use ``VecMapfEnv`` directly.
+"""
+import hashlib
+import struct
+
+import numpy as np
+
+from gym_mapf_amd.envs import (ACTIONS, ACTIONS_TO_INT, ALL_STAY_JOINT_ACTION, DOWN, LEFT, MAPS_PATH, POSSIBILITIES,
+                               RIGHT, STAY, UP, integer_to_vector, integer_to_vector_multiple_numbers,
+                               map_name_to_files, vector_to_integer, vector_to_integer_multiple_numbers)
+from gym_mapf_amd.envs.grid import EmptyCell, MapfGrid, ObstacleCell
+from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv
+
+try:  # gym / gymnasium are optional: subclass gym.Env when one is installed
+    import gym as _gym
+    from gym import spaces as _spaces
+except ImportError:  # pragma: no cover - depends on the host
+    try:
+        import gymnasium as _gym
+        from gymnasium import spaces as _spaces
+    except ImportError:
+        _gym = _spaces = None
+
+try:
+    from colorama import Fore as _Fore
+except ImportError:  # pragma: no cover - colour is cosmetic
+    class _Fore:
+        RED = GREEN = YELLOW = BLUE = RESET = ''
+
+CELL_TO_CHAR = {EmptyCell: '.', ObstacleCell: '@'}
+ACTION_TO_CHAR = {UP: '^', RIGHT: '>', DOWN: 'V', LEFT: '<', STAY: 'S'}
+GYM_MAPF_SEED = 42
+
+_EnvBase = _gym.Env if _gym is not None else object
+
+
+class _Discrete:
+    """Minimal stand-in for gym.spaces.Discrete when no gym flavour is installed."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def contains(self, x):
+        return isinstance(x, int) and 0 <= x < self.n
+
+    def __repr__(self):
+        return 'Discrete(%d)' % self.n
+
+
+def _make_discrete(n):
+    if _spaces is not None:
+        try:
+            return _spaces.Discrete(n)
+        except Exception:  # nS overflows int64 for larger instances; gym 0.13 stored any int
+            pass
+    return _Discrete(n)
+
+
+def np_random(seed=None):
+    """``(RandomState, seed)`` seeded the way gym==0.13.0's ``gym.utils.seeding.np_random`` does
+    (sha512 of ``str(seed)``, first 8 bytes + 4 zero bytes, as base-2**32 digits).  The reference
+    calls it at mapf_env.py:139; gym is a third-party package absent from the reference tree, so
+    this stream is NOT pinned by any reference fixture."""
+    digest = hashlib.sha512(str(seed).encode('utf8')).digest()[:8] + b'\0' * 4
+    value = sum(w << (32 * i) for i, w in enumerate(struct.unpack('3I', digest)))
+    words = []
+    while value > 0:
+        value, low = divmod(value, 2 ** 32)
+        words.append(low)
+    rng = np.random.RandomState()
+    rng.seed(words)
+    return rng, seed
+
+
+# ------------------------------------------------------------ noise-free moves (host utility)
+_DELTA = {UP: (-1, 0), DOWN: (1, 0), LEFT: (0, -1), RIGHT: (0, 1), STAY: (0, 0)}
+
+
+def execute_action(grid, s, noised_action):
+    """Move every location of ``s`` by its action: clamp at the map border, stay put if the
+    clamped target is an obstacle (reference mapf_env.py:43-94).  Host-side helper for callers
+    and tests; the device path uses the table ``MapfGrid.tables()`` builds from the same rule."""
+    n_rows, n_cols = len(grid), len(grid[0])
+    moved = []
+    for loc, action in zip(s, noised_action):
+        dr, dc = _DELTA[action]
+        target = (min(max(loc[0] + dr, 0), n_rows - 1), min(max(loc[1] + dc, 0), n_cols - 1))
+        moved.append(loc if grid[target] is ObstacleCell else target)
+    return tuple(moved)
+
+
+def vector_action_to_integer(a):
+    """Reference mapf_env.py:97-98."""
+    return vector_to_integer(a, [len(ACTIONS)] * len(a), lambda x: ACTIONS.index(x))
+
+
+def integer_action_to_vector(a, n_agents):
+    """Reference mapf_env.py:101-102."""
+    return integer_to_vector(a, [len(ACTIONS)] * n_agents, n_agents, lambda n: ACTIONS[n])
+
+
+class MapfEnv(_EnvBase):
+    def __init__(self, grid, n_agents, start_locations, goal_locations, fail_prob,
+                 reward_of_collision, reward_of_goal, reward_of_living, optimization_criteria):
+        self.grid = grid
+        self.agents_starts, self.agents_goals = start_locations, goal_locations
+        self.n_agents = n_agents
+        self.fail_prob = fail_prob
+        self.right_fail = self.fail_prob / 2
+        self.left_fail = self.fail_prob / 2
+        self.reward_of_clash = reward_of_collision
+        self.reward_of_goal = reward_of_goal
+        self.reward_of_living = reward_of_living
+        self.optimization_criteria = optimization_criteria
+
+        self.np_random, self.seed = np_random(GYM_MAPF_SEED)
+
+        self.valid_locations, self.loc_to_int, _ = grid.tables()
+        self.nS = len(self.valid_locations) ** self.n_agents
+        self.nA = len(ACTIONS) ** self.n_agents
+        self.action_space = _make_discrete(self.nA)
+        self.observation_space = _make_discrete(self.nS)
+
+        self._vec = None        # one-env VecMapfEnv, created on first use (needs the GPU)
+        self._terminal = None   # is_terminal(self.s) if known
+        self.reset()
+        self.locations_to_state(self.agents_goals)   # KeyError if a goal is an obstacle
+        self.lastaction = None
+
+    # -------------------------------------------------------------- state <-> device
+    @property
+    def s(self):
+        return self._s
+
+    @s.setter
+    def s(self, value):
+        local = integer_to_vector(value, [len(self.valid_locations)] * self.n_agents, self.n_agents, lambda x: x)
+        self._s, self._local, self._terminal = value, local, None
+        if self._vec is not None:
+            self._vec.set_state(np.asarray([local], dtype=np.uint16))
+
+    def _device(self):
+        if self._vec is None:
+            self._vec = VecMapfEnv(self.grid, self.n_agents, self.agents_starts, self.agents_goals,
+                                   self.fail_prob, self.reward_of_clash, self.reward_of_goal,
+                                   self.reward_of_living, self.optimization_criteria, n_envs=1)
+            self._vec.set_state(np.asarray([self._local], dtype=np.uint16))
+        return self._vec
+
+    def __copy__(self):
+        twin = object.__new__(type(self))
+        twin.__dict__.update(self.__dict__)   # shares grid and np_random like the reference's copy
+        twin._vec = None                      # ... but owns its own device state
+        return twin
+
+    def close(self):
+        if self._vec is not None:
+            self._vec.close()
+            self._vec = None
+
+    # ------------------------------------------------------------------ gym surface
+    def reset(self):
+        """Back to the start locations; the RNG is not reseeded (reference :290-293)."""
+        self.lastaction = None
+        self.s = self.locations_to_state(self.agents_starts)
+        return self.s
+
+    def step(self, a: int):
+        """Reference mapf_env.py:237-266; the transition is computed by the HIP kernel."""
+        dev = self._device()
+        if self._terminal is None:
+            self._terminal = bool(dev.query_terminal()[0])
+        if self._terminal:
+            return self.s, 0, True, {"prob": 0}
+        digits = integer_to_vector(a, [len(ACTIONS)] * self.n_agents, self.n_agents, lambda n: n)
+        uniforms = [self.np_random.rand() for _ in range(self.n_agents)]
+        local, reward, done, info = dev.step(np.asarray([digits], dtype=np.uint8),
+                                             uniforms=np.asarray([uniforms], dtype=np.float64))
+        self._local = tuple(int(x) for x in local[0])
+        self._s = vector_to_integer(self._local, [len(self.valid_locations)] * self.n_agents, lambda x: x)
+        done = bool(done[0])
+        self._terminal = None if done else False   # a done state may (vertex/goal) or may not (swap) be terminal
+        return self._s, float(reward[0]), done, {"prob": float(info['prob'][0]),
+                                                 "collision": bool(info['collision'][0])}
+
+    def render(self, mode='human'):
+        """ASCII picture, same priorities as the reference (:295-322): '*' where agents share a
+        cell, an agent's index (green on its own goal, yellow elsewhere), a goal's owner in blue,
+        else the map character."""
+        where = self.state_to_locations(self.s)
+        goals = tuple(tuple(g) for g in self.agents_goals)
+        for r in range(len(self.grid)):
+            row = self.grid[r]
+            for c in range(len(row)):
+                here = (r, c)
+                if here in where:
+                    first = where.index(here)
+                    if here in where[first + 1:]:
+                        token = _Fore.RED + '*' + _Fore.RESET
+                    elif here in goals and goals.index(here) == first:
+                        token = _Fore.GREEN + str(first) + _Fore.RESET
+                    else:
+                        token = _Fore.YELLOW + str(first) + _Fore.RESET
+                elif here in goals:
+                    token = _Fore.BLUE + str(goals.index(here)) + _Fore.RESET
+                else:
+                    token = CELL_TO_CHAR[row[c]]
+                print(token, end=' ')
+            print('')
+
+    # ------------------------------------------------------------------ joint codecs
+    def state_to_locations(self, state):
+        """Joint state int -> tuple of (row, col), agent 0 first (reference :358-362)."""
+        return integer_to_vector(state, [len(self.valid_locations)] * self.n_agents, self.n_agents,
+                                 lambda x: self.valid_locations[x])
+
+    def locations_to_state(self, locs):
+        """Tuple of (row, col) -> joint state int (reference :364-371)."""
+        if self.n_agents != len(locs):
+            raise AssertionError(f'{locs} locations number is different than the number of agents {self.n_agents}')
+        local = tuple(self.loc_to_int[tuple(loc)] for loc in locs)
+        return vector_to_integer(local, [len(self.valid_locations)] * len(local), lambda x: x)

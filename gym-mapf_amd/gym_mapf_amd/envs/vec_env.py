@@ -1,0 +1,310 @@
+"""VecMapfEnv -- E concurrent MAPF environments stepped by one HIP kernel launch.
+
+This is the batched form of the reference's ``MapfEnv`` (gym_mapf/envs/mapf_env.py:115-266):
+same constructor arguments, same transition semantics per env, but state, actions and
+results are env-major arrays (``x[e, i]`` = agent i of env e) and the work happens in
+``libmapf_hip.so``.  Two memory modes:
+
+* host mode (default): numpy arrays in, numpy arrays out, each call synchronises;
+* device mode (``device_arrays=True``): torch CUDA tensors in/out, calls only enqueue on the
+  env's HIP stream -- call ``sync()`` before reading results on another stream.
+
+There is no CPU implementation behind this class: without the library or a GPU the
+constructor raises ``MapfNativeError``.
+"""
+import ctypes
+import enum
+
+import numpy as np
+
+from gym_mapf_amd import _native as nat
+
+
+class OptimizationCriteria(enum.Enum):
+    """Reference mapf_env.py:31-33."""
+    SoC = 'SoC'
+    Makespan = 'Makespan'
+
+
+_CRITERIA_CODE = {OptimizationCriteria.Makespan: nat.MAPF_MAKESPAN, OptimizationCriteria.SoC: nat.MAPF_SOC}
+
+
+def _locs_to_local(loc_to_int, locs):
+    """(row, col) sequence -> local ids; KeyError for obstacles / out-of-map cells (reference :143, :369)."""
+    return [loc_to_int[(int(l[0]), int(l[1]))] for l in locs]
+
+
+class VecMapfEnv:
+    def __init__(self, grid, n_agents, start_locations, goal_locations, fail_prob,
+                 reward_of_collision, reward_of_goal, reward_of_living, optimization_criteria,
+                 *, n_envs=None, seed=42, env_id_offset=0, device=0, device_arrays=False, stream=None,
+                 start_local=None, goal_local=None):
+        self.grid = grid
+        self.n_agents = int(n_agents)
+        self.fail_prob = fail_prob
+        self.reward_of_clash = reward_of_collision
+        self.reward_of_goal = reward_of_goal
+        self.reward_of_living = reward_of_living
+        self.optimization_criteria = optimization_criteria
+        self.seed = int(seed)
+        self.env_id_offset = int(env_id_offset)
+        self.device = int(device)
+        self.device_arrays = bool(device_arrays)
+        self.valid_locations, self.loc_to_int, self._nbr = grid.tables()
+        self.n_cells = len(self.valid_locations)
+
+        start, start_bcast = self._as_local(start_locations, start_local, 'start')
+        goal, goal_bcast = self._as_local(goal_locations, goal_local, 'goal')
+        if n_envs is None:
+            n_envs = 1
+            for arr, bc in ((start, start_bcast), (goal, goal_bcast)):
+                if not bc:
+                    n_envs = arr.shape[0]
+        self.n_envs = int(n_envs)
+        for arr, bc, what in ((start, start_bcast, 'start'), (goal, goal_bcast, 'goal')):
+            if not bc and arr.shape[0] != self.n_envs:
+                raise ValueError('%s_locations has %d envs, expected %d' % (what, arr.shape[0], self.n_envs))
+        self.start_local, self.goal_local = start, goal
+        self._start_bcast, self._goal_bcast = start_bcast, goal_bcast
+
+        flags = 0
+        flags |= nat.MAPF_FLAG_START_BROADCAST if start_bcast else 0
+        flags |= nat.MAPF_FLAG_GOAL_BROADCAST if goal_bcast else 0
+        flags |= nat.MAPF_FLAG_DEVICE_PTRS if self.device_arrays else 0
+        nbr = np.ascontiguousarray(self._nbr, dtype=np.uint16)
+        desc = nat.MapfDesc(
+            struct_size=ctypes.sizeof(nat.MapfDesc), n_cells=self.n_cells, n_agents=self.n_agents,
+            criteria=_CRITERIA_CODE[optimization_criteria], n_envs=self.n_envs,
+            env_id_offset=self.env_id_offset, seed=self.seed & 0xFFFFFFFFFFFFFFFF,
+            nbr=nbr.ctypes.data, start=start.ctypes.data, goal=goal.ctypes.data,
+            fail_prob=float(fail_prob), r_clash=float(reward_of_collision), r_goal=float(reward_of_goal),
+            r_living=float(reward_of_living), device=self.device, flags=flags,
+            stream=(int(stream) if stream else None))
+        self._lib = nat.load()
+        handle = ctypes.c_void_p()
+        nat.check(self._lib.mapf_create(ctypes.byref(desc), ctypes.byref(handle)))
+        self._h = handle
+        self._torch = None
+        if self.device_arrays:
+            import torch
+            self._torch = torch
+            self._tdev = torch.device('cuda', self.device)
+
+    # ------------------------------------------------------------------ construction
+    def _as_local(self, locations, local_ids, what):
+        """``locations``: A (row, col) pairs shared by every env, or an [E, A, 2] array of
+        per-env locations.  ``local_ids`` (keyword form): integer [A] or [E, A] local ids."""
+        A = self.n_agents
+        if local_ids is not None:
+            ids = np.asarray(local_ids)
+            if ids.ndim == 1:
+                ids = ids.reshape(1, -1)
+            if ids.ndim != 2 or ids.shape[1] != A or not np.issubdtype(ids.dtype, np.integer):
+                raise ValueError('%s_local must be an integer array of shape [A] or [E, A]' % what)
+            if ids.size and (ids.min() < 0 or ids.max() >= self.n_cells):
+                raise KeyError('%s_local: local id out of range' % what)
+            return np.ascontiguousarray(ids, dtype=np.uint16), local_ids is not None and np.asarray(local_ids).ndim == 1
+        if len(locations) != A and not (np.asarray(locations).ndim == 3):
+            raise AssertionError('%r locations number is different than the number of agents %d' % (locations, A))
+        arr = np.asarray(locations)
+        if arr.ndim == 2 and arr.shape == (A, 2):
+            return np.asarray(_locs_to_local(self.loc_to_int, arr), dtype=np.uint16).reshape(1, A), True
+        if arr.ndim == 3 and arr.shape[1:] == (A, 2):
+            flat = _locs_to_local(self.loc_to_int, arr.reshape(-1, 2))
+            return np.ascontiguousarray(np.asarray(flat, dtype=np.uint16).reshape(arr.shape[0], A)), False
+        raise ValueError('cannot interpret %s_locations of shape %r' % (what, arr.shape))
+
+    # --------------------------------------------------------------------- plumbing
+    def _ptr(self, arr, dtype, shape, name):
+        """Raw pointer of a caller-supplied array after checking dtype/shape/contiguity."""
+        if arr is None:
+            return None
+        if self.device_arrays:
+            t = self._torch
+            want = {np.uint8: t.uint8, np.uint16: t.uint16, np.float64: t.float64, np.uint32: t.uint32}[dtype]
+            if not (isinstance(arr, t.Tensor) and arr.is_cuda and arr.dtype == want and arr.is_contiguous()
+                    and tuple(arr.shape) == tuple(shape)):
+                raise ValueError('%s must be a contiguous CUDA %s tensor of shape %r' % (name, want, tuple(shape)))
+            return arr.data_ptr()
+        if not (isinstance(arr, np.ndarray) and arr.dtype == dtype and arr.flags.c_contiguous
+                and tuple(arr.shape) == tuple(shape)):
+            raise ValueError('%s must be a C-contiguous %s array of shape %r' % (name, np.dtype(dtype), tuple(shape)))
+        return arr.ctypes.data
+
+    def _empty(self, shape, dtype):
+        if self.device_arrays:
+            t = self._torch
+            td = {np.uint8: t.uint8, np.uint16: t.uint16, np.float64: t.float64, np.uint32: t.uint32}[dtype]
+            return t.empty(shape, dtype=td, device=self._tdev)
+        return np.empty(shape, dtype=dtype)
+
+    def _coerce(self, arr, dtype, shape, name):
+        """Inputs: accept anything array-like in host mode, strict tensors in device mode."""
+        if arr is None or self.device_arrays:
+            return arr
+        out = np.ascontiguousarray(arr, dtype=dtype)
+        if tuple(out.shape) != tuple(shape):
+            raise ValueError('%s must have shape %r, got %r' % (name, tuple(shape), tuple(out.shape)))
+        return out
+
+    # -------------------------------------------------------------------------- API
+    def reset(self, mask=None):
+        """``MapfEnv.reset()`` for all envs, or those with a non-zero mask byte.  No reseed."""
+        mask = self._coerce(mask, np.uint8, (self.n_envs,), 'mask')
+        nat.check(self._lib.mapf_reset(self._h, self._ptr(mask, np.uint8, (self.n_envs,), 'mask')))
+
+    def step(self, actions, uniforms=None, auto_reset=False, out=None):
+        """One ``MapfEnv.step()`` per env.
+
+        actions: uint8 [E, A] (0 STAY, 1 UP, 2 RIGHT, 3 DOWN, 4 LEFT).  uniforms: float64 [E, A]
+        values the reference would draw from ``np_random.rand()`` in agent order, or None for the
+        device Philox stream.  Returns ``(local, reward, done, info)`` with ``local`` uint16
+        [E, A], ``reward`` float64 [E], ``done`` uint8 [E] and ``info`` holding ``prob``,
+        ``collision`` and ``was_terminal`` arrays.  ``out`` may carry preallocated arrays under
+        those names (plus ``local``, ``reward``, ``done``).
+        """
+        E, A = self.n_envs, self.n_agents
+        actions = self._coerce(actions, np.uint8, (E, A), 'actions')
+        uniforms = self._coerce(uniforms, np.float64, (E, A), 'uniforms')
+        out = dict(out) if out else {}
+        spec = (('local', np.uint16, (E, A)), ('reward', np.float64, (E,)), ('done', np.uint8, (E,)),
+                ('collision', np.uint8, (E,)), ('prob', np.float64, (E,)), ('was_terminal', np.uint8, (E,)))
+        for name, dt, shp in spec:
+            if name not in out:
+                out[name] = self._empty(shp, dt)
+        p = {name: self._ptr(out[name], dt, shp, name) for name, dt, shp in spec}
+        nat.check(self._lib.mapf_step(
+            self._h, self._ptr(actions, np.uint8, (E, A), 'actions'),
+            self._ptr(uniforms, np.float64, (E, A), 'uniforms'),
+            p['local'], p['reward'], p['done'], p['collision'], p['prob'], p['was_terminal'],
+            nat.MAPF_STEP_AUTO_RESET if auto_reset else 0))
+        info = {'prob': out['prob'], 'collision': out['collision'], 'was_terminal': out['was_terminal']}
+        return out['local'], out['reward'], out['done'], info
+
+    def prepare_step(self, actions, uniforms=None, auto_reset=False, out=None):
+        """Validate once, call many times: returns ``(call, out)`` where ``call()`` performs
+        ``mapf_step`` on exactly these arrays (the per-call Python cost is one ctypes call).  Meant
+        for device mode, where a training loop refills ``actions`` in place every iteration."""
+        E, A = self.n_envs, self.n_agents
+        actions = self._coerce(actions, np.uint8, (E, A), 'actions')
+        uniforms = self._coerce(uniforms, np.float64, (E, A), 'uniforms')
+        out = dict(out) if out else {}
+        spec = (('local', np.uint16, (E, A)), ('reward', np.float64, (E,)), ('done', np.uint8, (E,)),
+                ('collision', np.uint8, (E,)), ('prob', np.float64, (E,)), ('was_terminal', np.uint8, (E,)))
+        for name, dt, shp in spec:
+            if name not in out:
+                out[name] = self._empty(shp, dt)
+        args = (self._h, self._ptr(actions, np.uint8, (E, A), 'actions'),
+                self._ptr(uniforms, np.float64, (E, A), 'uniforms'),
+                self._ptr(out['local'], np.uint16, (E, A), 'local'), self._ptr(out['reward'], np.float64, (E,), 'reward'),
+                self._ptr(out['done'], np.uint8, (E,), 'done'), self._ptr(out['collision'], np.uint8, (E,), 'collision'),
+                self._ptr(out['prob'], np.float64, (E,), 'prob'),
+                self._ptr(out['was_terminal'], np.uint8, (E,), 'was_terminal'),
+                nat.MAPF_STEP_AUTO_RESET if auto_reset else 0)
+        fn, check, keep = self._lib.mapf_step, nat.check, (actions, uniforms, out)
+
+        def call():
+            rc = fn(*args)
+            if rc:
+                check(rc)
+            return keep
+
+        return call, out
+
+    def rollout(self, n_steps, actions=None, auto_reset=True, record=False, accumulate_into=None):
+        """``n_steps`` fused steps in one launch.  ``actions`` uint8 [T, E, A] or None for the
+        synthetic policy stream.  Returns a dict with ``returns`` f64 [E], ``episodes`` u32 [E],
+        ``collisions`` u32 [E] and, when ``record``, the per-step ``local``/``reward``/``done``/
+        ``collision``/``prob`` trajectories (step-major)."""
+        E, A, T = self.n_envs, self.n_agents, int(n_steps)
+        actions = self._coerce(actions, np.uint8, (T, E, A), 'actions')
+        res = accumulate_into if accumulate_into is not None else {}
+        for name, dt in (('returns', np.float64), ('episodes', np.uint32), ('collisions', np.uint32)):
+            if name not in res:
+                res[name] = self._empty((E,), dt)
+        if record:
+            for name, dt, shp in (('local', np.uint16, (T, E, A)), ('reward', np.float64, (T, E)),
+                                  ('done', np.uint8, (T, E)), ('collision', np.uint8, (T, E)),
+                                  ('prob', np.float64, (T, E))):
+                res[name] = self._empty(shp, dt)
+        io = nat.MapfRolloutIO(
+            struct_size=ctypes.sizeof(nat.MapfRolloutIO), n_steps=T,
+            step_flags=nat.MAPF_STEP_AUTO_RESET if auto_reset else 0,
+            accumulate=1 if accumulate_into is not None else 0,
+            actions=self._ptr(actions, np.uint8, (T, E, A), 'actions'),
+            out_returns=self._ptr(res['returns'], np.float64, (E,), 'returns'),
+            out_episodes=self._ptr(res['episodes'], np.uint32, (E,), 'episodes'),
+            out_collisions=self._ptr(res['collisions'], np.uint32, (E,), 'collisions'),
+            rec_local=self._ptr(res.get('local') if record else None, np.uint16, (T, E, A), 'local'),
+            rec_reward=self._ptr(res.get('reward') if record else None, np.float64, (T, E), 'reward'),
+            rec_done=self._ptr(res.get('done') if record else None, np.uint8, (T, E), 'done'),
+            rec_collision=self._ptr(res.get('collision') if record else None, np.uint8, (T, E), 'collision'),
+            rec_prob=self._ptr(res.get('prob') if record else None, np.float64, (T, E), 'prob'))
+        nat.check(self._lib.mapf_rollout(self._h, ctypes.byref(io)))
+        return res
+
+    def fill_random_actions(self, t0, n_steps, out=None):
+        """Synthetic policy stream: uint8 [n_steps, E, A] uniform over the 5 actions."""
+        shape = (int(n_steps), self.n_envs, self.n_agents)
+        if out is None:
+            out = self._empty(shape, np.uint8)
+        nat.check(self._lib.mapf_fill_random_actions(self._h, self._ptr(out, np.uint8, shape, 'out'),
+                                                     int(t0), int(n_steps)))
+        return out
+
+    def query_terminal(self, out=None):
+        """``MapfEnv.is_terminal`` of every env's current state: uint8 [E]."""
+        if out is None:
+            out = self._empty((self.n_envs,), np.uint8)
+        nat.check(self._lib.mapf_query_terminal(self._h, self._ptr(out, np.uint8, (self.n_envs,), 'out')))
+        return out
+
+    def get_state(self, out=None):
+        """(local uint16 [E, A], step index t)."""
+        shape = (self.n_envs, self.n_agents)
+        if out is None:
+            out = self._empty(shape, np.uint16)
+        t = ctypes.c_uint64(0)
+        nat.check(self._lib.mapf_get_state(self._h, self._ptr(out, np.uint16, shape, 'out'), ctypes.byref(t)))
+        return out, t.value
+
+    def set_state(self, local=None, t=None):
+        shape = (self.n_envs, self.n_agents)
+        local = self._coerce(local, np.uint16, shape, 'local')
+        if t is None:
+            t = self.t
+        nat.check(self._lib.mapf_set_state(self._h, self._ptr(local, np.uint16, shape, 'local'), int(t)))
+
+    @property
+    def t(self):
+        t = ctypes.c_uint64(0)
+        nat.check(self._lib.mapf_get_state(self._h, None, ctypes.byref(t)))
+        return t.value
+
+    def sync(self):
+        nat.check(self._lib.mapf_sync(self._h))
+
+    def timer_begin(self):
+        nat.check(self._lib.mapf_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = ctypes.c_double(0.0)
+        nat.check(self._lib.mapf_timer_end(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    @property
+    def stream(self):
+        s = ctypes.c_void_p()
+        nat.check(self._lib.mapf_get_stream(self._h, ctypes.byref(s)))
+        return s.value
+
+    def close(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h:
+            self._lib.mapf_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,177 @@
+/*
+ * mapf_hip.h -- C ABI of libmapf_hip.so: the MI355X (gfx950) implementation of
+ * gym-mapf's batched MapfEnv.step() hot path.
+ *
+ * The reference has no FFI; its hot path sits behind a Python class
+ * (gym_mapf/envs/mapf_env.py:115 `class MapfEnv`).  Each entry point below
+ * names the reference method/lines it replaces.  The reference-side binding
+ * (ctypes) a maintainer would add is shown in INTEGRATION.md and implemented in
+ * gym-mapf_amd/gym_mapf_amd/_native.py.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative
+ *     MAPF_E* code, and mapf_last_error() (thread-local) holds the message;
+ *   - the handle owns its device buffers and (unless one is supplied) its HIP
+ *     stream; the caller owns every array it passes in;
+ *   - array arguments are HOST pointers unless the handle was created with
+ *     MAPF_FLAG_DEVICE_PTRS, in which case they are DEVICE pointers (e.g.
+ *     torch tensors' data_ptr()) and calls only enqueue work -- use
+ *     mapf_sync() before reading results;
+ *   - one handle is driven by one host thread at a time;
+ *   - layouts are env-major: x[e*A + i] is agent i of env e.  Cells are
+ *     "local ids": the index of a free cell in the reference's column-major
+ *     enumeration (mapf_env.py:142 valid_locations, grid.py:37-40), uint16
+ *     (every reference map has <= 65536 free cells);
+ *   - actions: 0 STAY, 1 UP, 2 RIGHT, 3 DOWN, 4 LEFT
+ *     (gym_mapf/envs/__init__.py:26 ACTIONS); values > 4 are treated as STAY.
+ */
+#ifndef MAPF_HIP_H
+#define MAPF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAPF_ABI_VERSION 1
+
+/* status codes */
+#define MAPF_OK            0
+#define MAPF_EINVAL       -1  /* bad argument / descriptor                   */
+#define MAPF_EHIP         -2  /* HIP runtime error (message has the detail)  */
+#define MAPF_ENODEVICE    -3  /* no usable HIP device                        */
+#define MAPF_EUNSUPPORTED -4  /* e.g. n_agents beyond MAPF_MAX_AGENTS        */
+
+#define MAPF_MAX_AGENTS 32
+
+/* optimisation criteria: mapf_env.py:31-33 OptimizationCriteria */
+#define MAPF_MAKESPAN 0
+#define MAPF_SOC      1
+
+/* mapf_desc.flags */
+#define MAPF_FLAG_DEVICE_PTRS     0x1u  /* array args of step/rollout/... are device pointers */
+#define MAPF_FLAG_START_BROADCAST 0x2u  /* desc.start is [A], shared by all envs              */
+#define MAPF_FLAG_GOAL_BROADCAST  0x4u  /* desc.goal  is [A], shared by all envs              */
+
+/* step_flags / rollout flags */
+#define MAPF_STEP_AUTO_RESET      0x1u  /* after a step returns done, the env's stored state
+                                           goes back to its start cells (mapf_env.py:290-293
+                                           reset(), no reseed) -- the outputs still report the
+                                           state step() returned                              */
+
+typedef struct mapf_handle_s *mapf_handle_t;
+
+/*
+ * Everything MapfEnv.__init__ (mapf_env.py:116-161) derives from its
+ * arguments, precomputed by the host wrapper and uploaded once.
+ * desc.nbr / start / goal are always HOST pointers.
+ */
+typedef struct mapf_desc {
+    uint32_t struct_size;    /* = sizeof(mapf_desc)                                        */
+    uint32_t n_cells;        /* V = len(valid_locations), 1..65536                         */
+    uint32_t n_agents;       /* A, 1..MAPF_MAX_AGENTS                                      */
+    uint32_t criteria;       /* MAPF_MAKESPAN | MAPF_SOC                                   */
+    uint64_t n_envs;         /* E: envs owned by this handle (this rank's shard)           */
+    uint64_t env_id_offset;  /* global id of local env 0 (RNG counters use global ids)     */
+    uint64_t seed;           /* Philox key (slip stream); policy stream uses seed + 1      */
+    const uint16_t *nbr;     /* [V*5]: nbr[v*5+a] = cell reached from v by noise-free a    */
+                             /*        (mapf_env.py:43-94 execute_action, folded to a table) */
+    const uint16_t *start;   /* [E*A] or [A]: start cells (mapf_env.py:128 agents_starts)   */
+    const uint16_t *goal;    /* [E*A] or [A]: goal cells                                    */
+    double fail_prob;        /* mapf_env.py:130; right_fail = left_fail = fail_prob / 2     */
+    double r_clash;          /* reward_of_collision                                         */
+    double r_goal;           /* reward_of_goal                                              */
+    double r_living;         /* reward_of_living                                            */
+    int32_t device;          /* HIP device ordinal                                          */
+    uint32_t flags;          /* MAPF_FLAG_*                                                 */
+    void *stream;            /* hipStream_t to enqueue on, or NULL: the handle creates one  */
+} mapf_desc;
+
+/* Replaces MapfEnv.__init__'s state setup; state = start cells, step index t = 0. */
+int mapf_create(const mapf_desc *desc, mapf_handle_t *out_handle);
+int mapf_destroy(mapf_handle_t h);
+
+/*
+ * MapfEnv.reset() (mapf_env.py:290-293) for every env, or for the envs whose
+ * mask byte is non-zero (mask: u8[E] or NULL).  Does not touch the RNG counters.
+ */
+int mapf_reset(mapf_handle_t h, const uint8_t *mask);
+
+/*
+ * MapfEnv.step() (mapf_env.py:237-266) for all E envs in one kernel launch.
+ *   actions   u8 [E*A]   per-agent actions (the decoded joint action, :242-243)
+ *   uniforms  f64[E*A]   the rand() values the reference would draw in agent order
+ *                        (:255), or NULL: drawn on device from Philox4x32-10 keyed by
+ *                        (seed; global env id, step index t, agent)
+ *   out_local u16[E*A]   the state step() returns, as per-agent cells
+ *   out_reward f64[E], out_done u8[E], out_collision u8[E], out_prob f64[E]
+ *   out_was_terminal u8[E]: 1 where the env was already terminal, i.e. the reference
+ *                        returned (s, 0, True, {"prob": 0}) and drew nothing (:239-240)
+ * Any out_* may be NULL.  Increments the handle's step index t.
+ */
+int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms,
+              uint16_t *out_local, double *out_reward, uint8_t *out_done,
+              uint8_t *out_collision, double *out_prob, uint8_t *out_was_terminal,
+              uint32_t step_flags);
+
+/*
+ * T fused steps in ONE launch (the caller-side loop around step()):
+ * state stays in registers, actions are streamed from `actions` u8[T*E*A] (step-major) or,
+ * when NULL, drawn from the policy stream (uniform over the 5 actions, key seed + 1).
+ * Every reward is added, in step order, to out_returns f64[E]; out_episodes u32[E] counts
+ * steps that returned done; out_collisions u32[E] counts collision steps.  Optional
+ * trajectory recording (any pointer may be NULL), step-major like `actions`:
+ *   rec_local u16[T*E*A], rec_reward f64[T*E], rec_done u8[T*E], rec_collision u8[T*E],
+ *   rec_prob f64[T*E].
+ * Advances t by T.  Equivalent to T mapf_step calls with the same flags.
+ */
+typedef struct mapf_rollout_io {
+    uint32_t struct_size;
+    uint32_t n_steps;           /* T */
+    uint32_t step_flags;        /* MAPF_STEP_* */
+    uint32_t accumulate;        /* 0: out_* are overwritten; 1: added to existing values */
+    const uint8_t *actions;     /* [T*E*A] or NULL */
+    double   *out_returns;      /* [E] or NULL */
+    uint32_t *out_episodes;     /* [E] or NULL */
+    uint32_t *out_collisions;   /* [E] or NULL */
+    uint16_t *rec_local;
+    double   *rec_reward;
+    uint8_t  *rec_done;
+    uint8_t  *rec_collision;
+    double   *rec_prob;
+} mapf_rollout_io;
+int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io);
+
+/* Synthetic policy used by bench/rollout: fills actions u8[n_steps*E*A] for step indices
+ * t0 .. t0+n_steps-1 from the policy stream (oracle/philox.py random_actions_np). */
+int mapf_fill_random_actions(mapf_handle_t h, uint8_t *actions, uint64_t t0, uint32_t n_steps);
+
+/* MapfEnv.is_terminal (mapf_env.py:210-223) of every env's CURRENT state: out_terminal u8[E] is 1
+ * where two agents share a cell or every agent is on its goal (a step there is a no-op). */
+int mapf_query_terminal(mapf_handle_t h, uint8_t *out_terminal);
+
+/* env.s as per-agent cells + the step index (the whole mutable state: the RNG is
+ * counter-based).  set_state validates cells < V. */
+int mapf_get_state(mapf_handle_t h, uint16_t *local, uint64_t *t);
+int mapf_set_state(mapf_handle_t h, const uint16_t *local, uint64_t t);
+
+/* Block until everything enqueued on the handle's stream has finished. */
+int mapf_sync(mapf_handle_t h);
+
+/* HIP-event timing on the handle's stream: begin records an event, end records another,
+ * waits for it and returns the elapsed milliseconds between the two. */
+int mapf_timer_begin(mapf_handle_t h);
+int mapf_timer_end(mapf_handle_t h, double *out_ms);
+
+/* The hipStream_t the handle enqueues on (for interop with other libraries). */
+int mapf_get_stream(mapf_handle_t h, void **out_stream);
+
+int mapf_device_count(int *out_count);
+const char *mapf_last_error(void);
+const char *mapf_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAPF_HIP_H */

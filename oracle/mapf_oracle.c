@@ -1,0 +1,195 @@
+/*
+ * mapf_oracle.c -- plain-C restatement of gym-mapf's MapfEnv.step() for many envs.
+ *
+ * TEST INFRASTRUCTURE ONLY: used by tests/ (full-size parity), __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg.  The product never links or calls it.
+ *
+ * Parity status: PINNED -- tests/test_oracle_golden.py checks this file (through
+ * oracle/c_oracle.py) against the golden vectors the unmodified reference produced
+ * (tests/golden/, generator tests/golden/make_golden.py).
+ *
+ * Each function cites the reference lines it restates (paths relative to
+ * /root/reference/gym_mapf/envs/).  Scalar loops, one env after another, no SIMD
+ * intrinsics, IEEE double arithmetic evaluated in the reference's order (build with
+ * -ffp-contract=off; x86-64 SSE2 doubles round like CPython's floats).
+ */
+#include <stdint.h>
+#include <stddef.h>
+
+#define MAXA 64
+
+/* ---- Philox4x32-10 (Salmon et al. SC'11); stream layout: oracle/philox.py ---- */
+static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+static double slip_uniform(uint64_t seed, uint64_t env_id, uint64_t t, uint32_t agent) {
+    uint32_t c[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)t,
+                     ((uint32_t)(t >> 32) & 0x00FFFFFFu) | ((agent >> 1) << 24)};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint32_t a = (agent & 1) ? c[2] : c[0], b = (agent & 1) ? c[3] : c[1];
+    uint64_t mant = ((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6);
+    return (double)mant / 9007199254740992.0;
+}
+
+static uint8_t policy_action(uint64_t seed, uint64_t env_id, uint64_t t, uint32_t agent) {
+    uint64_t key = seed + 1;
+    uint32_t c[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)t,
+                     ((uint32_t)(t >> 32) & 0x00FFFFFFu) | ((agent >> 2) << 24)};
+    philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
+    return (uint8_t)(((uint64_t)c[agent & 3] * 5u) >> 32);
+}
+
+/* __init__.py:19-25 POSSIBILITIES, indexed by ACTIONS order STAY,UP,RIGHT,DOWN,LEFT (:26) */
+static const uint8_t SLIP_RIGHT[5] = {0, 2, 3, 4, 1};
+static const uint8_t SLIP_LEFT[5]  = {0, 4, 1, 2, 3};
+
+typedef struct {
+    const uint16_t *nbr;  /* [V*5] noise-free moves (mapf_env.py:43-94 folded to a table) */
+    uint32_t V, A;
+    double fail_prob, r_clash, r_goal, r_living;
+    uint32_t criteria;    /* 0 Makespan, 1 SoC */
+} oracle_cfg;
+
+/* mapf_env.py:210-223 */
+static int is_terminal(const uint16_t *loc, const uint16_t *goal, uint32_t A) {
+    for (uint32_t i = 0; i < A; ++i)
+        for (uint32_t j = i + 1; j < A; ++j)
+            if (loc[i] == loc[j]) return 1;
+    for (uint32_t i = 0; i < A; ++i)
+        if (loc[i] != goal[i]) return 0;
+    return 1;
+}
+
+/* mapf_env.py:163-184 single_agent_movements: returns n, fills cells/probs */
+static int movements(const oracle_cfg *g, uint16_t cell, uint8_t a, uint16_t cells[3], double probs[3]) {
+    const double rf = g->fail_prob / 2, lf = g->fail_prob / 2;
+    const double cand_p[3] = {1 - rf - lf, rf, lf};
+    const uint8_t cand_a[3] = {a, SLIP_RIGHT[a], SLIP_LEFT[a]};
+    int n = 0;
+    for (int k = 0; k < 3; ++k) {
+        if (!(cand_p[k] > 0)) continue;                       /* :172 */
+        uint16_t nxt = g->nbr[(size_t)cell * 5 + cand_a[k]];
+        int hit = -1;
+        for (int m = 0; m < n; ++m) if (cells[m] == nxt) { hit = m; break; }
+        if (hit >= 0) probs[hit] = probs[hit] + cand_p[k];   /* :177-179 */
+        else { cells[n] = nxt; probs[n] = cand_p[k]; ++n; }  /* :181-182 */
+    }
+    return n;
+}
+
+/* One env, one step: mapf_env.py:237-266.  `u` NULL -> Philox.  Returns was_terminal. */
+static int env_step(const oracle_cfg *g, const uint16_t *prev, const uint16_t *goal, const uint8_t *act_in,
+                    const double *u, uint64_t seed, uint64_t env_id, uint64_t t,
+                    uint16_t *next, double *reward, double *prob, int *done, int *collision) {
+    const uint32_t A = g->A;
+    if (is_terminal(prev, goal, A)) {                         /* :239-240 */
+        for (uint32_t i = 0; i < A; ++i) next[i] = prev[i];
+        *reward = 0.0; *prob = 0.0; *done = 1; *collision = 0;
+        return 1;
+    }
+    uint8_t act[MAXA];
+    double total = 1.0;
+    for (uint32_t i = 0; i < A; ++i) {                        /* :253-257 */
+        act[i] = act_in[i] > 4 ? 0 : act_in[i];
+        uint16_t cells[3]; double probs[3];
+        int n = movements(g, prev[i], act[i], cells, probs);
+        double ui = u ? u[i] : slip_uniform(seed, env_id, t, i);
+        int idx = 0; double run = 0.0;                        /* (cumsum(p) > u).argmax() */
+        for (int k = 0; k < n; ++k) {
+            run = (k == 0) ? probs[0] : run + probs[k];
+            if (run > ui) { idx = k; break; }
+        }
+        next[i] = cells[idx];
+        total = (i == 0) ? probs[idx] : total * probs[idx];
+    }
+    *prob = total;
+    double living = g->r_living;                              /* :436-446 */
+    if (g->criteria == 1) {
+        int stayed = 0;
+        for (uint32_t i = 0; i < A; ++i) if (prev[i] == goal[i] && act[i] == 0) ++stayed;
+        living = (double)((int)A - stayed) * g->r_living;
+    }
+    int coll = 0;                                             /* :378-389 */
+    for (uint32_t i = 0; i < A && !coll; ++i)
+        for (uint32_t j = i + 1; j < A; ++j) {
+            if (prev[i] == next[j] && prev[j] == next[i]) { coll = 1; break; }
+            if (next[i] == next[j]) { coll = 1; break; }
+        }
+    int all_goal = 1;
+    for (uint32_t i = 0; i < A; ++i) if (next[i] != goal[i]) { all_goal = 0; break; }
+    if (coll) { *reward = g->r_clash + living; *done = 1; *collision = 1; }          /* :228-229 */
+    else if (all_goal) { *reward = g->r_goal + living; *done = 1; *collision = 0; }   /* :231-233 */
+    else { *reward = living; *done = 0; *collision = 0; }
+    return 0;
+}
+
+/* Batched single step over E envs; mirrors mapf_step() of include/mapf_hip.h. */
+int oracle_step(const uint16_t *nbr, uint32_t V, uint32_t A, uint64_t E,
+                const uint16_t *start, int start_bcast, const uint16_t *goal, int goal_bcast,
+                uint16_t *state, const uint8_t *actions, const double *uniforms,
+                uint64_t seed, uint64_t env_id_offset, uint64_t t,
+                double fail_prob, double r_clash, double r_goal, double r_living, uint32_t criteria,
+                int auto_reset,
+                uint16_t *out_local, double *out_reward, uint8_t *out_done, uint8_t *out_collision,
+                double *out_prob, uint8_t *out_was_terminal) {
+    if (A == 0 || A > MAXA) return -1;
+    oracle_cfg g = {nbr, V, A, fail_prob, r_clash, r_goal, r_living, criteria};
+    for (uint64_t e = 0; e < E; ++e) {
+        uint16_t *st = state + e * A;
+        const uint16_t *gl = goal + (goal_bcast ? 0 : e * A);
+        uint16_t next[MAXA]; double reward, prob; int done, coll;
+        int wt = env_step(&g, st, gl, actions + e * A, uniforms ? uniforms + e * A : NULL,
+                          seed, env_id_offset + e, t, next, &reward, &prob, &done, &coll);
+        if (out_local) for (uint32_t i = 0; i < A; ++i) out_local[e * A + i] = next[i];
+        if (out_reward) out_reward[e] = reward;
+        if (out_prob) out_prob[e] = prob;
+        if (out_done) out_done[e] = (uint8_t)done;
+        if (out_collision) out_collision[e] = (uint8_t)coll;
+        if (out_was_terminal) out_was_terminal[e] = (uint8_t)wt;
+        const uint16_t *src = (auto_reset && done) ? start + (start_bcast ? 0 : e * A) : next;
+        for (uint32_t i = 0; i < A; ++i) st[i] = src[i];
+    }
+    return 0;
+}
+
+/* T steps with the synthetic policy stream (or given actions [T*E*A]) and per-env return sums:
+ * the caller-side loop `s, r, done, _ = env.step(a); if done: env.reset()`.  Returns agent-steps. */
+uint64_t oracle_rollout(const uint16_t *nbr, uint32_t V, uint32_t A, uint64_t E,
+                        const uint16_t *start, int start_bcast, const uint16_t *goal, int goal_bcast,
+                        uint16_t *state, const uint8_t *actions, uint32_t T,
+                        uint64_t seed, uint64_t env_id_offset, uint64_t t0,
+                        double fail_prob, double r_clash, double r_goal, double r_living, uint32_t criteria,
+                        int auto_reset, double *out_returns, uint32_t *out_episodes, uint32_t *out_collisions) {
+    if (A == 0 || A > MAXA) return 0;
+    oracle_cfg g = {nbr, V, A, fail_prob, r_clash, r_goal, r_living, criteria};
+    for (uint64_t e = 0; e < E; ++e) {
+        uint16_t *st = state + e * A;
+        const uint16_t *gl = goal + (goal_bcast ? 0 : e * A);
+        const uint16_t *sl = start + (start_bcast ? 0 : e * A);
+        double ret = 0.0; uint32_t epi = 0, ncoll = 0;
+        for (uint32_t s = 0; s < T; ++s) {
+            uint8_t act[MAXA];
+            for (uint32_t i = 0; i < A; ++i)
+                act[i] = actions ? actions[((size_t)s * E + e) * A + i] : policy_action(seed, env_id_offset + e, t0 + s, i);
+            uint16_t next[MAXA]; double reward, prob; int done, coll;
+            env_step(&g, st, gl, act, NULL, seed, env_id_offset + e, t0 + s, next, &reward, &prob, &done, &coll);
+            ret = ret + reward; epi += (uint32_t)done; ncoll += (uint32_t)coll;
+            const uint16_t *src = (auto_reset && done) ? sl : next;
+            for (uint32_t i = 0; i < A; ++i) st[i] = src[i];
+        }
+        if (out_returns) out_returns[e] = ret;
+        if (out_episodes) out_episodes[e] = epi;
+        if (out_collisions) out_collisions[e] = ncoll;
+    }
+    return (uint64_t)T * E * A;
+}

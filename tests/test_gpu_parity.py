@@ -1,0 +1,216 @@
+"""GPU parity: the HIP path (through the C ABI / VecMapfEnv) against the reference's recorded
+outputs (tests/golden) and against the pinned CPU oracles.  Bit-exact: integers, flags and the
+float64 reward/prob bit patterns.  All tests here need a real MI355X (-m gpu)."""
+import numpy as np
+import pytest
+
+import c_oracle
+import mapf_oracle as mo
+import philox
+from conftest import load_json
+from gym_mapf_amd.envs.grid import MapfGrid
+from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv
+
+pytestmark = pytest.mark.gpu
+CRIT = {'Makespan': OptimizationCriteria.Makespan, 'SoC': OptimizationCriteria.SoC}
+OCRIT = {'Makespan': mo.MAKESPAN, 'SoC': mo.SOC}
+
+
+def _bits(x):
+    return np.asarray(x, np.float64).view(np.uint64)
+
+
+def _vec(meta, g, sel, env_id_offset=0, **kw):
+    return VecMapfEnv(MapfGrid(meta['lines']), meta['n_agents'], g['start_loc'][sel], g['goal_loc'][sel],
+                      meta['fail_prob'], meta['r_clash'], meta['r_goal'], meta['r_living'], CRIT[meta['criteria']],
+                      seed=meta['seed'], env_id_offset=env_id_offset, **kw)
+
+
+def _check_step(local, reward, done, info, g, t, sel, tag):
+    assert np.array_equal(local, g['next_local'][t][sel]), tag
+    assert np.array_equal(_bits(reward), _bits(g['reward'][t][sel])), tag
+    assert np.array_equal(_bits(info['prob']), _bits(g['prob'][t][sel])), tag
+    assert np.array_equal(done, g['done'][t][sel]), tag
+    assert np.array_equal(info['collision'], g['collision'][t][sel]), tag
+    assert np.array_equal(info['was_terminal'], g['was_terminal'][t][sel]), tag
+
+
+def _id_runs(env_ids):
+    """Split golden env ids into runs of consecutive ids (one handle per run)."""
+    runs, start = [], 0
+    ids = [int(x) for x in env_ids]
+    for k in range(1, len(ids) + 1):
+        if k == len(ids) or ids[k] != ids[k - 1] + 1:
+            runs.append((start, k))
+            start = k
+    return runs
+
+
+def test_step_with_injected_uniforms_matches_reference(trajectory_set):
+    """mapf_step(uniforms=...) fed the exact rand() values the reference consumed."""
+    meta, g = trajectory_set
+    A, T, E = meta['n_agents'], meta['T'], len(g['env_ids'])
+    sel = np.arange(E)
+    env = _vec(meta, g, sel)
+    assert np.array_equal(env.start_local, g['start_local']) and np.array_equal(env.goal_local, g['goal_local'])
+    for t in range(T):
+        u = np.stack([philox.slip_uniforms_np(meta['seed'], [e], t, A)[0] for e in g['env_ids']])
+        local, reward, done, info = env.step(g['actions'][t], uniforms=u, auto_reset=meta['auto_reset'])
+        _check_step(local, reward, done, info, g, t, sel, '%s t=%d' % (meta['name'], t))
+    env.close()
+
+
+def test_step_with_device_philox_matches_reference(trajectory_set):
+    """mapf_step(uniforms=NULL): the kernel's own Philox4x32-10 draws, keyed by global env id."""
+    meta, g = trajectory_set
+    for lo, hi in _id_runs(g['env_ids']):
+        sel = np.arange(lo, hi)
+        env = _vec(meta, g, sel, env_id_offset=int(g['env_ids'][lo]))
+        for t in range(meta['T']):
+            local, reward, done, info = env.step(g['actions'][t][sel], auto_reset=meta['auto_reset'])
+            _check_step(local, reward, done, info, g, t, sel, '%s ids[%d:%d] t=%d' % (meta['name'], lo, hi, t))
+        env.close()
+
+
+def test_fused_rollout_matches_reference(trajectory_set):
+    """mapf_rollout: T steps in one launch, recorded trajectory == reference step by step, with
+    streamed actions and with the in-kernel policy stream (the goldens' actions are that stream)."""
+    meta, g = trajectory_set
+    T = meta['T']
+    for lo, hi in _id_runs(g['env_ids']):
+        sel = np.arange(lo, hi)
+        for actions in (np.ascontiguousarray(g['actions'][:, sel]), None):
+            env = _vec(meta, g, sel, env_id_offset=int(g['env_ids'][lo]))
+            res = env.rollout(T, actions=actions, auto_reset=meta['auto_reset'], record=True)
+            assert np.array_equal(res['local'], g['next_local'][:, sel])
+            assert np.array_equal(_bits(res['reward']), _bits(g['reward'][:, sel]))
+            assert np.array_equal(_bits(res['prob']), _bits(g['prob'][:, sel]))
+            assert np.array_equal(res['done'], g['done'][:, sel])
+            assert np.array_equal(res['collision'], g['collision'][:, sel])
+            ret = np.zeros(hi - lo)
+            for t in range(T):
+                ret = ret + g['reward'][t, sel]          # same left-to-right float64 sum
+            assert np.array_equal(_bits(res['returns']), _bits(ret))
+            assert np.array_equal(res['episodes'], g['done'][:, sel].sum(0))
+            assert np.array_equal(res['collisions'], g['collision'][:, sel].sum(0))
+            # state after the rollout == state a step-by-step run leaves behind
+            state, t_now = env.get_state()
+            assert t_now == T
+            env.close()
+
+
+def test_rollout_split_equals_single_and_accumulates(trajectory_set):
+    meta, g = trajectory_set
+    if not meta['auto_reset']:
+        pytest.skip('accumulation check uses the auto-reset sets')
+    lo, hi = _id_runs(g['env_ids'])[0]
+    sel = np.arange(lo, hi)
+    T = meta['T']
+    one = _vec(meta, g, sel)
+    full = one.rollout(T, auto_reset=True)
+    st_full, _ = one.get_state()
+    two = _vec(meta, g, sel)
+    part = two.rollout(T // 3, auto_reset=True)
+    part = two.rollout(T - T // 3, auto_reset=True, accumulate_into=part)
+    st_two, t_two = two.get_state()
+    assert t_two == T and np.array_equal(st_full, st_two)
+    assert np.array_equal(_bits(full['returns']), _bits(part['returns']))
+    assert np.array_equal(full['episodes'], part['episodes']) and np.array_equal(full['collisions'], part['collisions'])
+    one.close(), two.close()
+
+
+def test_scripted_edge_cases_match_reference():
+    """Hand-picked uniforms: all-False argmax, merges, swap-not-sticky, terminal no-ops, SoC rules,
+    exotic fail_prob.  Driven through reset/set_state as the reference run did."""
+    for case in load_json('scripted_cases.json'):
+        A = len(case['starts'])
+        env = VecMapfEnv(MapfGrid(case['lines']), A, case['starts'], case['goals'], case['fail_prob'],
+                         case['r_clash'], case['r_goal'], case['r_living'], CRIT[case['criteria']], n_envs=1)
+        for k, st in enumerate(case['steps']):
+            if st.get('reset'):
+                env.reset()
+                continue
+            local, reward, done, info = env.step(np.asarray([st['actions']], np.uint8),
+                                                 uniforms=np.asarray([st['uniforms']]))
+            tag = '%s step %d' % (case['name'], k)
+            assert local[0].tolist() == st['next_local'], tag
+            assert _bits(reward[0]) == _bits(st['reward']) and _bits(info['prob'][0]) == _bits(st['prob']), tag
+            assert bool(done[0]) == st['done'], tag
+            was_term = bool(info['was_terminal'][0])
+            assert (None if was_term else bool(info['collision'][0])) == st['collision'], tag
+        env.close()
+
+
+def test_masked_reset_set_get_state_and_query_terminal():
+    lines = ['....', '.@..', '....']
+    grid = MapfGrid(lines)
+    E, A = 37, 3
+    rs = np.random.RandomState(5)
+    V = len(grid.tables()[0])
+    start = np.stack([rs.choice(V, A, replace=False) for _ in range(E)]).astype(np.uint16)
+    goal = np.stack([rs.choice(V, A, replace=False) for _ in range(E)]).astype(np.uint16)
+    env = VecMapfEnv(grid, A, None, None, 0.2, -10.0, 5.0, -1.0, OptimizationCriteria.SoC,
+                     start_local=start, goal_local=goal)
+    st, t = env.get_state()
+    assert t == 0 and np.array_equal(st, start)
+    new = rs.randint(0, V, size=(E, A)).astype(np.uint16)
+    env.set_state(new, t=11)
+    st, t = env.get_state()
+    assert t == 11 and np.array_equal(st, new)
+    term = env.query_terminal()
+    expect = np.array([len(set(r.tolist())) < A or np.array_equal(r, gl) for r, gl in zip(new, goal)], np.uint8)
+    assert np.array_equal(term, expect)
+    mask = (rs.rand(E) < 0.5).astype(np.uint8)
+    env.reset(mask)
+    st, _ = env.get_state()
+    assert np.array_equal(st, np.where(mask[:, None] != 0, start, new))
+    env.reset()
+    assert np.array_equal(env.get_state()[0], start)
+    with pytest.raises(Exception):
+        env.set_state(np.full((E, A), V, np.uint16))      # out-of-range cell
+    env.close()
+
+
+@pytest.mark.parametrize('n_agents', [1, 2, 3, 5, 7, 8, 9, 12, 16, 17, 24, 31, 32])
+def test_every_agent_count_specialisation_against_c_oracle(n_agents):
+    """Each A has its own kernel instantiation: run 257 envs x 40 steps on a 20% random map against
+    the C oracle (Philox on both sides), stepwise and fused."""
+    rs = np.random.RandomState(100 + n_agents)
+    H = W = 24
+    lines = [''.join('@' if rs.rand() < 0.2 else '.' for _ in range(W)) for _ in range(H)]
+    grid = MapfGrid(lines)
+    valid, _, nbr = grid.tables()
+    V, E, T, A = len(valid), 257, 40, n_agents
+    start = np.stack([rs.choice(V, A, replace=False) for _ in range(E)]).astype(np.uint16)
+    goal = np.stack([rs.choice(V, A, replace=False) for _ in range(E)]).astype(np.uint16)
+    for crit, ocrit, auto in ((OptimizationCriteria.SoC, mo.SOC, True), (OptimizationCriteria.Makespan, mo.MAKESPAN, False)):
+        env = VecMapfEnv(grid, A, None, None, 0.3, -1000.0, 100.0, -1.5, crit, seed=7, env_id_offset=12345678901,
+                         start_local=start, goal_local=goal)
+        co = c_oracle.COracle(nbr, A, start, goal, 0.3, -1000.0, 100.0, -1.5, ocrit, seed=7, env_id_offset=12345678901)
+        for t in range(T):
+            acts = rs.randint(0, 5, size=(E, A)).astype(np.uint8)
+            local, reward, done, info = env.step(acts, auto_reset=auto)
+            ref = co.step(acts, auto_reset=auto)
+            assert np.array_equal(local, ref['local']), (A, t)
+            assert np.array_equal(_bits(reward), _bits(ref['reward'])) and np.array_equal(_bits(info['prob']), _bits(ref['prob']))
+            assert np.array_equal(done, ref['done']) and np.array_equal(info['collision'], ref['collision'])
+            assert np.array_equal(info['was_terminal'], ref['was_terminal'])
+        res = env.rollout(25, auto_reset=auto)
+        ref = co.rollout(25, auto_reset=auto)
+        assert np.array_equal(_bits(res['returns']), _bits(ref['returns']))
+        assert np.array_equal(res['episodes'], ref['episodes']) and np.array_equal(res['collisions'], ref['collisions'])
+        assert np.array_equal(env.get_state()[0], co.state)
+        env.close()
+
+
+def test_fill_random_actions_matches_policy_stream():
+    grid = MapfGrid(['.....'] * 5)
+    for A in (1, 3, 4, 8, 13):
+        env = VecMapfEnv(grid, A, None, None, 0.0, -1.0, 1.0, -1.0, OptimizationCriteria.Makespan, seed=99,
+                         env_id_offset=(1 << 33) + 7, start_local=np.zeros((70, A), np.uint16) + np.arange(A, dtype=np.uint16),
+                         goal_local=np.zeros((70, A), np.uint16) + np.arange(A, dtype=np.uint16)[::-1])
+        got = env.fill_random_actions(5, 6)
+        ids = (1 << 33) + 7 + np.arange(70)
+        exp = np.stack([philox.random_actions_np(99, ids, 5 + s, A) for s in range(6)])
+        assert np.array_equal(got, exp)
+        env.close()

@@ -89,3 +89,59 @@ def test_trajectories_match_reference(trajectory_set):
                 assert str(env.s) == meta['joint_state_first_steps'][j][t], tag
             if done and meta['auto_reset']:
                 env.reset()
+
+
+# ------------------------------------------------------------------ C oracle (oracle/mapf_oracle.c)
+def _c_oracle_for(meta, g, env_sel, env_id_offset, use_seed=True):
+    import c_oracle
+    nbr = np.asarray(mo.neighbour_table(meta['lines']), np.uint16)
+    return c_oracle.COracle(nbr, meta['n_agents'], g['start_local'][env_sel], g['goal_local'][env_sel],
+                            meta['fail_prob'], meta['r_clash'], meta['r_goal'], meta['r_living'],
+                            CRIT[meta['criteria']], seed=meta['seed'], env_id_offset=env_id_offset)
+
+
+def _compare_step(out, g, t, sel, tag):
+    assert np.array_equal(out['local'], g['next_local'][t][sel]), tag
+    assert np.array_equal(_bits(out['reward']), _bits(g['reward'][t][sel])), tag
+    assert np.array_equal(_bits(out['prob']), _bits(g['prob'][t][sel])), tag
+    assert np.array_equal(out['done'], g['done'][t][sel]), tag
+    assert np.array_equal(out['collision'], g['collision'][t][sel]), tag
+    assert np.array_equal(out['was_terminal'], g['was_terminal'][t][sel]), tag
+
+
+def test_c_oracle_matches_reference_with_injected_uniforms(trajectory_set):
+    meta, g = trajectory_set
+    A, T, E = meta['n_agents'], meta['T'], len(g['env_ids'])
+    sel = np.arange(E)
+    co = _c_oracle_for(meta, g, sel, 0)
+    for t in range(T):
+        u = np.stack([philox.slip_uniforms_np(meta['seed'], [e], t, A)[0] for e in g['env_ids']])
+        out = co.step(g['actions'][t], uniforms=u, auto_reset=meta['auto_reset'])
+        _compare_step(out, g, t, sel, '%s t=%d' % (meta['name'], t))
+
+
+def test_c_oracle_philox_stream_matches_reference(trajectory_set):
+    """Same, but the C oracle draws its own Philox uniforms: one oracle per env id."""
+    meta, g = trajectory_set
+    T = min(meta['T'], 120)
+    for j, env_id in enumerate(g['env_ids']):
+        sel = np.array([j])
+        co = _c_oracle_for(meta, g, sel, int(env_id))
+        for t in range(T):
+            out = co.step(g['actions'][t][sel], auto_reset=meta['auto_reset'])
+            _compare_step(out, g, t, sel, '%s env=%d t=%d' % (meta['name'], int(env_id), t))
+
+
+def test_c_oracle_rollout_returns(trajectory_set):
+    meta, g = trajectory_set
+    if not meta['auto_reset']:
+        return
+    T = meta['T']
+    for j, env_id in enumerate(g['env_ids'][:6]):
+        co = _c_oracle_for(meta, g, np.array([j]), int(env_id))
+        out = co.rollout(T, actions=None, auto_reset=True)      # in-oracle policy stream == golden actions
+        ret = 0.0
+        for t in range(T):
+            ret = ret + g['reward'][t, j]
+        assert _bits(out['returns'][0]) == _bits(ret)
+        assert out['episodes'][0] == g['done'][:, j].sum() and out['collisions'][0] == g['collision'][:, j].sum()
