@@ -110,6 +110,7 @@ def main():
     ap.add_argument('--ring', type=int, default=512, help='distinct pre-generated action steps kept in HBM')
     ap.add_argument('--rollout-steps', type=int, default=64, help='T of the fused rollout leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--kernel', default='auto', choices=['auto', 'thread_per_env', 'lane_group'])
     args = ap.parse_args()
 
     import torch
@@ -132,7 +133,7 @@ def main():
     grid, nbr, start, goal = workload_tables(E, offset)
     env = VecMapfEnv(grid, A, None, None, FAIL_PROB, R_CLASH, R_GOAL, R_LIVING, OptimizationCriteria.Makespan,
                      seed=SEED, env_id_offset=offset, device=local_rank, device_arrays=True,
-                     start_local=start, goal_local=goal)
+                     start_local=start, goal_local=goal, kernel=args.kernel)
     ring = max(1, min(args.ring, K + W))
     actions = env.fill_random_actions(0, ring)                      # [ring, E, A] u8, resident in HBM
     env.sync()

@@ -51,9 +51,11 @@ struct mapf_handle_s {
     uint64_t E = 0, env_id_offset = 0, t = 0;
     mapf::EnvConsts c{};
     bool start_broadcast = false, goal_broadcast = false, device_ptrs = false, own_stream = false;
+    bool lane_group = false;   // kernel family
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     uint2 *nbr4 = nullptr;
+    mapf::SlipRow *slip = nullptr;
     uint16_t *state = nullptr, *start = nullptr, *goal = nullptr;
     // host-pointer mode staging
     DeviceBuf s_actions, s_uniforms, s_local, s_reward, s_prob, s_done, s_coll, s_term, s_mask, s_ret, s_epi, s_ncoll;
@@ -105,6 +107,51 @@ int fetch_out(mapf_handle_t h, const T *dev, T *dst, size_t count) {
     return MAPF_OK;
 }
 
+// Replay single_agent_movements (mapf_env.py:163-184) for each equality pattern of the candidate cells
+// (m intended, r right slip, l left slip), in IEEE double and the reference's evaluation order -- the
+// same operations CPython performs: rf = lf = fail_prob / 2 (:131-132), p0 = 1 - rf - lf (:167), drop
+// p <= 0 (:172), merge equal cells with old + new in first-seen order (:177-182); cum = np.cumsum.
+// Returns true when some list has more than one entry, i.e. a uniform is actually consumed.
+bool build_slip_table(double fail_prob, mapf::SlipRow (&rows)[8]) {
+    const double rf = fail_prob / 2, lf = fail_prob / 2;
+    const double cand_p[3] = {(1 - rf) - lf, rf, lf};
+    bool any_multi = false;
+    for (unsigned code = 0; code < 8; ++code) {
+        // representative cells realising the pattern (inconsistent codes cannot occur at run time)
+        const int m = 0, r = (code & 1u) ? 0 : 1, l = (code & 2u) ? 0 : ((code & 4u) ? r : 2);
+        const int cand_cell[3] = {m, r, l};
+        int cells[3] = {-1, -1, -1}, src[3] = {0, 0, 0}, n = 0;
+        double q[3] = {0, 0, 0};
+        for (int k = 0; k < 3; ++k) {
+            if (!(cand_p[k] > 0)) continue;
+            int hit = -1;
+            for (int j = 0; j < n; ++j) if (cells[j] == cand_cell[k]) { hit = j; break; }
+            if (hit >= 0) q[hit] = q[hit] + cand_p[k];
+            else { cells[n] = cand_cell[k]; src[n] = k; q[n] = cand_p[k]; ++n; }
+        }
+        mapf::SlipRow &row = rows[code];
+        std::memset(&row, 0, sizeof(row));
+        row.n = uint32_t(n);
+        double run = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            if (k < n) {
+                run = (k == 0) ? q[0] : run + q[k];
+                row.cum[k] = run;
+                row.q[k] = q[k];
+                const double scaled = std::ceil(std::ldexp(run, 53));          // exact: power-of-two scaling
+                row.thr[k] = scaled >= 9007199254740992.0 ? (uint64_t(1) << 53) : (scaled <= 0 ? 0 : uint64_t(scaled));
+                row.src |= uint32_t(src[k]) << (8 * k);
+            } else {
+                row.cum[k] = -HUGE_VAL;
+                row.q[k] = 0.0;
+                row.thr[k] = 0;
+            }
+        }
+        any_multi |= n > 1;
+    }
+    return any_multi;
+}
+
 void destroy_impl(mapf_handle_t h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
@@ -113,6 +160,7 @@ void destroy_impl(mapf_handle_t h) {
                          &h->s_coll, &h->s_term, &h->s_mask, &h->s_ret, &h->s_epi, &h->s_ncoll})
         b->release();
     if (h->nbr4) (void)hipFree(h->nbr4);
+    if (h->slip) (void)hipFree(h->slip);
     if (h->state) (void)hipFree(h->state);
     if (h->start) (void)hipFree(h->start);
     if (h->goal) (void)hipFree(h->goal);
@@ -145,7 +193,11 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
     if (d->struct_size != sizeof(mapf_desc)) return fail(MAPF_EINVAL, "mapf_desc.struct_size does not match this library");
     if (d->n_cells == 0 || d->n_cells > 65536u) return fail(MAPF_EINVAL, "n_cells must be in 1..65536 (uint16 local ids)");
     if (d->n_agents == 0) return fail(MAPF_EINVAL, "n_agents must be >= 1");
-    if (d->n_agents > MAPF_MAX_AGENTS) return fail(MAPF_EUNSUPPORTED, "n_agents beyond MAPF_MAX_AGENTS (32)");
+    if (d->n_agents > MAPF_MAX_AGENTS) return fail(MAPF_EUNSUPPORTED, "n_agents beyond MAPF_MAX_AGENTS (128)");
+    if ((d->flags & MAPF_FLAG_THREAD_PER_ENV) && (d->flags & MAPF_FLAG_LANE_GROUP))
+        return fail(MAPF_EINVAL, "MAPF_FLAG_THREAD_PER_ENV and MAPF_FLAG_LANE_GROUP are exclusive");
+    if ((d->flags & MAPF_FLAG_THREAD_PER_ENV) && d->n_agents > uint32_t(mapf::kTpeMaxAgents))
+        return fail(MAPF_EUNSUPPORTED, "thread-per-env kernels exist for n_agents <= 16 only");
     if (d->criteria > MAPF_SOC) return fail(MAPF_EINVAL, "criteria must be MAPF_MAKESPAN or MAPF_SOC");
     if (!d->nbr || !d->start || !d->goal) return fail(MAPF_EINVAL, "nbr/start/goal must be non-null host pointers");
     if (!std::isfinite(d->fail_prob) || !std::isfinite(d->r_clash) || !std::isfinite(d->r_goal) || !std::isfinite(d->r_living))
@@ -181,12 +233,13 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
     h->env_id_offset = d->env_id_offset; h->t = 0;
     h->start_broadcast = sb; h->goal_broadcast = gb;
     h->device_ptrs = d->flags & MAPF_FLAG_DEVICE_PTRS;
+    // kernel family: forced by flag, else lane groups whenever an env has more than one agent pair
+    if (d->flags & MAPF_FLAG_THREAD_PER_ENV) h->lane_group = false;
+    else if (d->flags & MAPF_FLAG_LANE_GROUP) h->lane_group = true;
+    else h->lane_group = A > 2;
 
-    // mapf_env.py:131-132 and :167-169, evaluated left to right in IEEE double like CPython
-    const double rf = d->fail_prob / 2, lf = d->fail_prob / 2;
-    const double p0 = (1 - rf) - lf;
-    h->c.p0 = p0; h->c.rf = rf; h->c.lf = lf;
-    h->c.keep = (p0 > 0 ? 1u : 0u) | (rf > 0 ? 2u : 0u) | (lf > 0 ? 4u : 0u);
+    mapf::SlipRow slip_host[8];
+    h->c.need_rng = build_slip_table(d->fail_prob, slip_host) ? 1u : 0u;
     h->c.r_clash = d->r_clash; h->c.r_goal = d->r_goal; h->c.r_living = d->r_living;
     h->c.criteria = d->criteria; h->c.n_cells = V;
     h->c.seed_lo = uint32_t(d->seed); h->c.seed_hi = uint32_t(d->seed >> 32);
@@ -215,6 +268,8 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->state), (E ? E : 1) * row));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->start), (sb ? 1 : (E ? E : 1)) * row));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->goal), (gb ? 1 : (E ? E : 1)) * row));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->slip), sizeof(slip_host)));
+    CREATE_TRY(hipMemcpy(h->slip, slip_host, sizeof(slip_host), hipMemcpyHostToDevice));
     CREATE_TRY(hipMemcpy(h->nbr4, packed.data(), size_t(V) * sizeof(uint2), hipMemcpyHostToDevice));
     if (n_start) CREATE_TRY(hipMemcpy(h->start, d->start, n_start * sizeof(uint16_t), hipMemcpyHostToDevice));
     if (n_goal) CREATE_TRY(hipMemcpy(h->goal, d->goal, n_goal * sizeof(uint16_t), hipMemcpyHostToDevice));
@@ -277,7 +332,7 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     if (step_flags & ~MAPF_STEP_AUTO_RESET) return fail(MAPF_EINVAL, "unknown step flag");
     const size_t E = size_t(h->E), EA = E * h->A;
     mapf::StepArgs a{};
-    a.c = h->c; a.nbr4 = h->nbr4; a.state = h->state; a.start = h->start; a.goal = h->goal;
+    a.c = h->c; a.nbr4 = h->nbr4; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
     a.n_envs = h->E; a.env_id_offset = h->env_id_offset; a.t = h->t;
     a.start_broadcast = h->start_broadcast; a.goal_broadcast = h->goal_broadcast;
     a.auto_reset = step_flags & MAPF_STEP_AUTO_RESET;
@@ -289,7 +344,7 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     if (int rc = stage_out(h, h->s_done, out_done, E, &a.out_done, "out_done")) return rc;
     if (int rc = stage_out(h, h->s_coll, out_collision, E, &a.out_collision, "out_collision")) return rc;
     if (int rc = stage_out(h, h->s_term, out_was_terminal, E, &a.out_was_terminal, "out_was_terminal")) return rc;
-    HIP_TRY(mapf::launch_step(int(h->A), a, h->stream));
+    HIP_TRY(h->lane_group ? mapf::launch_step_lg(int(h->A), a, h->stream) : mapf::launch_step(int(h->A), a, h->stream));
     h->t += 1;
     if (!h->device_ptrs) {
         if (int rc = fetch_out(h, a.out_local, out_local, EA)) return rc;
@@ -309,7 +364,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     if (io->step_flags & ~MAPF_STEP_AUTO_RESET) return fail(MAPF_EINVAL, "unknown step flag");
     const size_t E = size_t(h->E), T = io->n_steps, TE = T * E, TEA = TE * h->A;
     mapf::RolloutArgs a{};
-    a.c = h->c; a.nbr4 = h->nbr4; a.state = h->state; a.start = h->start; a.goal = h->goal;
+    a.c = h->c; a.nbr4 = h->nbr4; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
     a.n_envs = h->E; a.env_id_offset = h->env_id_offset; a.t = h->t; a.n_steps = io->n_steps;
     a.start_broadcast = h->start_broadcast; a.goal_broadcast = h->goal_broadcast;
     a.auto_reset = io->step_flags & MAPF_STEP_AUTO_RESET;
@@ -322,7 +377,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
         a.actions = io->actions; a.out_returns = io->out_returns; a.out_episodes = io->out_episodes;
         a.out_collisions = io->out_collisions; a.rec_local = io->rec_local; a.rec_reward = io->rec_reward;
         a.rec_done = io->rec_done; a.rec_collision = io->rec_collision; a.rec_prob = io->rec_prob;
-        HIP_TRY(mapf::launch_rollout(int(h->A), a, h->stream));
+        HIP_TRY(h->lane_group ? mapf::launch_rollout_lg(int(h->A), a, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
         h->t += io->n_steps;
         return MAPF_OK;
     }
@@ -348,7 +403,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     if (int rc = stage_out(h, h->s_prob, io->rec_prob, TE, &a.rec_prob, "rec_prob")) return rc;
     if (int rc = stage_out(h, h->s_done, io->rec_done, TE, &a.rec_done, "rec_done")) return rc;
     if (int rc = stage_out(h, h->s_coll, io->rec_collision, TE, &a.rec_collision, "rec_collision")) return rc;
-    HIP_TRY(mapf::launch_rollout(int(h->A), a, h->stream));
+    HIP_TRY(h->lane_group ? mapf::launch_rollout_lg(int(h->A), a, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
     h->t += io->n_steps;
     if (int rc = fetch_out(h, a.out_returns, io->out_returns, E)) return rc;
     if (int rc = fetch_out(h, a.out_episodes, io->out_episodes, E)) return rc;

@@ -19,22 +19,24 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
                                               uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0;
-        c1 = lo1;
-        c2 = hi0 ^ c3 ^ k1;
-        c3 = lo0;
+        const uint64_t p0 = uint64_t(0xD2511F53u) * c0;   // one v_mad_u64_u32 gives hi and lo
+        const uint64_t p1 = uint64_t(0xCD9E8D57u) * c2;
+        c0 = uint32_t(p1 >> 32) ^ c1 ^ k0;
+        c1 = uint32_t(p1);
+        c2 = uint32_t(p0 >> 32) ^ c3 ^ k1;
+        c3 = uint32_t(p0);
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
+        // Keep the key schedule as two live scalars: without this the compiler hoists all 20 round keys
+        // of each stream into SGPRs for the whole kernel, which forces SGPR spills at larger A.
+        asm volatile("" : "+s"(k0), "+s"(k1));
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// 53-bit uniform in [0,1) from two words -- same construction as RandomState.rand().
-__device__ __forceinline__ double uniform53(uint32_t a, uint32_t b) {
-    const uint64_t mant = (uint64_t(a >> 5) << 26) | uint64_t(b >> 6);
-    return __dmul_rn(double(mant), 1.1102230246251565e-16 /* 2^-53 */);
+// 53-bit integer of a uniform in [0,1): u = mant * 2^-53 -- same construction as RandomState.rand().
+__device__ __forceinline__ uint64_t mantissa53(uint32_t a, uint32_t b) {
+    return (uint64_t(a >> 5) << 26) | uint64_t(b >> 6);
 }
 
 // ------------------------------------------------------------ env-major row I/O
@@ -67,19 +69,59 @@ __device__ __forceinline__ uint32_t pick_move(uint32_t cell, uint64_t n64, uint3
     return a == 0u ? cell : moved;
 }
 
+// The slip table lives in LDS: 8 rows (one per equality code of the three candidate cells), built on
+// the host by replaying single_agent_movements (mapf_env.py:163-184) -- see build_slip_table().
+__device__ __forceinline__ void stage_slip_table(const SlipRow *__restrict__ src, SlipRow *lds) {
+    const uint64_t *s = reinterpret_cast<const uint64_t *>(src);
+    uint64_t *d = reinterpret_cast<uint64_t *>(lds);
+    constexpr int n_words = int(sizeof(SlipRow) * 8 / sizeof(uint64_t));
+    for (int w = threadIdx.x; w < n_words; w += blockDim.x) d[w] = s[w];
+    __syncthreads();
+}
+
+// One agent: candidates (intended, slip right, slip left) -> merged list -> sampled target.
+// `mant` is the 53-bit integer of the uniform (u = mant * 2^-53), used when !EXT_UNIFORMS.
+template <bool EXT_UNIFORMS>
+__device__ __forceinline__ void slip_move(const SlipRow *lds_slip, uint32_t cell, uint64_t n64, uint32_t a,
+                                          uint64_t mant, double u, uint32_t &next, double &q) {
+    // POSSIBILITIES (gym_mapf/envs/__init__.py:19-25): right/left slips of UP,RIGHT,DOWN,LEFT
+    const uint32_t ar = a == 0u ? 0u : (a & 3u) + 1u;
+    const uint32_t al = a == 0u ? 0u : ((a + 2u) & 3u) + 1u;
+    const uint32_t m = pick_move(cell, n64, a);
+    const uint32_t r = pick_move(cell, n64, ar);
+    const uint32_t l = pick_move(cell, n64, al);
+    const uint32_t code = (m == r ? 1u : 0u) | (m == l ? 2u : 0u) | (r == l ? 4u : 0u);
+    const SlipRow &row = lds_slip[code];
+    // categorical_sample (call site mapf_env.py:255): (cumsum(p) > u).argmax(), all-False -> 0.
+    // cum[k] > u  <=>  mant < ceil(cum[k] * 2^53) = thr[k]; rows shorter than 3 carry thr = 0 / cum = -inf.
+    bool b0, b1, b2;
+    if (EXT_UNIFORMS) {
+        b0 = row.cum[0] > u; b1 = row.cum[1] > u; b2 = row.cum[2] > u;
+    } else {
+        b0 = mant < row.thr[0]; b1 = mant < row.thr[1]; b2 = mant < row.thr[2];
+    }
+    const uint32_t idx = b0 ? 0u : (b1 ? 1u : (b2 ? 2u : 0u));
+    const uint32_t src = (row.src >> (idx * 8u)) & 0xFFu;   // which candidate sits in list slot idx
+    next = src == 0u ? m : (src == 1u ? r : l);
+    q = row.q[idx];
+}
+
 template <int A, bool EXT_UNIFORMS>
 __device__ __forceinline__ void env_transition(const EnvConsts &c, const uint2 *__restrict__ nbr4,
+                                               const SlipRow *lds_slip,
                                                const uint32_t (&prev)[A], const uint32_t (&goal)[A],
                                                const uint32_t (&act_in)[A], const double *ext_u,
                                                uint64_t env_id, uint64_t t, StepResult<A> &out) {
-    // is_terminal(prev): mapf_env.py:210-223
-    bool dup = false, all_goal = true;
+    // is_terminal(prev): mapf_env.py:210-223.  Pair tests accumulate min(xor) in a VGPR (zero <=> some pair
+    // equal) instead of OR-ing wave masks: 1.5 VALU per pair and no SGPR pressure at A = 32.
+    uint32_t dup_acc = 0xFFFFFFFFu, goal_acc = 0u;
 #pragma unroll
     for (int i = 0; i < A; ++i) {
-        all_goal &= (prev[i] == goal[i]);
+        goal_acc |= prev[i] ^ goal[i];
 #pragma unroll
-        for (int j = i + 1; j < A; ++j) dup |= (prev[i] == prev[j]);
+        for (int j = i + 1; j < A; ++j) dup_acc = min(dup_acc, prev[i] ^ prev[j]);
     }
+    const bool dup = (A > 1) && dup_acc == 0u, all_goal = goal_acc == 0u;
     if (dup || all_goal) {  // mapf_env.py:239-240 -- (s, 0, True, {"prob": 0}), nothing drawn
 #pragma unroll
         for (int i = 0; i < A; ++i) out.next[i] = prev[i];
@@ -89,8 +131,6 @@ __device__ __forceinline__ void env_transition(const EnvConsts &c, const uint2 *
     }
     out.was_terminal = false;
 
-    const bool k0 = c.keep & 1u, k1 = c.keep & 2u, k2 = c.keep & 4u;
-    const bool need_u = (c.keep & (c.keep - 1u)) != 0u;  // more than one candidate survives
     uint32_t act[A];
 #pragma unroll
     for (int i = 0; i < A; ++i) act[i] = act_in[i] > 4u ? 0u : act_in[i];
@@ -108,66 +148,21 @@ __device__ __forceinline__ void env_transition(const EnvConsts &c, const uint2 *
     uint32_t w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < A; ++i) {
+        uint64_t mant = 0;
         double u = 0.0;
-        if (need_u) {  // uniform branch
-            if (EXT_UNIFORMS) {
-                u = ext_u[i];
+        if (EXT_UNIFORMS) {
+            u = ext_u[i];
+        } else if (c.need_rng) {  // uniform branch: a single surviving candidate needs no draw
+            if ((i & 1) == 0) {
+                const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | (uint32_t(i >> 1) << 24);
+                philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, c.seed_lo, c.seed_hi, w);
+                mant = mantissa53(w[0], w[1]);
             } else {
-                if ((i & 1) == 0) {
-                    const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | (uint32_t(i >> 1) << 24);
-                    philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3,
-                                  c.seed_lo, c.seed_hi, w);
-                    u = uniform53(w[0], w[1]);
-                } else {
-                    u = uniform53(w[2], w[3]);
-                }
+                mant = mantissa53(w[2], w[3]);
             }
         }
-        const uint32_t a = act[i];
-        // POSSIBILITIES (gym_mapf/envs/__init__.py:19-25): right/left slips of UP,RIGHT,DOWN,LEFT
-        const uint32_t ar = a == 0u ? 0u : (a & 3u) + 1u;
-        const uint32_t al = a == 0u ? 0u : ((a + 2u) & 3u) + 1u;
-        const uint32_t m = pick_move(prev[i], n64[i], a);
-        const uint32_t r = pick_move(prev[i], n64[i], ar);
-        const uint32_t l = pick_move(prev[i], n64[i], al);
-
-        // single_agent_movements (mapf_env.py:163-184): drop p <= 0, merge equal targets
-        // in first-seen order with old + new.
-        uint32_t c0 = 0u, c1 = 0u, c2 = 0u;
-        double q0 = 0.0, q1 = 0.0, q2 = 0.0;
-        int n = 0;
-        if (k0) { c0 = m; q0 = c.p0; n = 1; }
-        if (k1) {
-            const bool hit0 = (n >= 1) && (c0 == r);
-            const bool app0 = (n == 0);
-            q0 = hit0 ? __dadd_rn(q0, c.rf) : (app0 ? c.rf : q0);
-            c0 = app0 ? r : c0;
-            const bool app1 = !hit0 && !app0;
-            c1 = app1 ? r : c1;
-            q1 = app1 ? c.rf : q1;
-            n = hit0 ? n : n + 1;
-        }
-        if (k2) {
-            const bool hit0 = (n >= 1) && (c0 == l);
-            const bool hit1 = !hit0 && (n >= 2) && (c1 == l);
-            const bool app = !hit0 && !hit1;
-            const bool app0 = app && n == 0, app1 = app && n == 1, app2 = app && n == 2;
-            q0 = hit0 ? __dadd_rn(q0, c.lf) : (app0 ? c.lf : q0);
-            q1 = hit1 ? __dadd_rn(q1, c.lf) : (app1 ? c.lf : q1);
-            q2 = app2 ? c.lf : q2;
-            c0 = app0 ? l : c0;
-            c1 = app1 ? l : c1;
-            c2 = app2 ? l : c2;
-            n = app ? n + 1 : n;
-        }
-        // categorical_sample (call site mapf_env.py:255): (cumsum(p) > u).argmax(), all-False -> 0
-        const double s0 = q0;
-        const double s1 = __dadd_rn(s0, q1);
-        const double s2 = __dadd_rn(s1, q2);
-        const bool pick1 = !(s0 > u) && (n > 1) && (s1 > u);
-        const bool pick2 = !(s0 > u) && !pick1 && (n > 2) && (s2 > u);
-        out.next[i] = pick2 ? c2 : (pick1 ? c1 : c0);
-        const double pr = pick2 ? q2 : (pick1 ? q1 : q0);
+        double pr;
+        slip_move<EXT_UNIFORMS>(lds_slip, prev[i], n64[i], act[i], mant, u, out.next[i], pr);
         prob = (i == 0) ? pr : __dmul_rn(prob, pr);  // total_prob *= p, agent order (:257)
     }
     out.prob = prob;
@@ -181,17 +176,18 @@ __device__ __forceinline__ void env_transition(const EnvConsts &c, const uint2 *
         living = __dmul_rn(double(A - stayed), c.r_living);
     }
     // _is_collision_transition_from_local_states: mapf_env.py:378-389
-    bool coll = false, goal_next = true;
+    uint32_t coll_acc = 0xFFFFFFFFu, goal_next_acc = 0u;
 #pragma unroll
     for (int i = 0; i < A; ++i) {
-        goal_next &= (out.next[i] == goal[i]);
+        goal_next_acc |= out.next[i] ^ goal[i];
         const uint32_t fwd = prev[i] | (out.next[i] << 16);
 #pragma unroll
         for (int j = i + 1; j < A; ++j) {
             const uint32_t rev = out.next[j] | (prev[j] << 16);
-            coll |= (out.next[i] == out.next[j]) | (fwd == rev);
+            coll_acc = min(coll_acc, min(out.next[i] ^ out.next[j], fwd ^ rev));   // vertex, swap
         }
     }
+    const bool coll = (A > 1) && coll_acc == 0u, goal_next = goal_next_acc == 0u;
     // calc_transition_reward_from_local_states: mapf_env.py:225-235 (collision before goal)
     out.collision = coll;
     out.done = coll || goal_next;

@@ -4,8 +4,7 @@
 //                       (MapfEnv.step, mapf_env.py:237-266) + optional fused auto-reset
 //   rollout_kernel<A>   T transitions per env in one launch, state in registers,
 //                       optional trajectory recording (the caller-side loop around step)
-//   reset_kernel<A>     masked MapfEnv.reset (mapf_env.py:290-293)
-//   fill_actions_kernel the synthetic policy stream used by bench/rollout
+// (reset / query_terminal / fill_actions are run-time-A kernels in mapf_lg_kernels.hip)
 //
 // Mapping: one thread = one env, all A agents in registers; rows are env-major so a lane
 // reads/writes its whole row with the widest aligned access (dwordx4 at A = 8).
@@ -29,6 +28,8 @@ __device__ __forceinline__ void load_cells(const uint16_t *base, uint64_t e, boo
 
 template <int A, bool EXT_UNIFORMS>
 __global__ void __launch_bounds__(256) step_kernel(const StepArgs p) {
+    __shared__ SlipRow slip[8];
+    stage_slip_table(p.slip, slip);
     const uint64_t e = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (e >= p.n_envs) return;
 
@@ -48,7 +49,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs p) {
     }
 
     StepResult<A> res;
-    env_transition<A, EXT_UNIFORMS>(p.c, p.nbr4, prev, goal, act, uext, p.env_id_offset + e, p.t, res);
+    env_transition<A, EXT_UNIFORMS>(p.c, p.nbr4, slip, prev, goal, act, uext, p.env_id_offset + e, p.t, res);
 
     Row<uint16_t, A> nx;
 #pragma unroll
@@ -69,13 +70,14 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs p) {
 
 template <int A>
 __global__ void __launch_bounds__(256) rollout_kernel(const RolloutArgs p) {
+    __shared__ SlipRow slip[8];
+    stage_slip_table(p.slip, slip);
     const uint64_t e = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (e >= p.n_envs) return;
 
-    uint32_t cur[A], goal[A], start[A];
+    uint32_t cur[A], goal[A];
     load_cells<A>(p.state, e, false, cur);
     load_cells<A>(p.goal, e, p.goal_broadcast, goal);
-    if (p.auto_reset) load_cells<A>(p.start, e, p.start_broadcast, start);
 
     double ret = (p.accumulate && p.out_returns) ? p.out_returns[e] : 0.0;
     uint32_t episodes = (p.accumulate && p.out_episodes) ? p.out_episodes[e] : 0u;
@@ -94,7 +96,7 @@ __global__ void __launch_bounds__(256) rollout_kernel(const RolloutArgs p) {
             policy_actions<A>(p.c, env_id, t, act);
         }
         StepResult<A> res;
-        env_transition<A, false>(p.c, p.nbr4, cur, goal, act, nullptr, env_id, t, res);
+        env_transition<A, false>(p.c, p.nbr4, slip, cur, goal, act, nullptr, env_id, t, res);
 
         ret = __dadd_rn(ret, res.reward);
         episodes += res.done ? 1u : 0u;
@@ -110,9 +112,12 @@ __global__ void __launch_bounds__(256) rollout_kernel(const RolloutArgs p) {
         if (p.rec_done) p.rec_done[row] = res.done ? 1 : 0;
         if (p.rec_collision) p.rec_collision[row] = res.collision ? 1 : 0;
 
-        const bool back_to_start = p.auto_reset && res.done;
+        if (p.auto_reset && res.done) {
+            load_cells<A>(p.start, e, p.start_broadcast, cur);   // rare: re-read the start row instead of pinning A registers
+        } else {
 #pragma unroll
-        for (int i = 0; i < A; ++i) cur[i] = back_to_start ? start[i] : res.next[i];
+            for (int i = 0; i < A; ++i) cur[i] = res.next[i];
+        }
     }
 
     Row<uint16_t, A> fin;
@@ -124,49 +129,6 @@ __global__ void __launch_bounds__(256) rollout_kernel(const RolloutArgs p) {
     if (p.out_collisions) p.out_collisions[e] = collisions;
 }
 
-template <int A>
-__global__ void __launch_bounds__(256) reset_kernel(uint16_t *state, const uint16_t *start, bool start_broadcast,
-                                                    const uint8_t *mask, uint64_t n_envs) {
-    const uint64_t e = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (e >= n_envs) return;
-    if (mask && mask[e] == 0) return;
-    store_row<uint16_t, A>(state, e, load_row<uint16_t, A>(start, start_broadcast ? 0 : e));
-}
-
-// MapfEnv.is_terminal (mapf_env.py:210-223) of the stored state
-template <int A>
-__global__ void __launch_bounds__(256) query_terminal_kernel(const uint16_t *state, const uint16_t *goal,
-                                                             bool goal_broadcast, uint8_t *out, uint64_t n_envs) {
-    const uint64_t e = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (e >= n_envs) return;
-    uint32_t cur[A], g[A];
-    load_cells<A>(state, e, false, cur);
-    load_cells<A>(goal, e, goal_broadcast, g);
-    bool dup = false, all_goal = true;
-#pragma unroll
-    for (int i = 0; i < A; ++i) {
-        all_goal &= (cur[i] == g[i]);
-#pragma unroll
-        for (int j = i + 1; j < A; ++j) dup |= (cur[i] == cur[j]);
-    }
-    out[e] = (dup || all_goal) ? 1 : 0;
-}
-
-// one thread per (step, env) row of A bytes
-template <int A>
-__global__ void __launch_bounds__(256) fill_actions_kernel(uint8_t *actions, EnvConsts c, uint64_t env_id_offset,
-                                                           uint64_t n_envs, uint64_t t0, uint64_t n_rows) {
-    const uint64_t row = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (row >= n_rows) return;
-    const uint64_t s = row / n_envs, e = row - s * n_envs;
-    uint32_t act[A];
-    policy_actions<A>(c, env_id_offset + e, t0 + s, act);
-    Row<uint8_t, A> r;
-#pragma unroll
-    for (int i = 0; i < A; ++i) r.v[i] = uint8_t(act[i]);
-    store_row<uint8_t, A>(actions, row, r);
-}
-
 // ------------------------------------------------------------------- launchers
 static inline unsigned pick_block(uint64_t n) { return n <= (1u << 18) ? 64u : 256u; }
 static inline unsigned grid_for(uint64_t n, unsigned block) { return unsigned((n + block - 1) / block); }
@@ -174,7 +136,7 @@ static inline unsigned grid_for(uint64_t n, unsigned block) { return unsigned((n
 // This file is compiled once per agent-count group g (-DMAPF_GROUP=g, A in 4g+1 .. 4g+4) so the
 // 32 specialisations build in parallel; mapf_dispatch.hip routes a launch to its group.
 #ifndef MAPF_GROUP
-#error "compile with -DMAPF_GROUP=0..7"
+#error "compile with -DMAPF_GROUP=0..3"
 #endif
 #define MAPF_A0 (4 * MAPF_GROUP + 1)
 #define MAPF_FOR_EACH_A(X) X((MAPF_A0)) X((MAPF_A0 + 1)) X((MAPF_A0 + 2)) X((MAPF_A0 + 3))
@@ -204,54 +166,6 @@ hipError_t MAPF_G(launch_rollout_g)(int n_agents, const RolloutArgs &args, hipSt
     switch (n_agents) {
 #define X(N)                                                                                       \
     case N: hipLaunchKernelGGL((rollout_kernel<N>), dim3(grid), dim3(block), 0, stream, args); break;
-        MAPF_FOR_EACH_A(X)
-#undef X
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-hipError_t MAPF_G(launch_reset_g)(int n_agents, uint16_t *state, const uint16_t *start, bool start_broadcast,
-                        const uint8_t *mask, uint64_t n_envs, hipStream_t stream) {
-    if (n_envs == 0) return hipSuccess;
-    const unsigned block = 256, grid = grid_for(n_envs, block);
-    switch (n_agents) {
-#define X(N)                                                                                       \
-    case N: hipLaunchKernelGGL((reset_kernel<N>), dim3(grid), dim3(block), 0, stream, state, start, \
-                               start_broadcast, mask, n_envs); break;
-        MAPF_FOR_EACH_A(X)
-#undef X
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-hipError_t MAPF_G(launch_query_terminal_g)(int n_agents, const uint16_t *state, const uint16_t *goal,
-                                           bool goal_broadcast, uint8_t *out, uint64_t n_envs, hipStream_t stream) {
-    if (n_envs == 0) return hipSuccess;
-    const unsigned block = 256, grid = grid_for(n_envs, block);
-    switch (n_agents) {
-#define X(N)                                                                                       \
-    case N: hipLaunchKernelGGL((query_terminal_kernel<N>), dim3(grid), dim3(block), 0, stream, state, goal, \
-                               goal_broadcast, out, n_envs); break;
-        MAPF_FOR_EACH_A(X)
-#undef X
-        default: return hipErrorInvalidValue;
-    }
-    return hipGetLastError();
-}
-
-hipError_t MAPF_G(launch_fill_actions_g)(int n_agents, uint8_t *actions, const EnvConsts &c, uint64_t env_id_offset,
-                               uint64_t n_envs, uint64_t t0, uint64_t n_steps, hipStream_t stream) {
-    const uint64_t n_rows = n_envs * n_steps;
-    if (n_rows == 0) return hipSuccess;
-    const unsigned block = 256;
-    const uint64_t grid64 = (n_rows + block - 1) / block;
-    if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    switch (n_agents) {
-#define X(N)                                                                                       \
-    case N: hipLaunchKernelGGL((fill_actions_kernel<N>), dim3(unsigned(grid64)), dim3(block), 0, stream, \
-                               actions, c, env_id_offset, n_envs, t0, n_rows); break;
         MAPF_FOR_EACH_A(X)
 #undef X
         default: return hipErrorInvalidValue;

@@ -5,10 +5,21 @@
 
 namespace mapf {
 
+// Merged slip distribution of one agent for one equality pattern of its three candidate cells
+// (m = intended move, r = right slip, l = left slip; code = (m==r) | (m==l) << 1 | (r==l) << 2).
+// Built on the host by replaying single_agent_movements (mapf_env.py:163-184): drop p <= 0, merge equal
+// cells in first-seen order with old + new, then cumsum left to right.
+struct SlipRow {
+    uint64_t thr[3];               // ceil(cum[k] * 2^53): cum[k] > u  <=>  mant(u) < thr[k]; 0 past the list end
+    double cum[3];                 // running float64 sums (for caller-supplied uniforms); -inf past the list end
+    double q[3];                   // merged probabilities, list order
+    uint32_t src;                  // byte k: candidate (0 m, 1 r, 2 l) in list slot k
+    uint32_t n;                    // list length, 1..3
+};
+
 struct EnvConsts {
-    double p0, rf, lf;             // 1 - rf - lf, right_fail, left_fail (host-computed; mapf_env.py:131-132, :167-169)
     double r_clash, r_goal, r_living;
-    uint32_t keep;                 // bit k set <=> slip candidate k has p > 0 (mapf_env.py:172)
+    uint32_t need_rng;             // 0 when every slip list has one entry (e.g. fail_prob == 0)
     uint32_t criteria;             // 0 Makespan, 1 SoC
     uint32_t n_cells;              // V
     uint32_t seed_lo, seed_hi;     // slip-stream Philox key
@@ -18,6 +29,7 @@ struct EnvConsts {
 struct StepArgs {
     EnvConsts c;
     const uint2 *nbr4;             // [V] {up | right << 16, down | left << 16}
+    const SlipRow *slip;           // [8] device copy of the slip table
     uint16_t *state;               // [E*A] persistent env state
     const uint16_t *start, *goal;  // [E*A] or [A]
     const uint8_t *actions;        // [E*A]
@@ -32,6 +44,7 @@ struct StepArgs {
 struct RolloutArgs {
     EnvConsts c;
     const uint2 *nbr4;
+    const SlipRow *slip;
     uint16_t *state;
     const uint16_t *start, *goal;
     const uint8_t *actions;        // [T*E*A] or null (policy stream)
@@ -56,77 +69,27 @@ hipError_t launch_fill_actions(int n_agents, uint8_t *actions, const EnvConsts &
 hipError_t launch_query_terminal(int n_agents, const uint16_t *state, const uint16_t *goal, bool goal_broadcast,
                                  uint8_t *out, uint64_t n_envs, hipStream_t stream);
 
+// lane-group family (mapf_lg_kernels.hip): any A up to 128, run-time A
+constexpr int kTpeMaxAgents = 16;   // thread-per-env kernels are specialised for A = 1..16
+hipError_t launch_step_lg(int n_agents, const StepArgs &args, hipStream_t stream);
+hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, hipStream_t stream);
+int lg_group_size(int n_agents);
+
 // per-group entry points: group g holds the kernels specialised for A in 4g+1 .. 4g+4
 hipError_t launch_step_g0(int n_agents, const StepArgs &args, hipStream_t stream);
 hipError_t launch_rollout_g0(int n_agents, const RolloutArgs &args, hipStream_t stream);
-hipError_t launch_reset_g0(int n_agents, uint16_t *state, const uint16_t *start, bool start_broadcast,
-                        const uint8_t *mask, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_fill_actions_g0(int n_agents, uint8_t *actions, const EnvConsts &c, uint64_t env_id_offset,
-                               uint64_t n_envs, uint64_t t0, uint64_t n_steps, hipStream_t stream);
 
 hipError_t launch_step_g1(int n_agents, const StepArgs &args, hipStream_t stream);
 hipError_t launch_rollout_g1(int n_agents, const RolloutArgs &args, hipStream_t stream);
-hipError_t launch_reset_g1(int n_agents, uint16_t *state, const uint16_t *start, bool start_broadcast,
-                        const uint8_t *mask, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_fill_actions_g1(int n_agents, uint8_t *actions, const EnvConsts &c, uint64_t env_id_offset,
-                               uint64_t n_envs, uint64_t t0, uint64_t n_steps, hipStream_t stream);
 
 hipError_t launch_step_g2(int n_agents, const StepArgs &args, hipStream_t stream);
 hipError_t launch_rollout_g2(int n_agents, const RolloutArgs &args, hipStream_t stream);
-hipError_t launch_reset_g2(int n_agents, uint16_t *state, const uint16_t *start, bool start_broadcast,
-                        const uint8_t *mask, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_fill_actions_g2(int n_agents, uint8_t *actions, const EnvConsts &c, uint64_t env_id_offset,
-                               uint64_t n_envs, uint64_t t0, uint64_t n_steps, hipStream_t stream);
 
 hipError_t launch_step_g3(int n_agents, const StepArgs &args, hipStream_t stream);
 hipError_t launch_rollout_g3(int n_agents, const RolloutArgs &args, hipStream_t stream);
-hipError_t launch_reset_g3(int n_agents, uint16_t *state, const uint16_t *start, bool start_broadcast,
-                        const uint8_t *mask, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_fill_actions_g3(int n_agents, uint8_t *actions, const EnvConsts &c, uint64_t env_id_offset,
-                               uint64_t n_envs, uint64_t t0, uint64_t n_steps, hipStream_t stream);
 
-hipError_t launch_step_g4(int n_agents, const StepArgs &args, hipStream_t stream);
-hipError_t launch_rollout_g4(int n_agents, const RolloutArgs &args, hipStream_t stream);
-hipError_t launch_reset_g4(int n_agents, uint16_t *state, const uint16_t *start, bool start_broadcast,
-                        const uint8_t *mask, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_fill_actions_g4(int n_agents, uint8_t *actions, const EnvConsts &c, uint64_t env_id_offset,
-                               uint64_t n_envs, uint64_t t0, uint64_t n_steps, hipStream_t stream);
 
-hipError_t launch_step_g5(int n_agents, const StepArgs &args, hipStream_t stream);
-hipError_t launch_rollout_g5(int n_agents, const RolloutArgs &args, hipStream_t stream);
-hipError_t launch_reset_g5(int n_agents, uint16_t *state, const uint16_t *start, bool start_broadcast,
-                        const uint8_t *mask, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_fill_actions_g5(int n_agents, uint8_t *actions, const EnvConsts &c, uint64_t env_id_offset,
-                               uint64_t n_envs, uint64_t t0, uint64_t n_steps, hipStream_t stream);
 
-hipError_t launch_step_g6(int n_agents, const StepArgs &args, hipStream_t stream);
-hipError_t launch_rollout_g6(int n_agents, const RolloutArgs &args, hipStream_t stream);
-hipError_t launch_reset_g6(int n_agents, uint16_t *state, const uint16_t *start, bool start_broadcast,
-                        const uint8_t *mask, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_fill_actions_g6(int n_agents, uint8_t *actions, const EnvConsts &c, uint64_t env_id_offset,
-                               uint64_t n_envs, uint64_t t0, uint64_t n_steps, hipStream_t stream);
 
-hipError_t launch_step_g7(int n_agents, const StepArgs &args, hipStream_t stream);
-hipError_t launch_rollout_g7(int n_agents, const RolloutArgs &args, hipStream_t stream);
-hipError_t launch_reset_g7(int n_agents, uint16_t *state, const uint16_t *start, bool start_broadcast,
-                        const uint8_t *mask, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_fill_actions_g7(int n_agents, uint8_t *actions, const EnvConsts &c, uint64_t env_id_offset,
-                               uint64_t n_envs, uint64_t t0, uint64_t n_steps, hipStream_t stream);
 
-hipError_t launch_query_terminal_g0(int n_agents, const uint16_t *state, const uint16_t *goal, bool goal_broadcast,
-                                 uint8_t *out, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_query_terminal_g1(int n_agents, const uint16_t *state, const uint16_t *goal, bool goal_broadcast,
-                                 uint8_t *out, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_query_terminal_g2(int n_agents, const uint16_t *state, const uint16_t *goal, bool goal_broadcast,
-                                 uint8_t *out, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_query_terminal_g3(int n_agents, const uint16_t *state, const uint16_t *goal, bool goal_broadcast,
-                                 uint8_t *out, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_query_terminal_g4(int n_agents, const uint16_t *state, const uint16_t *goal, bool goal_broadcast,
-                                 uint8_t *out, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_query_terminal_g5(int n_agents, const uint16_t *state, const uint16_t *goal, bool goal_broadcast,
-                                 uint8_t *out, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_query_terminal_g6(int n_agents, const uint16_t *state, const uint16_t *goal, bool goal_broadcast,
-                                 uint8_t *out, uint64_t n_envs, hipStream_t stream);
-hipError_t launch_query_terminal_g7(int n_agents, const uint16_t *state, const uint16_t *goal, bool goal_broadcast,
-                                 uint8_t *out, uint64_t n_envs, hipStream_t stream);
 }  // namespace mapf

@@ -10,9 +10,11 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_int, c_int32
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libmapf_hip.so')
 
 MAPF_OK, MAPF_EINVAL, MAPF_EHIP, MAPF_ENODEVICE, MAPF_EUNSUPPORTED = 0, -1, -2, -3, -4
-MAPF_MAX_AGENTS = 32
+MAPF_MAX_AGENTS = 128
 MAPF_MAKESPAN, MAPF_SOC = 0, 1
 MAPF_FLAG_DEVICE_PTRS, MAPF_FLAG_START_BROADCAST, MAPF_FLAG_GOAL_BROADCAST = 0x1, 0x2, 0x4
+MAPF_FLAG_THREAD_PER_ENV, MAPF_FLAG_LANE_GROUP = 0x10, 0x20
+MAPF_TPE_MAX_AGENTS = 16
 MAPF_STEP_AUTO_RESET = 0x1
 
 

@@ -38,7 +38,7 @@ class VecMapfEnv:
     def __init__(self, grid, n_agents, start_locations, goal_locations, fail_prob,
                  reward_of_collision, reward_of_goal, reward_of_living, optimization_criteria,
                  *, n_envs=None, seed=42, env_id_offset=0, device=0, device_arrays=False, stream=None,
-                 start_local=None, goal_local=None):
+                 start_local=None, goal_local=None, kernel='auto'):
         self.grid = grid
         self.n_agents = int(n_agents)
         self.fail_prob = fail_prob
@@ -71,6 +71,10 @@ class VecMapfEnv:
         flags |= nat.MAPF_FLAG_START_BROADCAST if start_bcast else 0
         flags |= nat.MAPF_FLAG_GOAL_BROADCAST if goal_bcast else 0
         flags |= nat.MAPF_FLAG_DEVICE_PTRS if self.device_arrays else 0
+        # kernel family: both give identical results; 'auto' lets the library choose
+        flags |= {'auto': 0, 'thread_per_env': nat.MAPF_FLAG_THREAD_PER_ENV,
+                  'lane_group': nat.MAPF_FLAG_LANE_GROUP}[kernel]
+        self.kernel = kernel
         nbr = np.ascontiguousarray(self._nbr, dtype=np.uint16)
         desc = nat.MapfDesc(
             struct_size=ctypes.sizeof(nat.MapfDesc), n_cells=self.n_cells, n_agents=self.n_agents,

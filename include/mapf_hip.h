@@ -43,7 +43,7 @@ extern "C" {
 #define MAPF_ENODEVICE    -3  /* no usable HIP device                        */
 #define MAPF_EUNSUPPORTED -4  /* e.g. n_agents beyond MAPF_MAX_AGENTS        */
 
-#define MAPF_MAX_AGENTS 32
+#define MAPF_MAX_AGENTS 128
 
 /* optimisation criteria: mapf_env.py:31-33 OptimizationCriteria */
 #define MAPF_MAKESPAN 0
@@ -53,6 +53,11 @@ extern "C" {
 #define MAPF_FLAG_DEVICE_PTRS     0x1u  /* array args of step/rollout/... are device pointers */
 #define MAPF_FLAG_START_BROADCAST 0x2u  /* desc.start is [A], shared by all envs              */
 #define MAPF_FLAG_GOAL_BROADCAST  0x4u  /* desc.goal  is [A], shared by all envs              */
+/* Kernel family (default: chosen from A and E).  Both compute identical results.
+ *   THREAD_PER_ENV: one lane owns all A agents of an env (A <= 16 only);
+ *   LANE_GROUP:     an env is spread over pow2(ceil(A/2)) adjacent lanes, two agents per lane. */
+#define MAPF_FLAG_THREAD_PER_ENV  0x10u
+#define MAPF_FLAG_LANE_GROUP      0x20u
 
 /* step_flags / rollout flags */
 #define MAPF_STEP_AUTO_RESET      0x1u  /* after a step returns done, the env's stored state

@@ -16,7 +16,7 @@
 #include <stdint.h>
 #include <stddef.h>
 
-#define MAXA 64
+#define MAXA 128
 
 /* ---- Philox4x32-10 (Salmon et al. SC'11); stream layout: oracle/philox.py ---- */
 static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {

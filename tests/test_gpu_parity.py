@@ -12,6 +12,12 @@ from gym_mapf_amd.envs.grid import MapfGrid
 from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv
 
 pytestmark = pytest.mark.gpu
+KERNELS = ('thread_per_env', 'lane_group')
+
+
+def _families(n_agents):
+    """Kernel families that exist for this agent count (thread-per-env is specialised for A <= 16)."""
+    return [k for k in KERNELS if k == 'lane_group' or n_agents <= 16]
 CRIT = {'Makespan': OptimizationCriteria.Makespan, 'SoC': OptimizationCriteria.SoC}
 OCRIT = {'Makespan': mo.MAKESPAN, 'SoC': mo.SOC}
 
@@ -51,25 +57,27 @@ def test_step_with_injected_uniforms_matches_reference(trajectory_set):
     meta, g = trajectory_set
     A, T, E = meta['n_agents'], meta['T'], len(g['env_ids'])
     sel = np.arange(E)
-    env = _vec(meta, g, sel)
-    assert np.array_equal(env.start_local, g['start_local']) and np.array_equal(env.goal_local, g['goal_local'])
-    for t in range(T):
-        u = np.stack([philox.slip_uniforms_np(meta['seed'], [e], t, A)[0] for e in g['env_ids']])
-        local, reward, done, info = env.step(g['actions'][t], uniforms=u, auto_reset=meta['auto_reset'])
-        _check_step(local, reward, done, info, g, t, sel, '%s t=%d' % (meta['name'], t))
-    env.close()
+    us = [np.stack([philox.slip_uniforms_np(meta['seed'], [e], t, A)[0] for e in g['env_ids']]) for t in range(T)]
+    for kernel in _families(A):
+        env = _vec(meta, g, sel, kernel=kernel)
+        assert np.array_equal(env.start_local, g['start_local']) and np.array_equal(env.goal_local, g['goal_local'])
+        for t in range(T):
+            local, reward, done, info = env.step(g['actions'][t], uniforms=us[t], auto_reset=meta['auto_reset'])
+            _check_step(local, reward, done, info, g, t, sel, '%s %s t=%d' % (meta['name'], kernel, t))
+        env.close()
 
 
 def test_step_with_device_philox_matches_reference(trajectory_set):
     """mapf_step(uniforms=NULL): the kernel's own Philox4x32-10 draws, keyed by global env id."""
     meta, g = trajectory_set
-    for lo, hi in _id_runs(g['env_ids']):
-        sel = np.arange(lo, hi)
-        env = _vec(meta, g, sel, env_id_offset=int(g['env_ids'][lo]))
-        for t in range(meta['T']):
-            local, reward, done, info = env.step(g['actions'][t][sel], auto_reset=meta['auto_reset'])
-            _check_step(local, reward, done, info, g, t, sel, '%s ids[%d:%d] t=%d' % (meta['name'], lo, hi, t))
-        env.close()
+    for kernel in _families(meta['n_agents']):
+        for lo, hi in _id_runs(g['env_ids']):
+            sel = np.arange(lo, hi)
+            env = _vec(meta, g, sel, env_id_offset=int(g['env_ids'][lo]), kernel=kernel)
+            for t in range(meta['T']):
+                local, reward, done, info = env.step(g['actions'][t][sel], auto_reset=meta['auto_reset'])
+                _check_step(local, reward, done, info, g, t, sel, '%s %s ids[%d:%d] t=%d' % (meta['name'], kernel, lo, hi, t))
+            env.close()
 
 
 def test_fused_rollout_matches_reference(trajectory_set):
@@ -77,10 +85,10 @@ def test_fused_rollout_matches_reference(trajectory_set):
     streamed actions and with the in-kernel policy stream (the goldens' actions are that stream)."""
     meta, g = trajectory_set
     T = meta['T']
-    for lo, hi in _id_runs(g['env_ids']):
+    for kernel, (lo, hi) in [(k, r) for k in _families(meta['n_agents']) for r in _id_runs(g['env_ids'])]:
         sel = np.arange(lo, hi)
         for actions in (np.ascontiguousarray(g['actions'][:, sel]), None):
-            env = _vec(meta, g, sel, env_id_offset=int(g['env_ids'][lo]))
+            env = _vec(meta, g, sel, env_id_offset=int(g['env_ids'][lo]), kernel=kernel)
             res = env.rollout(T, actions=actions, auto_reset=meta['auto_reset'], record=True)
             assert np.array_equal(res['local'], g['next_local'][:, sel])
             assert np.array_equal(_bits(res['reward']), _bits(g['reward'][:, sel]))
@@ -106,10 +114,10 @@ def test_rollout_split_equals_single_and_accumulates(trajectory_set):
     lo, hi = _id_runs(g['env_ids'])[0]
     sel = np.arange(lo, hi)
     T = meta['T']
-    one = _vec(meta, g, sel)
+    one = _vec(meta, g, sel, kernel='lane_group')
     full = one.rollout(T, auto_reset=True)
     st_full, _ = one.get_state()
-    two = _vec(meta, g, sel)
+    two = _vec(meta, g, sel, kernel=_families(meta['n_agents'])[0])
     part = two.rollout(T // 3, auto_reset=True)
     part = two.rollout(T - T // 3, auto_reset=True, accumulate_into=part)
     st_two, t_two = two.get_state()
@@ -171,10 +179,14 @@ def test_masked_reset_set_get_state_and_query_terminal():
     env.close()
 
 
-@pytest.mark.parametrize('n_agents', [1, 2, 3, 5, 7, 8, 9, 12, 16, 17, 24, 31, 32])
-def test_every_agent_count_specialisation_against_c_oracle(n_agents):
-    """Each A has its own kernel instantiation: run 257 envs x 40 steps on a 20% random map against
-    the C oracle (Philox on both sides), stepwise and fused."""
+@pytest.mark.parametrize('kernel', KERNELS)
+@pytest.mark.parametrize('n_agents', list(range(1, 18)) + [24, 29, 31, 32, 33, 47, 64, 65, 100, 128])
+def test_every_agent_count_against_c_oracle(n_agents, kernel):
+    """Every thread-per-env specialisation (A = 1..16) and every lane-group width (A up to 128, odd
+    counts included): 257 envs x 40 steps on a 20% random map against the C oracle (Philox on both
+    sides), stepwise and fused."""
+    if kernel not in _families(n_agents):
+        pytest.skip('thread-per-env kernels exist for A <= 16')
     rs = np.random.RandomState(100 + n_agents)
     H = W = 24
     lines = [''.join('@' if rs.rand() < 0.2 else '.' for _ in range(W)) for _ in range(H)]
@@ -185,7 +197,7 @@ def test_every_agent_count_specialisation_against_c_oracle(n_agents):
     goal = np.stack([rs.choice(V, A, replace=False) for _ in range(E)]).astype(np.uint16)
     for crit, ocrit, auto in ((OptimizationCriteria.SoC, mo.SOC, True), (OptimizationCriteria.Makespan, mo.MAKESPAN, False)):
         env = VecMapfEnv(grid, A, None, None, 0.3, -1000.0, 100.0, -1.5, crit, seed=7, env_id_offset=12345678901,
-                         start_local=start, goal_local=goal)
+                         start_local=start, goal_local=goal, kernel=kernel)
         co = c_oracle.COracle(nbr, A, start, goal, 0.3, -1000.0, 100.0, -1.5, ocrit, seed=7, env_id_offset=12345678901)
         for t in range(T):
             acts = rs.randint(0, 5, size=(E, A)).astype(np.uint8)
