@@ -129,7 +129,8 @@ def main():
 
     from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv
     E, A, K, W = args.envs, N_AGENTS, args.steps, args.warmup
-    offset = rank * E
+    from gym_mapf_amd import sharding
+    offset = sharding.shard_offset(E, rank)
     grid, nbr, start, goal = workload_tables(E, offset)
     env = VecMapfEnv(grid, A, None, None, FAIL_PROB, R_CLASH, R_GOAL, R_LIVING, OptimizationCriteria.Makespan,
                      seed=SEED, env_id_offset=offset, device=local_rank, device_arrays=True,
@@ -204,11 +205,6 @@ def main():
     rec = {k: res[k] for k in ('local', 'reward', 'done', 'collision', 'prob')}
     barrier()
 
-    def rollout_once(acc):
-        io_res = dict(acc)
-        io_res.update(rec)
-        return io_res
-
     acc = {k: res[k] for k in ('returns', 'episodes', 'collisions')}
     import ctypes
     from gym_mapf_amd import _native as nat
@@ -231,9 +227,10 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         ro_wall = float(tmax.item())
         # the one collective of the path: gather per-env episode returns
-        gathered = torch.empty(world * E, dtype=torch.float64, device='cuda')
-        dist.all_gather_into_tensor(gathered, acc['returns'])
+        env.sync()
+        gathered = sharding.gather_returns(acc['returns'])
         torch.cuda.synchronize()
+        assert gathered.numel() == world * E
     ro_launch_ms = ro_gpu_ms / n_launch
     ro_bytes = float(T) * E * A * bpas
     rollout = {"value": n_launch * float(T) * E * A * world / ro_wall, "unit": "agent-steps/s",

@@ -52,6 +52,9 @@ struct mapf_handle_s {
     mapf::EnvConsts c{};
     bool start_broadcast = false, goal_broadcast = false, device_ptrs = false, own_stream = false;
     bool lane_group = false;   // kernel family
+    // The thread-per-env rollout specialisations for A >= 8 need SGPR spills (the pointer-heavy argument block
+    // plus A-wide unrolling); only spill-free kernels are dispatched, so those sizes use the lane-group rollout.
+    bool lane_group_rollout = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     uint2 *nbr4 = nullptr;
@@ -237,6 +240,7 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
     if (d->flags & MAPF_FLAG_THREAD_PER_ENV) h->lane_group = false;
     else if (d->flags & MAPF_FLAG_LANE_GROUP) h->lane_group = true;
     else h->lane_group = A > 2;
+    h->lane_group_rollout = h->lane_group || A > uint32_t(mapf::kTpeRolloutMaxAgents);
 
     mapf::SlipRow slip_host[8];
     h->c.need_rng = build_slip_table(d->fail_prob, slip_host) ? 1u : 0u;
@@ -377,7 +381,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
         a.actions = io->actions; a.out_returns = io->out_returns; a.out_episodes = io->out_episodes;
         a.out_collisions = io->out_collisions; a.rec_local = io->rec_local; a.rec_reward = io->rec_reward;
         a.rec_done = io->rec_done; a.rec_collision = io->rec_collision; a.rec_prob = io->rec_prob;
-        HIP_TRY(h->lane_group ? mapf::launch_rollout_lg(int(h->A), a, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
+        HIP_TRY(h->lane_group_rollout ? mapf::launch_rollout_lg(int(h->A), a, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
         h->t += io->n_steps;
         return MAPF_OK;
     }
@@ -403,7 +407,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     if (int rc = stage_out(h, h->s_prob, io->rec_prob, TE, &a.rec_prob, "rec_prob")) return rc;
     if (int rc = stage_out(h, h->s_done, io->rec_done, TE, &a.rec_done, "rec_done")) return rc;
     if (int rc = stage_out(h, h->s_coll, io->rec_collision, TE, &a.rec_collision, "rec_collision")) return rc;
-    HIP_TRY(h->lane_group ? mapf::launch_rollout_lg(int(h->A), a, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
+    HIP_TRY(h->lane_group_rollout ? mapf::launch_rollout_lg(int(h->A), a, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
     h->t += io->n_steps;
     if (int rc = fetch_out(h, a.out_returns, io->out_returns, E)) return rc;
     if (int rc = fetch_out(h, a.out_episodes, io->out_episodes, E)) return rc;

@@ -165,7 +165,11 @@ hipError_t MAPF_G(launch_rollout_g)(int n_agents, const RolloutArgs &args, hipSt
     const unsigned block = pick_block(args.n_envs), grid = grid_for(args.n_envs, block);
     switch (n_agents) {
 #define X(N)                                                                                       \
-    case N: hipLaunchKernelGGL((rollout_kernel<N>), dim3(grid), dim3(block), 0, stream, args); break;
+    case N:                                                                                        \
+        if constexpr (N <= kTpeRolloutMaxAgents)                                                   \
+            hipLaunchKernelGGL((rollout_kernel<N>), dim3(grid), dim3(block), 0, stream, args);    \
+        else return hipErrorInvalidValue;                                                          \
+        break;
         MAPF_FOR_EACH_A(X)
 #undef X
         default: return hipErrorInvalidValue;

@@ -70,7 +70,8 @@ hipError_t launch_query_terminal(int n_agents, const uint16_t *state, const uint
                                  uint8_t *out, uint64_t n_envs, hipStream_t stream);
 
 // lane-group family (mapf_lg_kernels.hip): any A up to 128, run-time A
-constexpr int kTpeMaxAgents = 16;   // thread-per-env kernels are specialised for A = 1..16
+constexpr int kTpeMaxAgents = 16;         // thread-per-env step kernels are specialised for A = 1..16
+constexpr int kTpeRolloutMaxAgents = 7;   // ... their rollout form is dispatched only where it is spill-free
 hipError_t launch_step_lg(int n_agents, const StepArgs &args, hipStream_t stream);
 hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, hipStream_t stream);
 int lg_group_size(int n_agents);

@@ -226,3 +226,31 @@ def test_fill_random_actions_matches_policy_stream():
         exp = np.stack([philox.random_actions_np(99, ids, 5 + s, A) for s in range(6)])
         assert np.array_equal(got, exp)
         env.close()
+
+
+def test_results_do_not_depend_on_how_envs_are_sharded():
+    """One handle with 600 envs == three handles owning [0,200), [200,400), [400,600) with global env ids
+    (what bench.py's ranks do): same trajectories, same returns, stepwise and fused."""
+    rs = np.random.RandomState(3)
+    lines = [''.join('@' if rs.rand() < 0.15 else '.' for _ in range(20)) for _ in range(20)]
+    grid = MapfGrid(lines)
+    V, E, A, T = len(grid.tables()[0]), 600, 6, 50
+    start = np.stack([rs.choice(V, A, replace=False) for _ in range(E)]).astype(np.uint16)
+    goal = np.stack([rs.choice(V, A, replace=False) for _ in range(E)]).astype(np.uint16)
+    mk = lambda lo, hi: VecMapfEnv(grid, A, None, None, 0.25, -50.0, 10.0, -1.0, OptimizationCriteria.SoC, seed=5,  # noqa: E731
+                                   env_id_offset=1000 + lo, start_local=start[lo:hi], goal_local=goal[lo:hi])
+    whole, parts = mk(0, E), [mk(lo, lo + 200) for lo in (0, 200, 400)]
+    acts = rs.randint(0, 5, size=(T, E, A)).astype(np.uint8)
+    for t in range(T):
+        l, r, d, info = whole.step(acts[t], auto_reset=True)
+        for k, p in enumerate(parts):
+            sl = slice(200 * k, 200 * k + 200)
+            lp, rp, dp, ip = p.step(acts[t][sl], auto_reset=True)
+            assert np.array_equal(lp, l[sl]) and np.array_equal(_bits(rp), _bits(r[sl])) and np.array_equal(dp, d[sl])
+            assert np.array_equal(_bits(ip['prob']), _bits(info['prob'][sl]))
+    full = whole.rollout(40)
+    for k, p in enumerate(parts):
+        sl = slice(200 * k, 200 * k + 200)
+        assert np.array_equal(_bits(p.rollout(40)['returns']), _bits(full['returns'][sl]))
+    whole.close()
+    [p.close() for p in parts]

@@ -1,0 +1,64 @@
+"""The N > 1 path on CPU: two gloo ranks shard the env axis, build their slice of the bench workload
+and all-gather per-env returns in global-id order.  (The stepping itself is covered on the GPU,
+including placement independence of the RNG: test_gpu_parity.py.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from gym_mapf_amd import sharding
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, envs_per_rank, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import bench
+    offset = sharding.shard_offset(envs_per_rank, rank)
+    _, _, start, goal = bench.workload_tables(envs_per_rank, offset)
+    ids = offset + np.arange(envs_per_rank)
+    local = torch.from_numpy(ids.astype(np.float64) * 0.5 + start[:, 0])       # a value tied to the global id
+    gathered = sharding.gather_returns(local)
+    tmax = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)                                 # bench.py's max-over-ranks timing
+    np.save(os.path.join(out_dir, 'r%d.npy' % rank), gathered.numpy())
+    np.save(os.path.join(out_dir, 's%d.npy' % rank), start)
+    assert float(tmax) == world
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_gather(tmp_path):
+    world, per_rank = 2, 96
+    mp.spawn(_worker, args=(world, _free_port(), per_rank, str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, ROOT)
+    import bench
+    _, _, start_all, _ = bench.workload_tables(world * per_rank, 0)
+    got = [np.load(tmp_path / ('r%d.npy' % r)) for r in range(world)]
+    assert np.array_equal(got[0], got[1])                                       # every rank sees the same gather
+    expect = np.arange(world * per_rank) * 0.5 + start_all[:, 0]
+    assert np.array_equal(got[0], expect)                                       # ordered by global env id
+    shards = np.concatenate([np.load(tmp_path / ('s%d.npy' % r)) for r in range(world)])
+    assert np.array_equal(shards, start_all)                                    # slices tile the global workload
+
+
+def test_split_evenly_covers_every_env_once():
+    for n, world in ((262144, 8), (131072, 8), (10, 4), (7, 8), (0, 3)):
+        spans = [sharding.split_evenly(n, r, world) for r in range(world)]
+        assert sum(c for _, c in spans) == n
+        pos = 0
+        for off, cnt in spans:
+            assert off == pos
+            pos += cnt
+    assert sharding.shard_offset(65536, 3) == 196608
