@@ -57,7 +57,7 @@ struct mapf_handle_s {
     bool lane_group_rollout = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    uint2 *nbr4 = nullptr;
+    uint64_t *mv = nullptr;
     mapf::SlipRow *slip = nullptr;
     uint16_t *state = nullptr, *start = nullptr, *goal = nullptr;
     // host-pointer mode staging
@@ -162,7 +162,7 @@ void destroy_impl(mapf_handle_t h) {
     for (DeviceBuf *b : {&h->s_actions, &h->s_uniforms, &h->s_local, &h->s_reward, &h->s_prob, &h->s_done,
                          &h->s_coll, &h->s_term, &h->s_mask, &h->s_ret, &h->s_epi, &h->s_ncoll})
         b->release();
-    if (h->nbr4) (void)hipFree(h->nbr4);
+    if (h->mv) (void)hipFree(h->mv);
     if (h->slip) (void)hipFree(h->slip);
     if (h->state) (void)hipFree(h->state);
     if (h->start) (void)hipFree(h->start);
@@ -261,20 +261,36 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
     CREATE_TRY(hipEventCreate(&h->ev_begin));
     CREATE_TRY(hipEventCreate(&h->ev_end));
 
-    // pack nbr[V][5] into {up | right << 16, down | left << 16}
-    std::vector<uint2> packed(V);
+    // Move table: for every (cell, action) the merged movement list of single_agent_movements
+    // (mapf_env.py:163-184) -- its cells in list order and the equality code of the three candidates.
+    const double rf_ = d->fail_prob / 2, lf_ = d->fail_prob / 2;
+    const bool keep[3] = {((1 - rf_) - lf_) > 0, rf_ > 0, lf_ > 0};
+    static const uint8_t kSlipRight[5] = {0, 2, 3, 4, 1}, kSlipLeft[5] = {0, 4, 1, 2, 3};   // __init__.py:19-25
+    std::vector<uint64_t> packed(size_t(V) * 5);
     for (uint32_t v = 0; v < V; ++v) {
         const uint16_t *r = d->nbr + uint64_t(v) * 5;
-        packed[v] = make_uint2(uint32_t(r[1]) | (uint32_t(r[2]) << 16), uint32_t(r[3]) | (uint32_t(r[4]) << 16));
+        for (uint32_t a = 0; a < 5; ++a) {
+            const uint16_t cand[3] = {r[a], r[kSlipRight[a]], r[kSlipLeft[a]]};
+            const uint64_t code = (cand[0] == cand[1] ? 1u : 0u) | (cand[0] == cand[2] ? 2u : 0u) | (cand[1] == cand[2] ? 4u : 0u);
+            uint16_t cells[3] = {0, 0, 0};
+            int n = 0;
+            for (int k = 0; k < 3; ++k) {
+                if (!keep[k]) continue;
+                bool seen = false;
+                for (int j = 0; j < n; ++j) seen |= (cells[j] == cand[k]);
+                if (!seen) cells[n++] = cand[k];
+            }
+            packed[size_t(v) * 5 + a] = uint64_t(cells[0]) | (uint64_t(cells[1]) << 16) | (uint64_t(cells[2]) << 32) | (code << 48);
+        }
     }
     const size_t row = size_t(A) * sizeof(uint16_t);
-    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->nbr4), size_t(V) * sizeof(uint2)));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->mv), packed.size() * sizeof(uint64_t)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->state), (E ? E : 1) * row));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->start), (sb ? 1 : (E ? E : 1)) * row));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->goal), (gb ? 1 : (E ? E : 1)) * row));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->slip), sizeof(slip_host)));
     CREATE_TRY(hipMemcpy(h->slip, slip_host, sizeof(slip_host), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(h->nbr4, packed.data(), size_t(V) * sizeof(uint2), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->mv, packed.data(), packed.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     if (n_start) CREATE_TRY(hipMemcpy(h->start, d->start, n_start * sizeof(uint16_t), hipMemcpyHostToDevice));
     if (n_goal) CREATE_TRY(hipMemcpy(h->goal, d->goal, n_goal * sizeof(uint16_t), hipMemcpyHostToDevice));
     CREATE_TRY(mapf::launch_reset(int(A), h->state, h->start, sb, nullptr, E, h->stream));
@@ -336,7 +352,7 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     if (step_flags & ~MAPF_STEP_AUTO_RESET) return fail(MAPF_EINVAL, "unknown step flag");
     const size_t E = size_t(h->E), EA = E * h->A;
     mapf::StepArgs a{};
-    a.c = h->c; a.nbr4 = h->nbr4; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
+    a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
     a.n_envs = h->E; a.env_id_offset = h->env_id_offset; a.t = h->t;
     a.start_broadcast = h->start_broadcast; a.goal_broadcast = h->goal_broadcast;
     a.auto_reset = step_flags & MAPF_STEP_AUTO_RESET;
@@ -368,7 +384,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     if (io->step_flags & ~MAPF_STEP_AUTO_RESET) return fail(MAPF_EINVAL, "unknown step flag");
     const size_t E = size_t(h->E), T = io->n_steps, TE = T * E, TEA = TE * h->A;
     mapf::RolloutArgs a{};
-    a.c = h->c; a.nbr4 = h->nbr4; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
+    a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
     a.n_envs = h->E; a.env_id_offset = h->env_id_offset; a.t = h->t; a.n_steps = io->n_steps;
     a.start_broadcast = h->start_broadcast; a.goal_broadcast = h->goal_broadcast;
     a.auto_reset = io->step_flags & MAPF_STEP_AUTO_RESET;

@@ -63,12 +63,6 @@ struct StepResult {
     bool done, collision, was_terminal;
 };
 
-// nbr4[v] = {up | right << 16, down | left << 16}; STAY is the cell itself.
-__device__ __forceinline__ uint32_t pick_move(uint32_t cell, uint64_t n64, uint32_t a) {
-    const uint32_t moved = uint32_t(n64 >> (((a - 1u) & 3u) * 16u)) & 0xFFFFu;
-    return a == 0u ? cell : moved;
-}
-
 // The slip table lives in LDS: 8 rows (one per equality code of the three candidate cells), built on
 // the host by replaying single_agent_movements (mapf_env.py:163-184) -- see build_slip_table().
 __device__ __forceinline__ void stage_slip_table(const SlipRow *__restrict__ src, SlipRow *lds) {
@@ -79,19 +73,14 @@ __device__ __forceinline__ void stage_slip_table(const SlipRow *__restrict__ src
     __syncthreads();
 }
 
-// One agent: candidates (intended, slip right, slip left) -> merged list -> sampled target.
-// `mant` is the 53-bit integer of the uniform (u = mant * 2^-53), used when !EXT_UNIFORMS.
+// One agent.  `entry` = move table row of (cell, action): the merged movement list's cells in list order
+// (c0 | c1 << 16 | c2 << 32) and the equality code of its three candidates (bits 48..50) -- the code picks
+// the LDS row holding that list's probabilities and cumulative thresholds.  `mant` is the 53-bit integer
+// of the uniform (u = mant * 2^-53), used when !EXT_UNIFORMS.
 template <bool EXT_UNIFORMS>
-__device__ __forceinline__ void slip_move(const SlipRow *lds_slip, uint32_t cell, uint64_t n64, uint32_t a,
-                                          uint64_t mant, double u, uint32_t &next, double &q) {
-    // POSSIBILITIES (gym_mapf/envs/__init__.py:19-25): right/left slips of UP,RIGHT,DOWN,LEFT
-    const uint32_t ar = a == 0u ? 0u : (a & 3u) + 1u;
-    const uint32_t al = a == 0u ? 0u : ((a + 2u) & 3u) + 1u;
-    const uint32_t m = pick_move(cell, n64, a);
-    const uint32_t r = pick_move(cell, n64, ar);
-    const uint32_t l = pick_move(cell, n64, al);
-    const uint32_t code = (m == r ? 1u : 0u) | (m == l ? 2u : 0u) | (r == l ? 4u : 0u);
-    const SlipRow &row = lds_slip[code];
+__device__ __forceinline__ void slip_move(const SlipRow *lds_slip, uint64_t entry, uint64_t mant, double u,
+                                          uint32_t &next, double &q) {
+    const SlipRow &row = lds_slip[uint32_t(entry >> 48) & 7u];
     // categorical_sample (call site mapf_env.py:255): (cumsum(p) > u).argmax(), all-False -> 0.
     // cum[k] > u  <=>  mant < ceil(cum[k] * 2^53) = thr[k]; rows shorter than 3 carry thr = 0 / cum = -inf.
     bool b0, b1, b2;
@@ -101,13 +90,20 @@ __device__ __forceinline__ void slip_move(const SlipRow *lds_slip, uint32_t cell
         b0 = mant < row.thr[0]; b1 = mant < row.thr[1]; b2 = mant < row.thr[2];
     }
     const uint32_t idx = b0 ? 0u : (b1 ? 1u : (b2 ? 2u : 0u));
-    const uint32_t src = (row.src >> (idx * 8u)) & 0xFFu;   // which candidate sits in list slot idx
-    next = src == 0u ? m : (src == 1u ? r : l);
+    const uint32_t lo = uint32_t(entry), hi = uint32_t(entry >> 32);
+    next = idx == 0u ? (lo & 0xFFFFu) : (idx == 1u ? (lo >> 16) : (hi & 0xFFFFu));
     q = row.q[idx];
 }
 
+// address of the move-table row; cells beyond V (only reachable through a corrupted state) are clamped
+__device__ __forceinline__ uint64_t move_entry(const uint64_t *__restrict__ mv, uint32_t n_cells, uint32_t cell,
+                                               uint32_t action) {
+    const uint32_t c = cell < n_cells ? cell : n_cells - 1u;
+    return mv[c * 5u + action];
+}
+
 template <int A, bool EXT_UNIFORMS>
-__device__ __forceinline__ void env_transition(const EnvConsts &c, const uint2 *__restrict__ nbr4,
+__device__ __forceinline__ void env_transition(const EnvConsts &c, const uint64_t *__restrict__ mv,
                                                const SlipRow *lds_slip,
                                                const uint32_t (&prev)[A], const uint32_t (&goal)[A],
                                                const uint32_t (&act_in)[A], const double *ext_u,
@@ -136,13 +132,9 @@ __device__ __forceinline__ void env_transition(const EnvConsts &c, const uint2 *
     for (int i = 0; i < A; ++i) act[i] = act_in[i] > 4u ? 0u : act_in[i];
 
     // the table rows of all agents are independent gathers: issue them together
-    uint64_t n64[A];
+    uint64_t entry[A];
 #pragma unroll
-    for (int i = 0; i < A; ++i) {
-        const uint32_t cell = prev[i] < c.n_cells ? prev[i] : c.n_cells - 1u;
-        const uint2 nb = nbr4[cell];
-        n64[i] = uint64_t(nb.x) | (uint64_t(nb.y) << 32);
-    }
+    for (int i = 0; i < A; ++i) entry[i] = move_entry(mv, c.n_cells, prev[i], act[i]);
 
     double prob = 1.0;
     uint32_t w[4] = {0u, 0u, 0u, 0u};
@@ -162,7 +154,7 @@ __device__ __forceinline__ void env_transition(const EnvConsts &c, const uint2 *
             }
         }
         double pr;
-        slip_move<EXT_UNIFORMS>(lds_slip, prev[i], n64[i], act[i], mant, u, out.next[i], pr);
+        slip_move<EXT_UNIFORMS>(lds_slip, entry[i], mant, u, out.next[i], pr);
         prob = (i == 0) ? pr : __dmul_rn(prob, pr);  // total_prob *= p, agent order (:257)
     }
     out.prob = prob;

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs p) {
     }
 
     StepResult<A> res;
-    env_transition<A, EXT_UNIFORMS>(p.c, p.nbr4, slip, prev, goal, act, uext, p.env_id_offset + e, p.t, res);
+    env_transition<A, EXT_UNIFORMS>(p.c, p.mv, slip, prev, goal, act, uext, p.env_id_offset + e, p.t, res);
 
     Row<uint16_t, A> nx;
 #pragma unroll
@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) rollout_kernel(const RolloutArgs p) {
             policy_actions<A>(p.c, env_id, t, act);
         }
         StepResult<A> res;
-        env_transition<A, false>(p.c, p.nbr4, slip, cur, goal, act, nullptr, env_id, t, res);
+        env_transition<A, false>(p.c, p.mv, slip, cur, goal, act, nullptr, env_id, t, res);
 
         ret = __dadd_rn(ret, res.reward);
         episodes += res.done ? 1u : 0u;

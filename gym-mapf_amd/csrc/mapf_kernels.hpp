@@ -13,7 +13,7 @@ struct SlipRow {
     uint64_t thr[3];               // ceil(cum[k] * 2^53): cum[k] > u  <=>  mant(u) < thr[k]; 0 past the list end
     double cum[3];                 // running float64 sums (for caller-supplied uniforms); -inf past the list end
     double q[3];                   // merged probabilities, list order
-    uint32_t src;                  // byte k: candidate (0 m, 1 r, 2 l) in list slot k
+    uint32_t src;                  // byte k: candidate (0 m, 1 r, 2 l) in list slot k (host bookkeeping)
     uint32_t n;                    // list length, 1..3
 };
 
@@ -28,7 +28,7 @@ struct EnvConsts {
 
 struct StepArgs {
     EnvConsts c;
-    const uint2 *nbr4;             // [V] {up | right << 16, down | left << 16}
+    const uint64_t *mv;            // [V*5] move table: list cells c0 | c1<<16 | c2<<32, equality code << 48
     const SlipRow *slip;           // [8] device copy of the slip table
     uint16_t *state;               // [E*A] persistent env state
     const uint16_t *start, *goal;  // [E*A] or [A]
@@ -43,7 +43,7 @@ struct StepArgs {
 
 struct RolloutArgs {
     EnvConsts c;
-    const uint2 *nbr4;
+    const uint64_t *mv;
     const SlipRow *slip;
     uint16_t *state;
     const uint16_t *start, *goal;
