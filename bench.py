@@ -9,11 +9,12 @@ Workload (BASELINE.json configs[2], SURVEY.md 8(d) "C3"): room-32-32-4, 8 agents
 ids so results do not depend on the rank count), synthetic uniform-random actions resident in
 HBM before the timed region, every done env auto-reset as the reference's caller loop does.
 
-A "step" is one mapf_step launch over the rank's envs: every output (next cells, reward,
-done, collision, prob) is written to HBM.  K steps are enqueued back to back on the env's HIP
-stream between barrier + synchronize on both sides; rank 0 prints ONE JSON line.  Extra keys:
-  roofline      dominant kernel (step_kernel<8>) -- algorithmic bytes / HIP-event time per launch
-  rollout       the fused T-step kernel (mapf_rollout with trajectory recording), same workload
+A "step" is one MapfEnv.step() of every env of the rank: every output (next cells, reward, done,
+collision, prob) is written to HBM.  The headline leg fuses T = 64 steps per mapf_rollout launch
+(state stays in registers between steps); K steps = ceil(K/T) launches enqueued back to back on the
+env's HIP stream between barrier + synchronize on both sides; rank 0 prints ONE JSON line.  Keys:
+  roofline      dominant kernel (lg_rollout_kernel<4,true>) -- algorithmic bytes / HIP-event time per launch
+  single_step_launches   the same steps as one mapf_step launch each (launch-latency bound at this size)
   cpu_baseline  the pure-Python restatement of the reference (oracle/, kind "port") timed on
                 this box's host cores on a bounded sample (rank 0, N=1 only)
   parity        bit-exact check of the first steps of this very run against the C oracle
@@ -169,91 +170,105 @@ def main():
         env.reset()
         env.set_state(None, t=0)
 
-    # ---- the timed region: K single-step launches
-    out = None
-    calls = []
-    for r in range(ring):
-        call, out = env.prepare_step(actions[r], auto_reset=True, out=out)
-        calls.append(call)
-    for k in range(W):
-        calls[k % ring]()
-    barrier()
-    env.timer_begin()
-    t0 = time.perf_counter()
-    for k in range(K):
-        calls[(W + k) % ring]()
-    gpu_ms = env.timer_end()                                        # HIP events on the env's stream
-    barrier()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        tmax = torch.tensor([wall], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall = float(tmax.item())
-    agent_steps = float(K) * E * A * world
-    value = agent_steps / wall
-    bpas = bytes_per_agent_step(A)
-    launch_bytes = E * A * bpas
-    step_ms = gpu_ms / K
-    roof_achieved = launch_bytes / (step_ms * 1e-3) / 1e9
-
-    # ---- fused rollout leg (same workload, T steps per launch, trajectory recorded to HBM)
-    T = args.rollout_steps
-    rec = None
-    n_launch = max(1, K // T)
-    env.reset()
-    res = env.rollout(T, auto_reset=True, record=True)
-    rec = {k: res[k] for k in ('local', 'reward', 'done', 'collision', 'prob')}
-    barrier()
-
-    acc = {k: res[k] for k in ('returns', 'episodes', 'collisions')}
     import ctypes
     from gym_mapf_amd import _native as nat
-    io = nat.MapfRolloutIO(struct_size=ctypes.sizeof(nat.MapfRolloutIO), n_steps=T, step_flags=nat.MAPF_STEP_AUTO_RESET,
-                           accumulate=1, actions=None, out_returns=acc['returns'].data_ptr(),
-                           out_episodes=acc['episodes'].data_ptr(), out_collisions=acc['collisions'].data_ptr(),
-                           rec_local=rec['local'].data_ptr(), rec_reward=rec['reward'].data_ptr(),
-                           rec_done=rec['done'].data_ptr(), rec_collision=rec['collision'].data_ptr(),
-                           rec_prob=rec['prob'].data_ptr())
-    barrier()
-    env.timer_begin()
-    t0 = time.perf_counter()
-    for _ in range(n_launch):
+    bpas = bytes_per_agent_step(A)
+
+    def timed(enqueue, n_warm, n_timed):
+        """barrier + sync, n_timed enqueues bracketed by HIP events on the env's stream, barrier + sync;
+        returns (max-over-ranks wall seconds, HIP-event milliseconds)."""
+        for k in range(n_warm):
+            enqueue(k)
+        barrier()
+        env.timer_begin()
+        t0 = time.perf_counter()
+        for k in range(n_timed):
+            enqueue(n_warm + k)
+        gpu_ms = env.timer_end()
+        barrier()
+        wall = time.perf_counter() - t0
+        if dist is not None:
+            tmax = torch.tensor([wall], dtype=torch.float64, device='cuda')
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            wall = float(tmax.item())
+        return wall, gpu_ms
+
+    # ---- headline leg: K steps as fused mapf_rollout launches of T steps each.  Every step's outputs
+    # (next cells, reward, done, collision, prob) are written to HBM, actions are streamed from the ring.
+    T = max(1, min(args.rollout_steps, ring, K))
+    rec = {'local': env._empty((T, E, A), np.uint16), 'reward': env._empty((T, E), np.float64),
+           'prob': env._empty((T, E), np.float64), 'done': env._empty((T, E), np.uint8),
+           'collision': env._empty((T, E), np.uint8)}
+    acc = {'returns': torch.zeros(E, dtype=torch.float64, device='cuda'),
+           'episodes': torch.zeros(E, dtype=torch.int32, device='cuda').view(torch.uint32),
+           'collisions': torch.zeros(E, dtype=torch.int32, device='cuda').view(torch.uint32)}
+    n_slots = max(1, ring // T)
+
+    def rollout_io(slot, n_steps):
+        return nat.MapfRolloutIO(
+            struct_size=ctypes.sizeof(nat.MapfRolloutIO), n_steps=n_steps, step_flags=nat.MAPF_STEP_AUTO_RESET,
+            accumulate=1, actions=actions[slot * T].data_ptr(), out_returns=acc['returns'].data_ptr(),
+            out_episodes=acc['episodes'].data_ptr(), out_collisions=acc['collisions'].data_ptr(),
+            rec_local=rec['local'].data_ptr(), rec_reward=rec['reward'].data_ptr(), rec_done=rec['done'].data_ptr(),
+            rec_collision=rec['collision'].data_ptr(), rec_prob=rec['prob'].data_ptr())
+
+    ios = [rollout_io(slot, T) for slot in range(n_slots)]
+    n_full, tail = divmod(K, T)
+    io_tail = rollout_io(n_full % n_slots, tail) if tail else None
+    n_launch = n_full + (1 if tail else 0)
+
+    def enqueue_rollout(k):
+        io = io_tail if (tail and k == W_launch + n_full) else ios[k % n_slots]
         nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(io)))
-    ro_gpu_ms = env.timer_end()
-    barrier()
-    ro_wall = time.perf_counter() - t0
+
+    W_launch = max(1, W // T)
+    env.reset()
+    wall, gpu_ms = timed(enqueue_rollout, W_launch, n_launch)
+    agent_steps = float(K) * E * A * world
+    value = agent_steps / wall
+    ro_launch_ms = gpu_ms / n_launch
+    ro_bytes = (float(K) / n_launch) * E * A * bpas                 # algorithmic bytes of an average launch
+    ro_achieved = ro_bytes / (ro_launch_ms * 1e-3) / 1e9
     if dist is not None:
-        tmax = torch.tensor([ro_wall], dtype=torch.float64, device='cuda')
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        ro_wall = float(tmax.item())
         # the one collective of the path: gather per-env episode returns (SURVEY.md 8(e))
         env.sync()
         gathered = sharding.gather_returns(acc['returns'])
         torch.cuda.synchronize()
         assert gathered.numel() == world * E
-    ro_launch_ms = ro_gpu_ms / n_launch
-    ro_bytes = float(T) * E * A * bpas
-    rollout = {"value": n_launch * float(T) * E * A * world / ro_wall, "unit": "agent-steps/s",
-               "steps_per_launch": T, "launches": n_launch, "ms_per_launch": ro_launch_ms, "records_trajectory": True,
-               "actions": "in-kernel policy stream (Philox, key seed+1)",
-               "roofline": {"bound": "hbm", "achieved": ro_bytes / (ro_launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                            "unit": "GB/s", "frac": ro_bytes / (ro_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                            "traffic": None}}
+
+    # ---- second leg: the same K steps as single-step mapf_step launches (one kernel launch per step)
+    out = None
+    calls = []
+    for r in range(ring):
+        call, out = env.prepare_step(actions[r], auto_reset=True, out=out)
+        calls.append(call)
+    env.reset()
+    K1 = min(K, 4000)
+    wall1, gpu_ms1 = timed(lambda k: calls[k % ring](), min(W, 200), K1)
+    step_ms = gpu_ms1 / K1
+    launch_bytes = E * A * bpas
+    single = {"value": float(K1) * E * A * world / wall1, "unit": "agent-steps/s", "steps": K1,
+              "ms_per_step": wall1 * 1e3 / K1, "kernel": "mapf::lg_step_kernel<4,true,false>",
+              "roofline": {"bound": "hbm", "achieved": launch_bytes / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                           "unit": "GB/s", "frac": launch_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                           "traffic": None, "bytes_per_launch": launch_bytes, "ms_per_launch_hip_events": step_ms}}
 
     if rank == 0:
         line = {
             "metric": "agent-steps/sec (batched MapfEnv.step)", "value": value, "unit": "agent-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u16/f64", "data": "synthetic",
-            "config": {"workload": "room-32-32-4 map, 8 agents, slip=0.2, %d envs per GPU (BASELINE configs[2]), "
-                                   "Makespan, auto-reset, one mapf_step launch per step" % E,
+            "config": {"workload": "room-32-32-4 map, 8 agents, slip=0.2, %d envs per GPU (BASELINE configs[2]), Makespan, "
+                                   "auto-reset; steps fused %d per mapf_rollout launch, every step's next cells / reward / "
+                                   "done / collision / prob written to HBM, actions streamed from HBM" % (E, T),
                        "envs_per_gpu": E, "n_agents": A, "fail_prob": FAIL_PROB, "seed": SEED,
-                       "action_ring_steps": ring, "parallelism": "env-sharded x%d" % world},
-            "roofline": {"bound": "hbm", "achieved": roof_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": roof_achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "mapf::step_kernel<8,false>", "bytes_per_launch": launch_bytes,
-                         "ms_per_launch_hip_events": step_ms},
-            "rollout": rollout,
+                       "steps_per_launch": T, "launches": n_launch, "action_ring_steps": ring,
+                       "parallelism": "env-sharded x%d" % world},
+            "roofline": {"bound": "hbm", "achieved": ro_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ro_achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "mapf::lg_rollout_kernel<4,true>", "bytes_per_launch": ro_bytes,
+                         "ms_per_launch_hip_events": ro_launch_ms},
+            "single_step_launches": single,
             "parity": parity,
         }
         if world == 1 and not args.no_cpu_baseline:

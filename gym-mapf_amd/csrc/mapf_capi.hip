@@ -62,6 +62,7 @@ struct mapf_handle_s {
     uint16_t *state = nullptr, *start = nullptr, *goal = nullptr;
     // host-pointer mode staging
     DeviceBuf s_actions, s_uniforms, s_local, s_reward, s_prob, s_done, s_coll, s_term, s_mask, s_ret, s_epi, s_ncoll;
+    DeviceBuf x_local, x_reward, x_prob, x_done, x_coll;   // stand-ins for trajectory arrays the caller left out
 };
 
 namespace {
@@ -70,6 +71,16 @@ int check_handle(mapf_handle_t h) {
     if (!h) return fail(MAPF_EINVAL, "null handle");
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    return MAPF_OK;
+}
+
+// The lane-group kernels address every array with 32-bit byte offsets (one SGPR base + one VGPR offset per
+// access): the largest array of a call must stay below 4 GiB.  rows = E (step) or T*E (rollout).
+int check_extent(mapf_handle_t h, uint64_t rows, bool has_uniforms) {
+    const uint64_t limit = uint64_t(1) << 32;
+    const uint64_t per_agent = has_uniforms ? sizeof(double) : sizeof(uint16_t);
+    if (rows * h->A * per_agent >= limit || rows * sizeof(double) >= limit)
+        return fail(MAPF_EINVAL, "call too large: every array of one call must stay below 4 GiB (use fewer steps per rollout)");
     return MAPF_OK;
 }
 
@@ -160,7 +171,8 @@ void destroy_impl(mapf_handle_t h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->s_actions, &h->s_uniforms, &h->s_local, &h->s_reward, &h->s_prob, &h->s_done,
-                         &h->s_coll, &h->s_term, &h->s_mask, &h->s_ret, &h->s_epi, &h->s_ncoll})
+                         &h->s_coll, &h->s_term, &h->s_mask, &h->s_ret, &h->s_epi, &h->s_ncoll, &h->x_local, &h->x_reward,
+                         &h->x_prob, &h->x_done, &h->x_coll})
         b->release();
     if (h->mv) (void)hipFree(h->mv);
     if (h->slip) (void)hipFree(h->slip);
@@ -350,6 +362,7 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     if (int rc = check_handle(h)) return rc;
     if (!actions) return fail(MAPF_EINVAL, "actions is null");
     if (step_flags & ~MAPF_STEP_AUTO_RESET) return fail(MAPF_EINVAL, "unknown step flag");
+    if (int rc = check_extent(h, h->E, uniforms != nullptr)) return rc;
     const size_t E = size_t(h->E), EA = E * h->A;
     mapf::StepArgs a{};
     a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
@@ -378,10 +391,25 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     return MAPF_OK;
 }
 
+namespace {
+// The recording rollout kernels write all five trajectory arrays (no per-array branches in the step loop): when
+// the caller asked for only some of them, the others go to handle-owned scratch.
+int complete_recording(mapf_handle_t h, mapf::RolloutArgs &a, size_t TE, size_t TEA) {
+    if (!(a.rec_local || a.rec_reward || a.rec_prob || a.rec_done || a.rec_collision)) return MAPF_OK;
+    if (!a.rec_local) { HIP_TRY(h->x_local.reserve(TEA * sizeof(uint16_t))); a.rec_local = static_cast<uint16_t *>(h->x_local.ptr); }
+    if (!a.rec_reward) { HIP_TRY(h->x_reward.reserve(TE * sizeof(double))); a.rec_reward = static_cast<double *>(h->x_reward.ptr); }
+    if (!a.rec_prob) { HIP_TRY(h->x_prob.reserve(TE * sizeof(double))); a.rec_prob = static_cast<double *>(h->x_prob.ptr); }
+    if (!a.rec_done) { HIP_TRY(h->x_done.reserve(TE)); a.rec_done = static_cast<uint8_t *>(h->x_done.ptr); }
+    if (!a.rec_collision) { HIP_TRY(h->x_coll.reserve(TE)); a.rec_collision = static_cast<uint8_t *>(h->x_coll.ptr); }
+    return MAPF_OK;
+}
+}  // namespace
+
 int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     if (int rc = check_handle(h)) return rc;
     if (!io || io->struct_size != sizeof(mapf_rollout_io)) return fail(MAPF_EINVAL, "bad mapf_rollout_io");
     if (io->step_flags & ~MAPF_STEP_AUTO_RESET) return fail(MAPF_EINVAL, "unknown step flag");
+    if (int rc = check_extent(h, uint64_t(h->E) * io->n_steps, false)) return rc;
     const size_t E = size_t(h->E), T = io->n_steps, TE = T * E, TEA = TE * h->A;
     mapf::RolloutArgs a{};
     a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
@@ -397,6 +425,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
         a.actions = io->actions; a.out_returns = io->out_returns; a.out_episodes = io->out_episodes;
         a.out_collisions = io->out_collisions; a.rec_local = io->rec_local; a.rec_reward = io->rec_reward;
         a.rec_done = io->rec_done; a.rec_collision = io->rec_collision; a.rec_prob = io->rec_prob;
+        if (int rc = complete_recording(h, a, TE, TEA)) return rc;
         HIP_TRY(h->lane_group_rollout ? mapf::launch_rollout_lg(int(h->A), a, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
         h->t += io->n_steps;
         return MAPF_OK;
@@ -423,6 +452,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     if (int rc = stage_out(h, h->s_prob, io->rec_prob, TE, &a.rec_prob, "rec_prob")) return rc;
     if (int rc = stage_out(h, h->s_done, io->rec_done, TE, &a.rec_done, "rec_done")) return rc;
     if (int rc = stage_out(h, h->s_coll, io->rec_collision, TE, &a.rec_collision, "rec_collision")) return rc;
+    if (int rc = complete_recording(h, a, TE, TEA)) return rc;
     HIP_TRY(h->lane_group_rollout ? mapf::launch_rollout_lg(int(h->A), a, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
     h->t += io->n_steps;
     if (int rc = fetch_out(h, a.out_returns, io->out_returns, E)) return rc;

@@ -80,19 +80,26 @@ __device__ __forceinline__ void stage_slip_table(const SlipRow *__restrict__ src
 template <bool EXT_UNIFORMS>
 __device__ __forceinline__ void slip_move(const SlipRow *lds_slip, uint64_t entry, uint64_t mant, double u,
                                           uint32_t &next, double &q) {
+#if defined(MAPF_ABLATE) && (MAPF_ABLATE & 8)
+    const SlipRow &row = lds_slip[0];
+#else
     const SlipRow &row = lds_slip[uint32_t(entry >> 48) & 7u];
+#endif
     // categorical_sample (call site mapf_env.py:255): (cumsum(p) > u).argmax(), all-False -> 0.
     // cum[k] > u  <=>  mant < ceil(cum[k] * 2^53) = thr[k]; rows shorter than 3 carry thr = 0 / cum = -inf.
+    // The three candidate probabilities are fetched together with the thresholds (one LDS round trip) and the
+    // sampled one is picked in registers.
+    const double qa = row.q[0], qb = row.q[1], qc = row.q[2];
     bool b0, b1, b2;
     if (EXT_UNIFORMS) {
         b0 = row.cum[0] > u; b1 = row.cum[1] > u; b2 = row.cum[2] > u;
     } else {
         b0 = mant < row.thr[0]; b1 = mant < row.thr[1]; b2 = mant < row.thr[2];
     }
-    const uint32_t idx = b0 ? 0u : (b1 ? 1u : (b2 ? 2u : 0u));
+    const bool pick1 = !b0 && b1, pick2 = !b0 && !b1 && b2;
     const uint32_t lo = uint32_t(entry), hi = uint32_t(entry >> 32);
-    next = idx == 0u ? (lo & 0xFFFFu) : (idx == 1u ? (lo >> 16) : (hi & 0xFFFFu));
-    q = row.q[idx];
+    next = pick2 ? (hi & 0xFFFFu) : (pick1 ? (lo >> 16) : (lo & 0xFFFFu));
+    q = pick2 ? qc : (pick1 ? qb : qa);
 }
 
 // address of the move-table row; cells beyond V (only reachable through a corrupted state) are clamped

@@ -11,8 +11,8 @@ namespace mapf {
 // cells in first-seen order with old + new, then cumsum left to right.
 struct SlipRow {
     uint64_t thr[3];               // ceil(cum[k] * 2^53): cum[k] > u  <=>  mant(u) < thr[k]; 0 past the list end
+    double q[3];                   // merged probabilities, list order (thr and q sit together: one LDS round trip)
     double cum[3];                 // running float64 sums (for caller-supplied uniforms); -inf past the list end
-    double q[3];                   // merged probabilities, list order
     uint32_t src;                  // byte k: candidate (0 m, 1 r, 2 l) in list slot k (host bookkeeping)
     uint32_t n;                    // list length, 1..3
 };

@@ -15,12 +15,27 @@
 #include "mapf_kernels.hpp"
 #include "mapf_device.hpp"
 
+#ifndef MAPF_ABLATE
+#define MAPF_ABLATE 0          // timing experiments only (scratch builds): bit 0 no Philox, 1 no prob chain,
+#endif                         // 2 no pair tests, 3 no slip LDS rows, 4 no move-table gather
+
+#ifdef MAPF_STAMPS   // diagnostic build only: per-segment cycle sums of the rollout loop (never shipped)
+struct StampCtx { unsigned long long seg[8]; unsigned long long last; };
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); st.seg[i] += _t - st.last; st.last = _t; } while (0)
+#define STAMP_PARAM , StampCtx &st
+#define STAMP_ARG , st
+#else
+#define STAMP(i)
+#define STAMP_PARAM
+#define STAMP_ARG
+#endif
+
 namespace mapf {
 
 template <int L>
 struct LaneCtx {
     uint32_t lane, g, base;      // lane in wave, position in group, first lane of the group
-    uint64_t e;                  // env index (local to the handle)
+    uint32_t e;                  // env index (local to the handle)
     bool v0, v1;                 // my two agent slots exist (2g < A, 2g+1 < A)
 };
 
@@ -73,11 +88,18 @@ __device__ __forceinline__ double group_bcast_f64(double v, const LaneCtx<L> &x)
     return __hiloint2double(int(hi), int(lo));
 }
 
-// bits of a wave ballot that belong to my group, right-aligned
-template <int L>
-__device__ __forceinline__ uint64_t group_bits(uint64_t ballot, uint32_t base) {
-    if (L == 64) return ballot;
-    return (ballot >> base) & ((uint64_t(1) << L) - 1u);
+// OR / sum of a per-lane word over my group, result in every lane.  Butterfly of DPP steps inside a 16-lane
+// row (pairs, quads, half-row mirror, row mirror); ds_bpermute xor-partners beyond a row.
+template <int L, bool ADD>
+__device__ __forceinline__ uint32_t group_reduce(uint32_t v, const LaneCtx<L> &x) {
+    auto comb = [](uint32_t a, uint32_t b) { return ADD ? a + b : (a | b); };
+    if constexpr (L >= 2) v = comb(v, dpp_mov<0xB1>(v));           // quad_perm [1,0,3,2]
+    if constexpr (L >= 4) v = comb(v, dpp_mov<0x4E>(v));           // quad_perm [2,3,0,1]
+    if constexpr (L >= 8) v = comb(v, dpp_mov<0x141>(v));          // row_half_mirror
+    if constexpr (L >= 16) v = comb(v, dpp_mov<0x140>(v));         // row_mirror
+    if constexpr (L >= 32) v = comb(v, uint32_t(__shfl_xor(int(v), 16, 64)));
+    if constexpr (L >= 64) v = comb(v, uint32_t(__shfl_xor(int(v), 32, 64)));
+    return v;
 }
 
 // ------------------------------------------------------------------ pair tests
@@ -107,7 +129,9 @@ __device__ __forceinline__ void pair_apply(const LaneCtx<L> &x, uint32_t n_agent
     if (MOVES) {
         const uint32_t on0 = o_next & 0xFFFFu, on1 = o_next >> 16;
         const uint32_t fwd0 = cur0 | (next0 << 16), fwd1 = cur1 | (next1 << 16);
-        const uint32_t rev0 = on0 | (op0 << 16), rev1 = on1 | (op1 << 16);
+        // rev_k = next_k | prev_k << 16 of the other lane: one v_perm_b32 each from the two packed words
+        const uint32_t rev0 = __builtin_amdgcn_perm(o_prev, o_next, 0x05040100u);
+        const uint32_t rev1 = __builtin_amdgcn_perm(o_prev, o_next, 0x07060302u);
         acc.vertex = min(acc.vertex, min((next0 ^ on0) | g0, (next0 ^ on1) | g1));
         acc.vertex = min(acc.vertex, min((next1 ^ on0) | g2, (next1 ^ on1) | g3));
         acc.swap = min(acc.swap, min((fwd0 ^ rev0) | g0, (fwd0 ^ rev1) | g1));
@@ -163,9 +187,8 @@ __device__ __forceinline__ bool lg_is_terminal(const LaneCtx<L> &x, uint32_t n_a
                                                uint32_t goal0, uint32_t goal1) {
     const PairAcc acc = pair_tests<L, FULL, true, false>(x, n_agents, cur0, cur1, 0u, 0u);
     const bool off_goal = ((FULL || x.v0) && cur0 != goal0) || ((FULL || x.v1) && cur1 != goal1);
-    const uint64_t b_dup = group_bits<L>(__ballot(acc.dup == 0u), x.base);
-    const uint64_t b_off = group_bits<L>(__ballot(off_goal), x.base);
-    return (b_dup != 0) || (b_off == 0);
+    const uint32_t flags = group_reduce<L, false>((acc.dup == 0u ? 1u : 0u) | (off_goal ? 2u : 0u), x);
+    return (flags & 1u) != 0u || (flags & 2u) == 0u;
 }
 
 // ordered product over agents 0..A-1 of the sampled probabilities (ghosts hold 1.0)
@@ -203,52 +226,67 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const uint64_t
                                               uint32_t cur0, uint32_t cur1, uint32_t goal0, uint32_t goal1,
                                               uint32_t act0_in, uint32_t act1_in, double u0, double u1,
                                               uint64_t env_id, uint64_t t, bool prev_terminal,
-                                              uint32_t &next0, uint32_t &next1, EnvOut &out) {
+                                              uint32_t &next0, uint32_t &next1, EnvOut &out STAMP_PARAM) {
     const uint32_t act0 = act0_in > 4u ? 0u : act0_in, act1 = act1_in > 4u ? 0u : act1_in;
     const bool v0 = FULL || x.v0, v1 = FULL || x.v1;
 
     // --- my two agents' moves (computed even if the env turns out terminal; discarded then)
-    const uint64_t entry0 = move_entry(mv, c.n_cells, cur0, act0), entry1 = move_entry(mv, c.n_cells, cur1, act1);
+    uint64_t entry0, entry1;
+    if (MAPF_ABLATE & 16) {
+        entry0 = uint64_t(cur0 + act0) | (uint64_t(cur0) << 16) | (uint64_t(cur0 ^ 1u) << 32);
+        entry1 = uint64_t(cur1 + act1) | (uint64_t(cur1) << 16) | (uint64_t(cur1 ^ 1u) << 32);
+    } else {
+        entry0 = move_entry(mv, c.n_cells, cur0, act0);
+        entry1 = move_entry(mv, c.n_cells, cur1, act1);
+    }
     uint64_t mant0 = 0, mant1 = 0;
-    if (!EXT_UNIFORMS && c.need_rng) {
+    if (MAPF_ABLATE & 1) {
+        mant0 = (uint64_t(x.lane * 2654435761u + uint32_t(t)) << 21) ^ env_id; mant1 = mant0 * 3u;
+        mant0 &= (uint64_t(1) << 53) - 1; mant1 &= (uint64_t(1) << 53) - 1;
+    } else if (!EXT_UNIFORMS && c.need_rng) {
         uint32_t w[4];
         const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | (x.g << 24);   // pair index = g
         philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, c.seed_lo, c.seed_hi, w);
         mant0 = mantissa53(w[0], w[1]);
         mant1 = mantissa53(w[2], w[3]);
     }
+    STAMP(1);   // philox + gather issue
     double q0, q1;
     slip_move<EXT_UNIFORMS>(lds_slip, entry0, mant0, u0, next0, q0);
     slip_move<EXT_UNIFORMS>(lds_slip, entry1, mant1, u1, next1, q1);
     if (!v0) { next0 = cur0; q0 = 1.0; }
     if (!v1) { next1 = cur1; q1 = 1.0; }
 
-    // --- pair tests and per-env facts from wave ballots
-    const PairAcc acc = pair_tests<L, FULL, !KNOWN_TERM, true>(x, n_agents, cur0, cur1, next0, next1);
+    STAMP(2);   // slip_move (gather wait, LDS rows, sampling)
+    // --- pair tests, then per-env facts: one flag word per lane, OR-reduced over the group
+    PairAcc acc;
+    if (MAPF_ABLATE & 4) { acc.vertex = next0 ^ next1; acc.swap = cur0 ^ next1; acc.dup = cur0 ^ cur1; }
+    else acc = pair_tests<L, FULL, !KNOWN_TERM, true>(x, n_agents, cur0, cur1, next0, next1);
+    STAMP(3);   // pair tests
     const bool off_goal_next = (v0 && next0 != goal0) || (v1 && next1 != goal1);
-    const uint64_t b_vertex = group_bits<L>(__ballot(acc.vertex == 0u), x.base);
-    const uint64_t b_swap = group_bits<L>(__ballot(acc.swap == 0u), x.base);
-    const uint64_t b_off_next = group_bits<L>(__ballot(off_goal_next), x.base);
-    bool was_terminal = prev_terminal;
+    uint32_t flags = (acc.vertex == 0u ? 1u : 0u) | (acc.swap == 0u ? 2u : 0u) | (off_goal_next ? 4u : 0u);
     if (!KNOWN_TERM) {
         const bool off_goal = (v0 && cur0 != goal0) || (v1 && cur1 != goal1);
-        const uint64_t b_dup = group_bits<L>(__ballot(acc.dup == 0u), x.base);
-        const uint64_t b_off = group_bits<L>(__ballot(off_goal), x.base);
-        was_terminal = (b_dup != 0) || (b_off == 0);
+        flags |= (acc.dup == 0u ? 8u : 0u) | (off_goal ? 16u : 0u);
     }
+    flags = group_reduce<L, false>(flags, x);
+    bool was_terminal = prev_terminal;
+    if (!KNOWN_TERM) was_terminal = (flags & 8u) != 0u || (flags & 16u) == 0u;
 
+    STAMP(4);   // flags + group reduce
     // --- total_prob: left-to-right product over agents 0..A-1 (ghosts contribute 1.0)
-    const double p = ProbChain<L, 0>::run(x, q0, q1, 1.0);
+    const double p = (MAPF_ABLATE & 2) ? __dmul_rn(q0, q1) : ProbChain<L, 0>::run(x, q0, q1, 1.0);
 
+    STAMP(5);   // prob chain
     // _living_reward: mapf_env.py:436-446
     double living = c.r_living;
     if (c.criteria == 1u) {
-        const bool st0 = v0 && cur0 == goal0 && act0 == 0u, st1 = v1 && cur1 == goal1 && act1 == 0u;
-        const int stayed = __popcll(group_bits<L>(__ballot(st0), x.base)) + __popcll(group_bits<L>(__ballot(st1), x.base));
+        const uint32_t mine = ((v0 && cur0 == goal0 && act0 == 0u) ? 1u : 0u) + ((v1 && cur1 == goal1 && act1 == 0u) ? 1u : 0u);
+        const int stayed = int(group_reduce<L, true>(mine, x));
         living = __dmul_rn(double(int(n_agents) - stayed), c.r_living);
     }
     // calc_transition_reward_from_local_states: mapf_env.py:225-235 (collision before goal)
-    const bool vertex = b_vertex != 0, coll = vertex || (b_swap != 0), goal_next = b_off_next == 0;
+    const bool vertex = (flags & 1u) != 0u, coll = (flags & 3u) != 0u, goal_next = (flags & 4u) == 0u;
     out.was_terminal = was_terminal;
     if (was_terminal) {   // mapf_env.py:239-240 -- (s, 0, True, {"prob": 0}), nothing drawn
         next0 = cur0; next1 = cur1;
@@ -263,12 +301,24 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const uint64_t
     }
 }
 
-// ---- row access for a lane's two slots.  A even: one dword (cells) / one short (actions) per lane, fully
-// coalesced: 4 B x 64 lanes.  `guard` = this lane really owns slot 0 (FULL kernels pass true for live lanes).
+// ---- memory access.  All element indices are 32-bit and turned into 32-bit BYTE offsets from a uniform base
+// pointer, so every access uses the SGPR-base + VGPR-offset addressing form (no 64-bit address arithmetic per
+// lane).  The C ABI rejects calls whose largest array would exceed 4 GiB (mapf_capi.hip: check_extent).
 template <typename T>
-__device__ __forceinline__ void load_pair(const T *base, uint64_t row, uint32_t n_agents, uint32_t g, bool v0, bool v1,
+__device__ __forceinline__ const T *at(const T *base, uint32_t index) {
+    return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + index * uint32_t(sizeof(T)));
+}
+template <typename T>
+__device__ __forceinline__ T *at(T *base, uint32_t index) {
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + index * uint32_t(sizeof(T)));
+}
+
+// A lane's two slots of row `row`.  A even: one dword (cells) / one short (actions) per lane, fully coalesced
+// (4 B x 64 lanes).
+template <typename T>
+__device__ __forceinline__ void load_pair(const T *base, uint32_t row, uint32_t n_agents, uint32_t g, bool v0, bool v1,
                                           uint32_t &a, uint32_t &b) {
-    const T *p = base + row * n_agents + 2u * g;
+    const T *p = at(base, row * n_agents + 2u * g);
     a = 0u; b = 0u;
     if ((n_agents & 1u) == 0u) {
         if (v0) {
@@ -281,10 +331,11 @@ __device__ __forceinline__ void load_pair(const T *base, uint64_t row, uint32_t 
     }
 }
 
-__device__ __forceinline__ void store_cells(uint16_t *base, uint64_t row, uint32_t n_agents, uint32_t g, bool v0, bool v1,
+template <bool EVEN = false>
+__device__ __forceinline__ void store_cells(uint16_t *base, uint32_t row, uint32_t n_agents, uint32_t g, bool v0, bool v1,
                                             uint32_t a, uint32_t b) {
-    uint16_t *p = base + row * n_agents + 2u * g;
-    if ((n_agents & 1u) == 0u) {
+    uint16_t *p = at(base, row * n_agents + 2u * g);
+    if (EVEN || (n_agents & 1u) == 0u) {
         if (v0) *reinterpret_cast<uint32_t *>(p) = a | (b << 16);
     } else {
         if (v0) p[0] = uint16_t(a);
@@ -298,10 +349,10 @@ __device__ __forceinline__ LaneCtx<L> lane_ctx(uint32_t n_agents, uint64_t n_env
     x.lane = threadIdx.x & 63u;
     x.g = x.lane & uint32_t(L - 1);
     x.base = x.lane & ~uint32_t(L - 1);
-    const uint64_t wave = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
-    x.e = wave * uint64_t(64 / L) + (x.lane / uint32_t(L));
-    // envs past the end keep their lanes alive (ballots / cross-lane moves are wave-wide) but own no agents
-    live = x.e < n_envs;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    x.e = wave * uint32_t(64 / L) + (x.lane / uint32_t(L));
+    // envs past the end keep their lanes alive (cross-lane moves are wave-wide) but own no agents
+    live = x.e < uint32_t(n_envs);
     x.v0 = live && 2u * x.g < n_agents;
     x.v1 = live && 2u * x.g + 1u < n_agents;
     if (!live) x.e = 0;
@@ -313,7 +364,7 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
     __shared__ SlipRow slip[8];
     bool live;
     const LaneCtx<L> x = lane_ctx<L>(n_agents, p.n_envs, live);
-    const uint64_t e = x.e;
+    const uint32_t e = x.e;
 
     // rows first, LDS staging second: both sets of loads are in flight together
     uint32_t cur0, cur1, goal0, goal1, act0, act1;
@@ -322,7 +373,7 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
     load_pair<uint8_t>(p.actions, e, n_agents, x.g, x.v0, x.v1, act0, act1);
     double u0 = 0.0, u1 = 0.0;
     if (EXT_UNIFORMS) {
-        const double *up = p.uniforms + e * n_agents + 2u * x.g;
+        const double *up = at(p.uniforms, e * n_agents + 2u * x.g);
         if (x.v0) u0 = up[0];
         if (x.v1) u1 = up[1];
     }
@@ -330,17 +381,20 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
 
     uint32_t next0, next1;
     EnvOut o;
+#ifdef MAPF_STAMPS
+    StampCtx st{};
+#endif
     lg_transition<L, FULL, EXT_UNIFORMS, false>(p.c, p.mv, slip, x, n_agents, cur0, cur1, goal0, goal1, act0, act1,
-                                                u0, u1, p.env_id_offset + e, p.t, false, next0, next1, o);
+                                                u0, u1, p.env_id_offset + e, p.t, false, next0, next1, o STAMP_ARG);
     if (!live) return;
 
     if (p.out_local) store_cells(p.out_local, e, n_agents, x.g, x.v0, x.v1, next0, next1);
     if (x.g == 0u) {
-        if (p.out_reward) p.out_reward[e] = o.reward;
-        if (p.out_prob) p.out_prob[e] = o.prob;
-        if (p.out_done) p.out_done[e] = o.done ? 1 : 0;
-        if (p.out_collision) p.out_collision[e] = o.collision ? 1 : 0;
-        if (p.out_was_terminal) p.out_was_terminal[e] = o.was_terminal ? 1 : 0;
+        if (p.out_reward) *at(p.out_reward, e) = o.reward;
+        if (p.out_prob) *at(p.out_prob, e) = o.prob;
+        if (p.out_done) *at(p.out_done, e) = o.done ? 1 : 0;
+        if (p.out_collision) *at(p.out_collision, e) = o.collision ? 1 : 0;
+        if (p.out_was_terminal) *at(p.out_was_terminal, e) = o.was_terminal ? 1 : 0;
     }
     if (p.auto_reset && o.done) {
         uint32_t s0, s1;
@@ -351,39 +405,86 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
     }
 }
 
-template <int L, bool FULL>
-__global__ void __launch_bounds__(256) lg_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
+// Largest block a rollout kernel may be launched with: groups of 16 lanes unroll 8 rotation rounds and need more
+// than the 128 registers a 1024-thread block leaves per lane.
+template <int L> constexpr unsigned rollout_max_block() { return L == 16 ? 512u : 1024u; }
+
+// raw (still packed) action bytes of a lane's two slots: byte 0 = agent 2g, byte 1 = agent 2g+1.  Kept packed so
+// that a prefetch issued one step ahead is not forced to complete by an unpack.
+template <bool EVEN>
+__device__ __forceinline__ uint32_t load_actions_raw(const uint8_t *base, uint32_t row, uint32_t n_agents, uint32_t g,
+                                                     bool v0, bool v1) {
+    const uint8_t *p = at(base, row * n_agents + 2u * g);
+    uint32_t raw = 0u;
+    if (EVEN || (n_agents & 1u) == 0u) {
+        if (v0) raw = *reinterpret_cast<const uint16_t *>(p);
+    } else {
+        uint32_t lo = 0u, hi = 0u;
+        if (v0) lo = p[0];
+        if (v1) hi = p[1];
+        raw = lo | (hi << 8);
+    }
+    return raw;
+}
+
+// MV_LDS: the whole move table (V*5 entries of 8 B) is staged into LDS once per block and the two gathers of
+// every step become ds_read_b64 (a random 64-lane gather through the vector-memory pipe touches up to 64 cache
+// lines).  RECORD: all five trajectory arrays are written every step (the C ABI substitutes scratch for absent
+// ones), STREAM: actions come from memory, else from the in-kernel policy stream.  Both are compile-time so the
+// loop body has no branches around its memory operations: the compiler can then wait for the action word that
+// was prefetched one step ahead with a counted vmcnt(N) instead of draining every store (vmcnt(0)).  Start
+// cells stay in two registers per lane, so an auto-reset touches no memory.
+template <int L, bool FULL, bool MV_LDS, bool RECORD, bool STREAM>
+__global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
     __shared__ SlipRow slip[8];
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_mv[];
     bool live;
     const LaneCtx<L> x = lane_ctx<L>(n_agents, p.n_envs, live);
-    const uint64_t e = x.e;
+    const uint32_t e = x.e;
     const bool leader = live && x.g == 0u;
 
-    uint32_t cur0, cur1, goal0, goal1;
+    uint32_t cur0, cur1, goal0, goal1, start0 = 0u, start1 = 0u;
     load_pair<uint16_t>(p.state, e, n_agents, x.g, x.v0, x.v1, cur0, cur1);
     load_pair<uint16_t>(p.goal, p.goal_broadcast ? 0 : e, n_agents, x.g, x.v0, x.v1, goal0, goal1);
-    stage_slip_table(p.slip, slip);
+    if (p.auto_reset) load_pair<uint16_t>(p.start, p.start_broadcast ? 0 : e, n_agents, x.g, x.v0, x.v1, start0, start1);
+    if (MV_LDS) {
+        const uint32_t n_words = p.c.n_cells * 5u;
+        for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) lds_mv[w] = p.mv[w];
+    }
+    stage_slip_table(p.slip, slip);   // ends with __syncthreads()
+    const uint64_t *mv = MV_LDS ? lds_mv : p.mv;
 
     // is_terminal is carried from step to step instead of re-deriving it from the cells every step
     bool terminal = lg_is_terminal<L, FULL>(x, n_agents, cur0, cur1, goal0, goal1);
-    bool start_terminal = false;
-    if (p.auto_reset) {
-        uint32_t s0, s1;
-        load_pair<uint16_t>(p.start, p.start_broadcast ? 0 : e, n_agents, x.g, x.v0, x.v1, s0, s1);
-        start_terminal = lg_is_terminal<L, FULL>(x, n_agents, s0, s1, goal0, goal1);
-    }
+    const bool start_terminal = p.auto_reset ? lg_is_terminal<L, FULL>(x, n_agents, start0, start1, goal0, goal1) : false;
 
-    double ret = (p.accumulate && p.out_returns && leader) ? p.out_returns[e] : 0.0;
-    uint32_t episodes = (p.accumulate && p.out_episodes && leader) ? p.out_episodes[e] : 0u;
-    uint32_t collisions = (p.accumulate && p.out_collisions && leader) ? p.out_collisions[e] : 0u;
+    double ret = (p.accumulate && p.out_returns && leader) ? *at(p.out_returns, e) : 0.0;
+    uint32_t episodes = (p.accumulate && p.out_episodes && leader) ? *at(p.out_episodes, e) : 0u;
+    uint32_t collisions = (p.accumulate && p.out_collisions && leader) ? *at(p.out_collisions, e) : 0u;
     const uint64_t env_id = p.env_id_offset + e;
+    const uint32_t n_envs = uint32_t(p.n_envs);
+
+#ifdef MAPF_STAMPS
+    StampCtx st{};
+    { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); st.last = _t; }
+#endif
+    // Software pipeline of the loop's memory operations.  The compiler waits for the prefetched action word with
+    // vmcnt(0), i.e. for EVERYTHING outstanding, so each iteration is ordered: (1) use the word loaded one
+    // iteration ago, (2) only then issue the next load and the PREVIOUS step's trajectory stores, (3) compute.
+    // Whatever the wait at (1) sees was issued a whole transition earlier and has long completed.
+    uint32_t raw = 0u;
+    if (STREAM && p.n_steps > 0) raw = load_actions_raw<FULL>(p.actions, e, n_agents, x.g, x.v0, x.v1);
+    uint32_t d_next0 = 0u, d_next1 = 0u, d_row = 0u, d_flags = 0u;   // step s-1's results, stored during step s
+    double d_reward = 0.0, d_prob = 0.0;
 
     for (uint32_t s = 0; s < p.n_steps; ++s) {
         const uint64_t t = p.t + s;
-        const uint64_t row = uint64_t(s) * p.n_envs + e;
+        const uint32_t row = s * n_envs + e;
         uint32_t act0, act1;
-        if (p.actions) {
-            load_pair<uint8_t>(p.actions, row, n_agents, x.g, x.v0, x.v1, act0, act1);
+        if (STREAM) {
+            act0 = raw & 0xFFu; act1 = raw >> 8;
+            asm volatile("" : "+v"(act0), "+v"(act1));       // (1) pins the wait for `raw` here, ahead of (2)
+            if (s + 1 < p.n_steps) raw = load_actions_raw<FULL>(p.actions, row + n_envs, n_agents, x.g, x.v0, x.v1);
         } else {   // policy stream: one Philox call covers agents 4q..4q+3; this lane needs words 2(g&1), 2(g&1)+1
             uint32_t w[4];
             const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | ((x.g >> 1) << 24);
@@ -392,36 +493,55 @@ __global__ void __launch_bounds__(256) lg_rollout_kernel(const RolloutArgs p, co
             act0 = __umulhi(hi ? w[2] : w[0], 5u);
             act1 = __umulhi(hi ? w[3] : w[1], 5u);
         }
+        if (RECORD && s > 0) {                               // (2) the previous step's outputs
+            if (live) store_cells<FULL>(p.rec_local, d_row, n_agents, x.g, x.v0, x.v1, d_next0, d_next1);
+            if (leader) {
+                *at(p.rec_reward, d_row) = d_reward;
+                *at(p.rec_prob, d_row) = d_prob;
+                *at(p.rec_done, d_row) = uint8_t(d_flags & 1u);
+                *at(p.rec_collision, d_row) = uint8_t(d_flags >> 1);
+            }
+        }
         uint32_t next0, next1;
         EnvOut o;
-        lg_transition<L, FULL, false, true>(p.c, p.mv, slip, x, n_agents, cur0, cur1, goal0, goal1, act0, act1, 0.0, 0.0,
-                                            env_id, t, terminal, next0, next1, o);
+        STAMP(0);   // loop top: action fetch / policy / delayed stores
+        lg_transition<L, FULL, false, true>(p.c, mv, slip, x, n_agents, cur0, cur1, goal0, goal1, act0, act1, 0.0, 0.0,
+                                            env_id, t, terminal, next0, next1, o STAMP_ARG);
+        STAMP(6);   // reward / selects
         ret = __dadd_rn(ret, o.reward);
         episodes += o.done ? 1u : 0u;
         collisions += o.collision ? 1u : 0u;
-        if (live) {
-            if (p.rec_local) store_cells(p.rec_local, row, n_agents, x.g, x.v0, x.v1, next0, next1);
-            if (leader) {
-                if (p.rec_reward) p.rec_reward[row] = o.reward;
-                if (p.rec_prob) p.rec_prob[row] = o.prob;
-                if (p.rec_done) p.rec_done[row] = o.done ? 1 : 0;
-                if (p.rec_collision) p.rec_collision[row] = o.collision ? 1 : 0;
-            }
+        if (RECORD) {
+            d_next0 = next0; d_next1 = next1; d_row = row; d_reward = o.reward; d_prob = o.prob;
+            d_flags = (o.done ? 1u : 0u) | (o.collision ? 2u : 0u);
         }
-        if (p.auto_reset && o.done) {
-            load_pair<uint16_t>(p.start, p.start_broadcast ? 0 : e, n_agents, x.g, x.v0, x.v1, cur0, cur1);
-            terminal = start_terminal;
-        } else {
-            cur0 = next0; cur1 = next1;
-            terminal = o.next_terminal;
+        const bool back = p.auto_reset && o.done;          // MapfEnv.reset(): start cells, no reseed
+        cur0 = back ? start0 : next0;
+        cur1 = back ? start1 : next1;
+        terminal = back ? start_terminal : o.next_terminal;
+        STAMP(7);   // reset handling
+    }
+    if (RECORD && p.n_steps > 0) {                           // flush the last step's outputs
+        if (live) store_cells<FULL>(p.rec_local, d_row, n_agents, x.g, x.v0, x.v1, d_next0, d_next1);
+        if (leader) {
+            *at(p.rec_reward, d_row) = d_reward;
+            *at(p.rec_prob, d_row) = d_prob;
+            *at(p.rec_done, d_row) = uint8_t(d_flags & 1u);
+            *at(p.rec_collision, d_row) = uint8_t(d_flags >> 1);
         }
     }
+#ifdef MAPF_STAMPS
+    if (live && x.lane == 0u && p.out_episodes) {   // diagnostic build: segment sums replace the episode counts
+        for (int k = 0; k < 8; ++k) *at(p.out_episodes, e + uint32_t(k)) = uint32_t(st.seg[k]);
+        return;
+    }
+#endif
     if (!live) return;
-    store_cells(p.state, e, n_agents, x.g, x.v0, x.v1, cur0, cur1);
+    store_cells<FULL>(p.state, e, n_agents, x.g, x.v0, x.v1, cur0, cur1);
     if (leader) {
-        if (p.out_returns) p.out_returns[e] = ret;
-        if (p.out_episodes) p.out_episodes[e] = episodes;
-        if (p.out_collisions) p.out_collisions[e] = collisions;
+        if (p.out_returns) *at(p.out_returns, e) = ret;
+        if (p.out_episodes) *at(p.out_episodes, e) = episodes;
+        if (p.out_collisions) *at(p.out_collisions, e) = collisions;
     }
 }
 
@@ -550,24 +670,60 @@ hipError_t launch_step_lg(int n_agents, const StepArgs &args, hipStream_t stream
     return hipGetLastError();
 }
 
+// LDS budget for the move table: the CU has 160 KiB; keep room for the slip rows
+static constexpr size_t kLdsBytes = 160 * 1024, kLdsReserve = 1024;
+
+template <int L, bool FULL, bool RECORD, bool STREAM>
+static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, hipStream_t stream) {
+    const size_t mv_bytes = size_t(args.c.n_cells) * 5 * sizeof(uint64_t);
+    const uint64_t threads = args.n_envs * uint64_t(L);
+    if (mv_bytes + kLdsReserve <= kLdsBytes && threads >= 64 * 256) {
+        // block size: as many waves as can share one table copy while >= 16 waves stay resident per CU
+        const size_t copies = (kLdsBytes - kLdsReserve) / (mv_bytes + sizeof(SlipRow) * 8);   // blocks per CU by LDS
+        unsigned block = copies >= 4 ? 256u : (copies >= 2 ? 512u : 1024u);
+        if (block > rollout_max_block<L>()) block = rollout_max_block<L>();
+        const uint64_t per_block = block / unsigned(L);
+        const unsigned grid = unsigned((args.n_envs + per_block - 1) / per_block);
+        auto kern = lg_rollout_kernel<L, FULL, true, RECORD, STREAM>;
+        static bool raised = false;    // one flag per instantiation: allow dynamic LDS beyond 64 KiB
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsBytes - kLdsReserve));
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), mv_bytes, stream, args, A);
+    } else {
+        unsigned grid, block;
+        lg_geometry(L, args.n_envs, grid, block);
+        hipLaunchKernelGGL((lg_rollout_kernel<L, FULL, false, RECORD, STREAM>), dim3(grid), dim3(block), 0, stream, args, A);
+    }
+    return hipGetLastError();
+}
+
 hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, hipStream_t stream) {
     if (args.n_envs == 0) return hipSuccess;
     const int L = lg_group_size(n_agents);
     const bool full = n_agents == 2 * L;
-    unsigned grid, block;
-    lg_geometry(L, args.n_envs, grid, block);
     const uint32_t A = uint32_t(n_agents);
+    // the record variant writes all five trajectory arrays: the C ABI passes either all of them or none
+    const bool record = args.rec_local != nullptr, stream_actions = args.actions != nullptr;
+    if (record && !(args.rec_reward && args.rec_prob && args.rec_done && args.rec_collision)) return hipErrorInvalidValue;
     switch (L) {
 #define X(N)                                                                                                         \
     case N:                                                                                                          \
-        if (full) hipLaunchKernelGGL((lg_rollout_kernel<N, true>), dim3(grid), dim3(block), 0, stream, args, A);     \
-        else hipLaunchKernelGGL((lg_rollout_kernel<N, false>), dim3(grid), dim3(block), 0, stream, args, A);         \
-        break;
+        if (full) return record ? (stream_actions ? launch_rollout_lg_impl<N, true, true, true>(args, A, stream)          \
+                                                  : launch_rollout_lg_impl<N, true, true, false>(args, A, stream))        \
+                                : (stream_actions ? launch_rollout_lg_impl<N, true, false, true>(args, A, stream)         \
+                                                  : launch_rollout_lg_impl<N, true, false, false>(args, A, stream));      \
+        return record ? (stream_actions ? launch_rollout_lg_impl<N, false, true, true>(args, A, stream)                   \
+                                        : launch_rollout_lg_impl<N, false, true, false>(args, A, stream))                 \
+                      : (stream_actions ? launch_rollout_lg_impl<N, false, false, true>(args, A, stream)                  \
+                                        : launch_rollout_lg_impl<N, false, false, false>(args, A, stream));
         MAPF_FOR_EACH_L(X)
 #undef X
         default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 }  // namespace mapf

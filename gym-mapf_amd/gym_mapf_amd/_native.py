@@ -7,7 +7,7 @@ import ctypes
 import os
 from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_int, c_int32, c_uint8, c_uint16, c_uint32, c_uint64, c_void_p
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libmapf_hip.so')
+LIB_PATH = os.environ.get('MAPF_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libmapf_hip.so')
 
 MAPF_OK, MAPF_EINVAL, MAPF_EHIP, MAPF_ENODEVICE, MAPF_EUNSUPPORTED = 0, -1, -2, -3, -4
 MAPF_MAX_AGENTS = 128

@@ -84,15 +84,18 @@ class VecMapfEnv:
             fail_prob=float(fail_prob), r_clash=float(reward_of_collision), r_goal=float(reward_of_goal),
             r_living=float(reward_of_living), device=self.device, flags=flags,
             stream=(int(stream) if stream else None))
+        self._torch = None
+        if self.device_arrays:
+            # torch wheels bundle their own HIP runtime: it must be initialised BEFORE libmapf_hip pulls in the
+            # system one, otherwise torch later reports "No HIP GPUs are available".
+            import torch
+            torch.cuda.init()
+            self._torch = torch
+            self._tdev = torch.device('cuda', self.device)
         self._lib = nat.load()
         handle = ctypes.c_void_p()
         nat.check(self._lib.mapf_create(ctypes.byref(desc), ctypes.byref(handle)))
         self._h = handle
-        self._torch = None
-        if self.device_arrays:
-            import torch
-            self._torch = torch
-            self._tdev = torch.device('cuda', self.device)
 
     # ------------------------------------------------------------------ construction
     def _as_local(self, locations, local_ids, what):
