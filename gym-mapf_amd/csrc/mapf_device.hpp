@@ -102,6 +102,37 @@ __device__ __forceinline__ void slip_move(const SlipRow *lds_slip, uint64_t entr
     q = pick2 ? qc : (pick1 ? qb : qa);
 }
 
+// Fast path of the same sampling with only the top 27 bits of the uniform (hi = mant >> 26): hi < th[k] decides
+// mant < thr[k] unless hi == th[k]; `ambiguous` is set in that (rare) case and the caller repeats the move
+// with the full 53-bit mantissa.
+__device__ __forceinline__ void slip_move_hi(const SlipRow *lds_slip, uint64_t entry, uint32_t hi, uint32_t &next,
+                                             double &q, bool &ambiguous) {
+#if defined(MAPF_ABLATE) && (MAPF_ABLATE & 8)
+    const SlipRow &row = lds_slip[0];
+#else
+    const SlipRow &row = lds_slip[uint32_t(entry >> 48) & 7u];
+#endif
+    const double qa = row.q[0], qb = row.q[1], qc = row.q[2];
+    const uint32_t t0 = row.th[0], t1 = row.th[1], t2 = row.th[2];
+    const bool b0 = hi < t0, b1 = hi < t1, b2 = hi < t2;
+    ambiguous = (hi == t0) | (hi == t1) | (hi == t2);
+    const bool pick1 = !b0 && b1, pick2 = !b0 && !b1 && b2;
+    const uint32_t lo = uint32_t(entry), up = uint32_t(entry >> 32);
+    next = pick2 ? (up & 0xFFFFu) : (pick1 ? (lo >> 16) : (lo & 0xFFFFu));
+    q = pick2 ? qc : (pick1 ? qb : qa);
+}
+
+// The four words of the slip stream that serve agents (2*pair, 2*pair+1) at steps (2h, 2h+1):
+// word 2*(t&1) + (agent&1).  refine = 0: source of the uniforms' top 27 bits; refine = 1: of their low 26 bits.
+struct Words4 { uint32_t w0, w1, w2, w3; };
+
+__device__ __forceinline__ Words4 slip_words(const EnvConsts &c, uint64_t env_id, uint64_t h, uint32_t pair, uint32_t refine) {
+    const uint32_t c3 = (uint32_t(h >> 32) & 0x00FFFFFFu) | (pair << 24) | (refine << 31);
+    uint32_t w[4];
+    philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(h), c3, c.seed_lo, c.seed_hi, w);
+    return Words4{w[0], w[1], w[2], w[3]};
+}
+
 // address of the move-table row; cells beyond V (only reachable through a corrupted state) are clamped
 __device__ __forceinline__ uint64_t move_entry(const uint64_t *__restrict__ mv, uint32_t n_cells, uint32_t cell,
                                                uint32_t action) {
@@ -144,7 +175,7 @@ __device__ __forceinline__ void env_transition(const EnvConsts &c, const uint64_
     for (int i = 0; i < A; ++i) entry[i] = move_entry(mv, c.n_cells, prev[i], act[i]);
 
     double prob = 1.0;
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    Words4 wh{0u, 0u, 0u, 0u}, wl{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         uint64_t mant = 0;
@@ -152,13 +183,14 @@ __device__ __forceinline__ void env_transition(const EnvConsts &c, const uint64_
         if (EXT_UNIFORMS) {
             u = ext_u[i];
         } else if (c.need_rng) {  // uniform branch: a single surviving candidate needs no draw
-            if ((i & 1) == 0) {
-                const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | (uint32_t(i >> 1) << 24);
-                philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, c.seed_lo, c.seed_hi, w);
-                mant = mantissa53(w[0], w[1]);
-            } else {
-                mant = mantissa53(w[2], w[3]);
+            if ((i & 1) == 0) {   // this family always evaluates both halves of the 53-bit uniform
+                wh = slip_words(c, env_id, t >> 1, uint32_t(i >> 1), 0u);
+                wl = slip_words(c, env_id, t >> 1, uint32_t(i >> 1), 1u);
             }
+            const bool odd = (t & 1u) != 0u;
+            const uint32_t hi = (i & 1) ? (odd ? wh.w3 : wh.w1) : (odd ? wh.w2 : wh.w0);
+            const uint32_t lo = (i & 1) ? (odd ? wl.w3 : wl.w1) : (odd ? wl.w2 : wl.w0);
+            mant = mantissa53(hi, lo);
         }
         double pr;
         slip_move<EXT_UNIFORMS>(lds_slip, entry[i], mant, u, out.next[i], pr);

@@ -10,11 +10,13 @@ namespace mapf {
 // Built on the host by replaying single_agent_movements (mapf_env.py:163-184): drop p <= 0, merge equal
 // cells in first-seen order with old + new, then cumsum left to right.
 struct SlipRow {
+    double q[3];                   // merged probabilities, list order
+    uint32_t th[3];                // thr[k] >> 26: top 27 bits of the thresholds (fast path, see slip_move_hi)
+    uint32_t n;                    // list length, 1..3
     uint64_t thr[3];               // ceil(cum[k] * 2^53): cum[k] > u  <=>  mant(u) < thr[k]; 0 past the list end
-    double q[3];                   // merged probabilities, list order (thr and q sit together: one LDS round trip)
     double cum[3];                 // running float64 sums (for caller-supplied uniforms); -inf past the list end
     uint32_t src;                  // byte k: candidate (0 m, 1 r, 2 l) in list slot k (host bookkeeping)
-    uint32_t n;                    // list length, 1..3
+    uint32_t pad;
 };
 
 struct EnvConsts {

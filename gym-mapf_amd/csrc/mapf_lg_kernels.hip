@@ -225,7 +225,7 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const uint64_t
                                               const SlipRow *lds_slip, const LaneCtx<L> &x, uint32_t n_agents,
                                               uint32_t cur0, uint32_t cur1, uint32_t goal0, uint32_t goal1,
                                               uint32_t act0_in, uint32_t act1_in, double u0, double u1,
-                                              uint64_t env_id, uint64_t t, bool prev_terminal,
+                                              uint64_t env_id, uint64_t t, const Words4 rng, bool prev_terminal,
                                               uint32_t &next0, uint32_t &next1, EnvOut &out STAMP_PARAM) {
     const uint32_t act0 = act0_in > 4u ? 0u : act0_in, act1 = act1_in > 4u ? 0u : act1_in;
     const bool v0 = FULL || x.v0, v1 = FULL || x.v1;
@@ -239,21 +239,27 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const uint64_t
         entry0 = move_entry(mv, c.n_cells, cur0, act0);
         entry1 = move_entry(mv, c.n_cells, cur1, act1);
     }
-    uint64_t mant0 = 0, mant1 = 0;
-    if (MAPF_ABLATE & 1) {
-        mant0 = (uint64_t(x.lane * 2654435761u + uint32_t(t)) << 21) ^ env_id; mant1 = mant0 * 3u;
-        mant0 &= (uint64_t(1) << 53) - 1; mant1 &= (uint64_t(1) << 53) - 1;
-    } else if (!EXT_UNIFORMS && c.need_rng) {
-        uint32_t w[4];
-        const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | (x.g << 24);   // pair index = g
-        philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, c.seed_lo, c.seed_hi, w);
-        mant0 = mantissa53(w[0], w[1]);
-        mant1 = mantissa53(w[2], w[3]);
-    }
-    STAMP(1);   // philox + gather issue
     double q0, q1;
-    slip_move<EXT_UNIFORMS>(lds_slip, entry0, mant0, u0, next0, q0);
-    slip_move<EXT_UNIFORMS>(lds_slip, entry1, mant1, u1, next1, q1);
+    if (EXT_UNIFORMS) {
+        slip_move<true>(lds_slip, entry0, 0, u0, next0, q0);
+        slip_move<true>(lds_slip, entry1, 0, u1, next1, q1);
+    } else {
+        // words of this step: 2*(t&1) and 2*(t&1)+1 of the call shared by steps 2h and 2h+1
+        const bool odd = (t & 1u) != 0u;
+        const uint32_t hi0 = (odd ? rng.w2 : rng.w0) >> 5, hi1 = (odd ? rng.w3 : rng.w1) >> 5;
+        STAMP(1);   // philox + gather issue
+        bool amb0, amb1;
+        slip_move_hi(lds_slip, entry0, hi0, next0, q0, amb0);
+        slip_move_hi(lds_slip, entry1, hi1, next1, q1, amb1);
+        if (__builtin_expect(__any((amb0 || amb1) && c.need_rng), 0)) {
+            // a top-27-bit tie somewhere in the wave (~2^-25 per agent-step): redo with all 53 bits
+            const Words4 wr = slip_words(c, env_id, t >> 1, x.g, 1u);
+            const uint64_t mant0 = (uint64_t(hi0) << 26) | uint64_t((odd ? wr.w2 : wr.w0) >> 6);
+            const uint64_t mant1 = (uint64_t(hi1) << 26) | uint64_t((odd ? wr.w3 : wr.w1) >> 6);
+            slip_move<false>(lds_slip, entry0, mant0, 0.0, next0, q0);
+            slip_move<false>(lds_slip, entry1, mant1, 0.0, next1, q1);
+        }
+    }
     if (!v0) { next0 = cur0; q0 = 1.0; }
     if (!v1) { next1 = cur1; q1 = 1.0; }
 
@@ -384,8 +390,10 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
 #ifdef MAPF_STAMPS
     StampCtx st{};
 #endif
+    Words4 rng{0u, 0u, 0u, 0u};
+    if (!EXT_UNIFORMS && p.c.need_rng) rng = slip_words(p.c, p.env_id_offset + e, p.t >> 1, x.g, 0u);
     lg_transition<L, FULL, EXT_UNIFORMS, false>(p.c, p.mv, slip, x, n_agents, cur0, cur1, goal0, goal1, act0, act1,
-                                                u0, u1, p.env_id_offset + e, p.t, false, next0, next1, o STAMP_ARG);
+                                                u0, u1, p.env_id_offset + e, p.t, rng, false, next0, next1, o STAMP_ARG);
     if (!live) return;
 
     if (p.out_local) store_cells(p.out_local, e, n_agents, x.g, x.v0, x.v1, next0, next1);
@@ -458,9 +466,18 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     bool terminal = lg_is_terminal<L, FULL>(x, n_agents, cur0, cur1, goal0, goal1);
     const bool start_terminal = p.auto_reset ? lg_is_terminal<L, FULL>(x, n_agents, start0, start1, goal0, goal1) : false;
 
-    double ret = (p.accumulate && p.out_returns && leader) ? *at(p.out_returns, e) : 0.0;
-    uint32_t episodes = (p.accumulate && p.out_episodes && leader) ? *at(p.out_episodes, e) : 0u;
-    uint32_t collisions = (p.accumulate && p.out_collisions && leader) ? *at(p.out_collisions, e) : 0u;
+    // per-env totals: their addresses are parked in VGPRs so the three base pointers do not occupy SGPRs
+    // across the step loop (the loop already keeps ~100 scalars live)
+    double *ret_p = p.out_returns ? at(p.out_returns, e) : nullptr;
+    uint32_t *epi_p = p.out_episodes ? at(p.out_episodes, e) : nullptr;
+    uint32_t *col_p = p.out_collisions ? at(p.out_collisions, e) : nullptr;
+    uint8_t *done_base = RECORD ? p.rec_done : nullptr, *coll_base = RECORD ? p.rec_collision : nullptr;
+    double *reward_base = RECORD ? p.rec_reward : nullptr, *prob_base = RECORD ? p.rec_prob : nullptr;
+    asm volatile("" : "+v"(ret_p), "+v"(epi_p), "+v"(col_p), "+v"(done_base), "+v"(coll_base), "+v"(reward_base),
+                 "+v"(prob_base));
+    double ret = (p.accumulate && ret_p && leader) ? *ret_p : 0.0;
+    uint32_t episodes = (p.accumulate && epi_p && leader) ? *epi_p : 0u;
+    uint32_t collisions = (p.accumulate && col_p && leader) ? *col_p : 0u;
     const uint64_t env_id = p.env_id_offset + e;
     const uint32_t n_envs = uint32_t(p.n_envs);
 
@@ -474,6 +491,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     // Whatever the wait at (1) sees was issued a whole transition earlier and has long completed.
     uint32_t raw = 0u;
     if (STREAM && p.n_steps > 0) raw = load_actions_raw<FULL>(p.actions, e, n_agents, x.g, x.v0, x.v1);
+    Words4 rng{0u, 0u, 0u, 0u};
     uint32_t d_next0 = 0u, d_next1 = 0u, d_row = 0u, d_flags = 0u;   // step s-1's results, stored during step s
     double d_reward = 0.0, d_prob = 0.0;
 
@@ -496,17 +514,19 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
         if (RECORD && s > 0) {                               // (2) the previous step's outputs
             if (live) store_cells<FULL>(p.rec_local, d_row, n_agents, x.g, x.v0, x.v1, d_next0, d_next1);
             if (leader) {
-                *at(p.rec_reward, d_row) = d_reward;
-                *at(p.rec_prob, d_row) = d_prob;
-                *at(p.rec_done, d_row) = uint8_t(d_flags & 1u);
-                *at(p.rec_collision, d_row) = uint8_t(d_flags >> 1);
+                reward_base[d_row] = d_reward;
+                prob_base[d_row] = d_prob;
+                done_base[d_row] = uint8_t(d_flags & 1u);
+                coll_base[d_row] = uint8_t(d_flags >> 1);
             }
         }
         uint32_t next0, next1;
         EnvOut o;
         STAMP(0);   // loop top: action fetch / policy / delayed stores
+        // one slip-stream call serves two steps: refresh at even t (and at an odd first step)
+        if (p.c.need_rng && ((t & 1u) == 0u || s == 0u)) rng = slip_words(p.c, env_id, t >> 1, x.g, 0u);
         lg_transition<L, FULL, false, true>(p.c, mv, slip, x, n_agents, cur0, cur1, goal0, goal1, act0, act1, 0.0, 0.0,
-                                            env_id, t, terminal, next0, next1, o STAMP_ARG);
+                                            env_id, t, rng, terminal, next0, next1, o STAMP_ARG);
         STAMP(6);   // reward / selects
         ret = __dadd_rn(ret, o.reward);
         episodes += o.done ? 1u : 0u;
@@ -524,24 +544,24 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     if (RECORD && p.n_steps > 0) {                           // flush the last step's outputs
         if (live) store_cells<FULL>(p.rec_local, d_row, n_agents, x.g, x.v0, x.v1, d_next0, d_next1);
         if (leader) {
-            *at(p.rec_reward, d_row) = d_reward;
-            *at(p.rec_prob, d_row) = d_prob;
-            *at(p.rec_done, d_row) = uint8_t(d_flags & 1u);
-            *at(p.rec_collision, d_row) = uint8_t(d_flags >> 1);
+            reward_base[d_row] = d_reward;
+            prob_base[d_row] = d_prob;
+            done_base[d_row] = uint8_t(d_flags & 1u);
+            coll_base[d_row] = uint8_t(d_flags >> 1);
         }
     }
 #ifdef MAPF_STAMPS
-    if (live && x.lane == 0u && p.out_episodes) {   // diagnostic build: segment sums replace the episode counts
-        for (int k = 0; k < 8; ++k) *at(p.out_episodes, e + uint32_t(k)) = uint32_t(st.seg[k]);
+    if (live && x.lane == 0u && epi_p) {   // diagnostic build: segment sums replace the episode counts
+        for (int k = 0; k < 8; ++k) epi_p[k] = uint32_t(st.seg[k]);
         return;
     }
 #endif
     if (!live) return;
     store_cells<FULL>(p.state, e, n_agents, x.g, x.v0, x.v1, cur0, cur1);
     if (leader) {
-        if (p.out_returns) *at(p.out_returns, e) = ret;
-        if (p.out_episodes) *at(p.out_episodes, e) = episodes;
-        if (p.out_collisions) *at(p.out_collisions, e) = collisions;
+        if (ret_p) *ret_p = ret;
+        if (epi_p) *epi_p = episodes;
+        if (col_p) *col_p = collisions;
     }
 }
 

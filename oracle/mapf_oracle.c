@@ -33,11 +33,14 @@ static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 }
 
 static double slip_uniform(uint64_t seed, uint64_t env_id, uint64_t t, uint32_t agent) {
-    uint32_t c[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)t,
-                     ((uint32_t)(t >> 32) & 0x00FFFFFFu) | ((agent >> 1) << 24)};
-    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
-    uint32_t a = (agent & 1) ? c[2] : c[0], b = (agent & 1) ? c[3] : c[1];
-    uint64_t mant = ((uint64_t)(a >> 5) << 26) | (uint64_t)(b >> 6);
+    const uint64_t h = t >> 1;
+    const uint32_t c3 = ((uint32_t)(h >> 32) & 0x00FFFFFFu) | (((agent >> 1) & 0x7Fu) << 24);
+    const uint32_t slot = 2u * (uint32_t)(t & 1) + (agent & 1u);
+    uint32_t a[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)h, c3};
+    uint32_t b[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)h, c3 | 0x80000000u};   /* refine */
+    philox4x32_10(a, (uint32_t)seed, (uint32_t)(seed >> 32));
+    philox4x32_10(b, (uint32_t)seed, (uint32_t)(seed >> 32));
+    uint64_t mant = ((uint64_t)(a[slot] >> 5) << 26) | (uint64_t)(b[slot] >> 6);
     return (double)mant / 9007199254740992.0;
 }
 

@@ -18,18 +18,24 @@ vectors in tests/test_philox.py.
 Stream layout (shared with include/mapf_hip.h):
 
     key  = (seed & 0xffffffff, seed >> 32)
+    h    = t >> 1                                   # one Philox call serves two consecutive steps
     ctr  = (env_id & 0xffffffff,
             env_id >> 32,
-            t & 0xffffffff,
-            ((t >> 32) & 0x00ffffff) | ((agent >> 1) << 24))
-    w    = philox4x32_10(ctr, key)
-    (a, b) = (w[0], w[1]) if agent is even else (w[2], w[3])
-    u    = ((a >> 5) * 2**26 + (b >> 6)) / 2**53          # 53-bit, in [0, 1)
+            h & 0xffffffff,
+            ((h >> 32) & 0x00ffffff) | ((agent >> 1) << 24) | (refine << 31))
+    slot = 2 * (t & 1) + (agent & 1)                # which of the four 32-bit output words
+    hi27 = philox4x32_10(ctr with refine = 0, key)[slot] >> 5
+    lo26 = philox4x32_10(ctr with refine = 1, key)[slot] >> 6
+    u    = (hi27 * 2**26 + lo26) / 2**53            # 53-bit, in [0, 1) -- the resolution of RandomState.rand()
 
-``t`` is the handle-global step index (number of ``step`` calls so far), so a
-terminal-state step simply leaves its counters unused -- equivalent to the
-reference's "no draw on terminal steps" because nothing downstream depends on
-how many words an env has consumed.
+A 53-bit uniform is thus split over two counters.  The kernel compares hi27 against the top 27 bits of
+its thresholds and evaluates the refine = 1 call only in the (probability ~2^-25) case where those bits
+tie, so the common path costs one Philox call per agent pair per TWO steps while the value compared is
+exactly the u above.  The CPU oracle simply computes both words every time.
+
+``t`` is the handle-global step index (number of ``step`` calls so far), so a terminal-state step simply
+leaves its counters unused -- equivalent to the reference's "no draw on terminal steps" because nothing
+downstream depends on how many words an env has consumed.
 """
 import numpy as np
 
@@ -79,20 +85,22 @@ def philox4x32_10_np(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
-def _ctr_words(env_id, t, agent):
+def _ctr_words(env_id, t, agent, refine):
+    h = t >> 1
     c0 = env_id & MASK32
     c1 = (env_id >> 32) & MASK32
-    c2 = t & MASK32
-    c3 = ((t >> 32) & 0x00FFFFFF) | (((agent >> 1) & 0xFF) << 24)
+    c2 = h & MASK32
+    c3 = ((h >> 32) & 0x00FFFFFF) | (((agent >> 1) & 0x7F) << 24) | ((refine & 1) << 31)
     return c0, c1, c2, c3
 
 
 def slip_uniform(seed, env_id, t, agent):
     """The 53-bit uniform the slip model of (env_id, step t, agent) consumes."""
-    w = philox4x32_10(_ctr_words(int(env_id), int(t), int(agent)),
-                      (seed & MASK32, (seed >> 32) & MASK32))
-    a, b = (w[0], w[1]) if (agent & 1) == 0 else (w[2], w[3])
-    return ((a >> 5) * 67108864 + (b >> 6)) / 9007199254740992.0
+    key = (seed & MASK32, (seed >> 32) & MASK32)
+    slot = 2 * (int(t) & 1) + (int(agent) & 1)
+    hi = philox4x32_10(_ctr_words(int(env_id), int(t), int(agent), 0), key)[slot] >> 5
+    lo = philox4x32_10(_ctr_words(int(env_id), int(t), int(agent), 1), key)[slot] >> 6
+    return (hi * 67108864 + lo) / 9007199254740992.0
 
 
 def slip_uniforms_np(seed, env_ids, t, n_agents):
@@ -100,15 +108,17 @@ def slip_uniforms_np(seed, env_ids, t, n_agents):
     env_ids = np.asarray(env_ids, dtype=np.uint64).reshape(-1, 1)
     pairs = (np.arange(n_agents, dtype=np.uint64) >> np.uint64(1)).reshape(1, -1)
     t = int(t)
+    h = t >> 1
     c0 = env_ids & np.uint64(MASK32)
     c1 = env_ids >> np.uint64(32)
-    c2 = np.uint64(t & MASK32)
-    c3 = np.uint64((t >> 32) & 0x00FFFFFF) | (pairs << np.uint64(24))
-    w0, w1, w2, w3 = philox4x32_10_np(c0, c1, c2, c3, seed & MASK32, (seed >> 32) & MASK32)
-    odd = (np.arange(n_agents) & 1).astype(bool).reshape(1, -1)
-    a = np.where(odd, w2, w0)
-    b = np.where(odd, w3, w1)
-    mant = (a >> np.uint64(5)) * np.uint64(67108864) + (b >> np.uint64(6))
+    c2 = np.uint64(h & MASK32)
+    c3 = np.uint64((h >> 32) & 0x00FFFFFF) | (pairs << np.uint64(24))
+    k0, k1 = seed & MASK32, (seed >> 32) & MASK32
+    slot = 2 * (t & 1) + (np.arange(n_agents) & 1).reshape(1, -1)
+    slot = np.broadcast_to(slot, (env_ids.shape[0], n_agents))
+    hi = np.choose(slot, philox4x32_10_np(c0, c1, c2, c3, k0, k1)) >> np.uint64(5)
+    lo = np.choose(slot, philox4x32_10_np(c0, c1, c2, c3 | np.uint64(1 << 31), k0, k1)) >> np.uint64(6)
+    mant = hi * np.uint64(67108864) + lo
     return mant.astype(np.float64) / 9007199254740992.0
 
 
