@@ -43,6 +43,17 @@ def bytes_per_agent_step(A):
     return 5.0 + 18.0 / A
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel`, from the committed rocprofv3 PMC passes of this same command
+    (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950).  None when no profile is present."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            return json.load(f)['kernels'][kernel]['hbm_bytes_per_launch']
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def workload_tables(n_envs, env_id_offset):
     from gym_mapf_amd.envs import map_name_to_files
     from gym_mapf_amd.envs.grid import MapfGrid
@@ -105,13 +116,16 @@ def cpu_baseline(budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2000)
-    ap.add_argument('--warmup', type=int, default=200)
+    ap.add_argument('--steps', type=int, default=2048)
+    ap.add_argument('--warmup', type=int, default=128)
     ap.add_argument('--envs', type=int, default=65536, help='envs per GPU')
     ap.add_argument('--ring', type=int, default=512, help='distinct pre-generated action steps kept in HBM')
     ap.add_argument('--rollout-steps', type=int, default=64, help='T of the fused rollout leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--kernel', default='auto', choices=['auto', 'thread_per_env', 'lane_group'])
+    ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="'gloo' + --share-device rehearses the N > 1 path on a one-GPU box")
+    ap.add_argument('--share-device', action='store_true', help='every rank uses cuda:0 (rehearsal only)')
     args = ap.parse_args()
 
     import torch
@@ -121,12 +135,18 @@ def main():
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
                          % (args.gpus, world, args.gpus))
+    if args.share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group('gloo')
+    coll_dev = 'cuda' if args.dist_backend == 'nccl' else 'cpu'
 
     from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv
     E, A, K, W = args.envs, N_AGENTS, args.steps, args.warmup
@@ -188,7 +208,7 @@ def main():
         barrier()
         wall = time.perf_counter() - t0
         if dist is not None:
-            tmax = torch.tensor([wall], dtype=torch.float64, device='cuda')
+            tmax = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             wall = float(tmax.item())
         return wall, gpu_ms
@@ -232,7 +252,7 @@ def main():
     if dist is not None:
         # the one collective of the path: gather per-env episode returns
         env.sync()
-        gathered = sharding.gather_returns(acc['returns'])
+        gathered = sharding.gather_returns(acc['returns'] if coll_dev == 'cuda' else acc['returns'].cpu())
         torch.cuda.synchronize()
         assert gathered.numel() == world * E
 
@@ -251,7 +271,8 @@ def main():
               "ms_per_step": wall1 * 1e3 / K1, "kernel": "mapf::lg_step_kernel<4,true,false>",
               "roofline": {"bound": "hbm", "achieved": launch_bytes / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": launch_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "traffic": None, "bytes_per_launch": launch_bytes, "ms_per_launch_hip_events": step_ms}}
+                           "traffic": measured_traffic("lg_step_kernel") if E == 65536 else None,
+                           "bytes_per_launch": launch_bytes, "ms_per_launch_hip_events": step_ms}}
 
     if rank == 0:
         line = {
@@ -265,8 +286,9 @@ def main():
                        "steps_per_launch": T, "launches": n_launch, "action_ring_steps": ring,
                        "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ro_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ro_achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "mapf::lg_rollout_kernel<4,true>", "bytes_per_launch": ro_bytes,
+                         "frac": ro_achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic("lg_rollout_kernel") if T == 64 and E == 65536 else None,
+                         "kernel": "mapf::lg_rollout_kernel<4,true,true,true,true>", "bytes_per_launch": ro_bytes,
                          "ms_per_launch_hip_events": ro_launch_ms},
             "single_step_launches": single,
             "parity": parity,
