@@ -254,3 +254,72 @@ def test_results_do_not_depend_on_how_envs_are_sharded():
         assert np.array_equal(_bits(p.rollout(40)['returns']), _bits(full['returns'][sl]))
     whole.close()
     [p.close() for p in parts]
+
+
+# ----------------------------------------------------------------------- BASELINE.json full sizes
+def _full_size_check(grid, nbr, A, start, goal, fail_prob, crit, ocrit, n_step, n_roll, kernel='auto'):
+    E = start.shape[0]
+    env = VecMapfEnv(grid, A, None, None, fail_prob, -1000.0, 100.0, -1.0, crit, seed=42, start_local=start,
+                     goal_local=goal, kernel=kernel)
+    co = c_oracle.COracle(nbr, A, start, goal, fail_prob, -1000.0, 100.0, -1.0, ocrit, seed=42)
+    ids = np.arange(E)
+    for t in range(n_step):
+        acts = philox.random_actions_np(42, ids, t, A)
+        local, reward, done, info = env.step(acts, auto_reset=True)
+        ref = co.step(acts, auto_reset=True)
+        assert np.array_equal(local, ref['local']), t
+        assert np.array_equal(_bits(reward), _bits(ref['reward'])) and np.array_equal(_bits(info['prob']), _bits(ref['prob']))
+        assert np.array_equal(done, ref['done']) and np.array_equal(info['collision'], ref['collision'])
+    res = env.rollout(n_roll, auto_reset=True, record=True)          # in-kernel policy stream, recorded
+    ref = co.rollout(n_roll, auto_reset=True)
+    assert np.array_equal(_bits(res['returns']), _bits(ref['returns']))
+    assert np.array_equal(res['episodes'], ref['episodes']) and np.array_equal(res['collisions'], ref['collisions'])
+    assert np.array_equal(env.get_state()[0], co.state)
+    # size-independent properties of the recorded trajectory
+    assert np.array_equal(res['done'].sum(0), res['episodes']) and np.array_equal(res['collision'].sum(0), res['collisions'])
+    ret = np.zeros(E)
+    for t in range(n_roll):
+        ret = ret + res['reward'][t]
+    assert np.array_equal(_bits(ret), _bits(res['returns']))          # returns == ordered sum of recorded rewards
+    assert np.all((res['prob'] > 0) & (res['prob'] <= 1.0)) and np.all(res['local'] < nbr.shape[0])
+    assert np.all(res['collision'] <= res['done'])                    # a collision always ends the episode
+    env.close()
+    return int(res['episodes'].sum())
+
+
+def test_config2_empty16_4agents_4096_envs():
+    """BASELINE configs[1]: empty-16-16, 4 agents, slip 0.1, 4096 envs, scen id 1 + e mod 25."""
+    from gym_mapf_amd.envs import map_name_to_files
+    from gym_mapf_amd.envs.utils import parse_map_file, parse_scen_file
+    grid = MapfGrid(parse_map_file(map_name_to_files('empty-16-16', 1)[0]))
+    _, l2i, nbr = grid.tables()
+    per = [parse_scen_file(map_name_to_files('empty-16-16', sid)[1], 4) for sid in range(1, 26)]
+    E = 4096
+    start = np.asarray([[l2i[l] for l in per[e % 25][0]] for e in range(E)], np.uint16)
+    goal = np.asarray([[l2i[l] for l in per[e % 25][1]] for e in range(E)], np.uint16)
+    for kernel in KERNELS:
+        assert _full_size_check(grid, nbr, 4, start, goal, 0.1, OptimizationCriteria.Makespan, mo.MAKESPAN, 60, 120, kernel) > 0
+
+
+def test_config3_room32_8agents_65536_envs():
+    """BASELINE configs[2] (the bench workload): room-32-32-4, 8 agents, slip 0.2, 65536 envs; every env of
+    every step against the C oracle, both criteria."""
+    import bench
+    grid, nbr, start, goal = bench.workload_tables(65536, 0)
+    assert _full_size_check(grid, nbr, 8, start, goal, 0.2, OptimizationCriteria.Makespan, mo.MAKESPAN, 12, 48) > 0
+    assert _full_size_check(grid, nbr, 8, start, goal, 0.2, OptimizationCriteria.SoC, mo.SOC, 4, 24, 'thread_per_env') > 0
+
+
+def test_config5_random64_32agents_16384_envs():
+    """BASELINE configs[4], one GPU's share (131072 / 8): synthetic 64x64 map with 20 % obstacles
+    (RandomState(20); the reference does not ship random-64-64-20), 32 agents, slip 0.2, seeded random
+    distinct starts / goals -- the conflict-heavy stress case."""
+    rs = np.random.RandomState(20)
+    obst = rs.rand(64, 64) < 0.20
+    grid = MapfGrid([''.join('@' if obst[r, c] else '.' for c in range(64)) for r in range(64)])
+    valid, _, nbr = grid.tables()
+    V, E, A = len(valid), 16384, 32
+    r2 = np.random.RandomState(42)
+    start = np.argsort(r2.rand(E, V), axis=1)[:, :A].astype(np.uint16)      # distinct cells per env
+    goal = np.argsort(r2.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    assert _full_size_check(grid, nbr, A, start, goal, 0.2, OptimizationCriteria.SoC, mo.SOC, 6, 24) > 1000
