@@ -216,6 +216,45 @@ class MapfEnv(_EnvBase):
                 print(token, end=' ')
             print('')
 
+    def render_with_policy(self, agent: int, policy):
+        """One agent's policy as arrows: every cell shows the action ``policy`` picks for ``agent`` when that agent
+        stands there and the others stay where they are; the agent's own cell (yellow; green on its goal) and its
+        goal (blue) show indices instead (reference :324-356).  Like the reference this raises ``KeyError`` on maps
+        with obstacles, because obstacle cells are encoded too."""
+        print('')
+        where = self.state_to_locations(self.s)
+        goals = tuple(tuple(g) for g in self.agents_goals)
+        here, target = where[agent], goals[agent]
+        for r in range(len(self.grid)):
+            print('')
+            for c in range(len(self.grid[0])):
+                cell = (r, c)
+                if cell == target and target == here:
+                    token = _Fore.GREEN + str(where.index(cell)) + _Fore.RESET
+                elif cell == here:
+                    token = _Fore.YELLOW + str(where.index(cell)) + _Fore.RESET
+                elif cell == target:
+                    token = _Fore.BLUE + str(goals.index(cell)) + _Fore.RESET
+                else:
+                    moved = where[:agent] + (cell,) + where[agent + 1:]
+                    joint = policy(self.locations_to_state(moved))
+                    token = ACTION_TO_CHAR[integer_action_to_vector(joint, self.n_agents)[agent]]
+                print(token, end=' ')
+        print('')
+
+    def predecessors(self, s: int):
+        """States from which ``s`` can be entered in one noise-free joint move: per agent the cells reached from its
+        location by any of the five actions (moves are symmetric on a grid with clamp/bounce), combined over
+        agents (reference :373-376, :414-434)."""
+        _, _, nbr = self.grid.tables()
+        options = [sorted(set(int(v) for v in nbr[self.loc_to_int[loc]])) for loc in self.state_to_locations(s)]
+        V = len(self.valid_locations)
+        states, weight = {0}, 1
+        for cells in options:                      # agent 0 is the least significant digit
+            states = {base + c * weight for base in states for c in cells}
+            weight *= V
+        return states
+
     # ------------------------------------------------------------------ joint codecs
     def state_to_locations(self, state):
         """Joint state int -> tuple of (row, col), agent 0 first (reference :358-362)."""

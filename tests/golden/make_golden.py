@@ -336,6 +336,79 @@ def transition_tables():
     print('transition tables: %d envs' % len(tabs))
 
 
+def host_api_cases():
+    """Planner-side helpers of the reference: sanity maps, local views, predecessors,
+    render / render_with_policy output -- recorded as plain data."""
+    import contextlib
+    from gym_mapf.envs.utils import create_sanity_mapf_env, get_local_view, manhattan_distance
+    out = {}
+    san = []
+    for (rooms, size, agents) in ((2, 8, 4), (3, 8, 7), (1, 16, 3), (4, 8, 4), (2, 32, 5)):
+        env = create_mapf_env('sanity-%d-%d' % (rooms, size), None, agents, 0.2, R_CLASH, R_GOAL, R_LIVING, CRITERIA['SoC'])
+        san.append(dict(name='sanity-%d-%d' % (rooms, size), n_agents=agents,
+                        lines=[''.join('.' if c.__name__ == 'EmptyCell' else '@' for c in env.grid[r]) for r in range(len(env.grid))],
+                        starts=[list(l) for l in env.agents_starts], goals=[list(l) for l in env.agents_goals],
+                        s=str(env.s), nS=str(env.nS)))
+    out['sanity'] = san
+    bad = []
+    for (rooms, size, agents) in ((3, 8, 2), (5, 8, 4)):
+        try:
+            create_sanity_mapf_env(rooms, size, agents, 0.1, R_CLASH, R_GOAL, R_LIVING, CRITERIA['SoC'])
+            bad.append(None)
+        except ValueError as e:
+            bad.append(str(e))
+    out['sanity_errors'] = bad
+    env = create_mapf_env('room-32-32-4', 12, 6, 0.2, R_CLASH, R_GOAL, R_LIVING, CRITERIA['Makespan'])
+    views = []
+    for idx in ([0, 2], [5], [1, 3, 4], [4, 1]):
+        v = get_local_view(env, idx)
+        v2 = get_local_view(env, idx, fail_prob=0.35)
+        views.append(dict(agents=idx, starts=[list(l) for l in v.agents_starts], goals=[list(l) for l in v.agents_goals],
+                          n_agents=v.n_agents, fail_prob=v.fail_prob, fail_prob_override=v2.fail_prob, s=str(v.s),
+                          same_grid=v.grid is env.grid))
+    out['local_view'] = dict(map='room-32-32-4', scen=12, n_agents=6, views=views,
+                             manhattan=[manhattan_distance(env, env.s, a, b) for a, b in ((0, 1), (2, 5), (3, 3))])
+    preds = []
+    for lines, starts, goals in ((['....', '....', '....'], ((1, 2), (2, 1)), ((0, 0), (2, 3))),
+                                 (['..@.', '....', '.@..'], ((0, 0), (1, 2)), ((2, 2), (0, 3))),
+                                 (['.@.', '...', '.@.'], ((1, 1),), ((0, 0),)),
+                                 (['...', '.@.', '...'], ((0, 0), (2, 2), (0, 2)), ((2, 2), (0, 0), (2, 0)))):
+        e = MapfEnv(MapfGrid(lines), len(starts), starts, goals, 0, R_CLASH, R_GOAL, -1, CRITERIA['Makespan'])
+        states = [e.s, e.locations_to_state(goals)]
+        preds.append(dict(lines=lines, starts=[list(l) for l in starts], goals=[list(l) for l in goals],
+                          queries=[dict(s=str(q), predecessors=sorted(str(x) for x in e.predecessors(q))) for q in states]))
+    out['predecessors'] = preds
+    rend = []
+    e = MapfEnv(MapfGrid(['....', '....', '....']), 2, ((0, 0), (1, 2)), ((2, 2), (0, 0)), 0, R_CLASH, R_GOAL, -1, CRITERIA['Makespan'])
+    for joint in (None, ('RIGHT', 'LEFT'), ('STAY', 'LEFT'), ('LEFT', 'LEFT')):
+        if joint is not None:
+            e.step(vector_action_to_integer(joint))
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            e.render()
+        pol = io.StringIO()
+        with contextlib.redirect_stdout(pol):
+            e.render_with_policy(0, lambda st: (st * 7 + 3) % e.nA)
+        rend.append(dict(after=list(joint) if joint else None, s=str(e.s), render=buf.getvalue(), render_with_policy=pol.getvalue()))
+    out['render'] = dict(lines=['....', '....', '....'], starts=[[0, 0], [1, 2]], goals=[[2, 2], [0, 0]], frames=rend)
+    # on a map with obstacles the reference's render_with_policy raises KeyError (it encodes obstacle cells too)
+    eo = MapfEnv(MapfGrid(['..@.', '....', '.@..']), 2, ((0, 0), (1, 2)), ((2, 2), (0, 0)), 0, R_CLASH, R_GOAL, -1, CRITERIA['Makespan'])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        eo.render()
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            eo.render_with_policy(0, lambda st: 0)
+        err = None
+    except KeyError as ex:
+        err = repr(ex.args[0])
+    out['render_obstacles'] = dict(lines=['..@.', '....', '.@..'], starts=[[0, 0], [1, 2]], goals=[[2, 2], [0, 0]],
+                                   render=buf.getvalue(), render_with_policy_keyerror=err)
+    with open(os.path.join(HERE, 'host_api_cases.json'), 'w') as f:
+        json.dump(out, f, indent=0)
+    print('host api cases: %d sanity, %d views, %d predecessor envs, %d render frames' % (len(san), len(views), len(preds), len(rend)))
+
+
 def reference_selftest():
     """Run the reference's own 25 unit tests under the stand-ins."""
     suite = unittest.defaultTestLoader.discover(os.path.join(REFERENCE, 'gym_mapf', 'tests'),
@@ -352,6 +425,7 @@ def main():
 
     scripted_cases()
     transition_tables()
+    host_api_cases()
 
     # C1: empty-8-8, scen 1, 2 agents, slip 0, one env (reference CPU path config)
     run_trajectories('c1_empty8_a2_slip0', ref_map_lines('empty-8-8'),
