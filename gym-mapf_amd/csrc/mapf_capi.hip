@@ -62,7 +62,8 @@ struct mapf_handle_s {
     uint16_t *state = nullptr, *start = nullptr, *goal = nullptr;
     // host-pointer mode staging
     DeviceBuf s_actions, s_uniforms, s_local, s_reward, s_prob, s_done, s_coll, s_term, s_mask, s_ret, s_epi, s_ncoll;
-    DeviceBuf x_local, x_reward, x_prob, x_done, x_coll;   // stand-ins for trajectory arrays the caller left out
+    DeviceBuf x_local, x_reward, x_prob, x_done, x_coll;
+    DeviceBuf q_local, q_actions, q_env, q_count, q_next, q_prob, q_reward, q_done, q_coll;   // mapf_transitions staging   // stand-ins for trajectory arrays the caller left out
 };
 
 namespace {
@@ -174,7 +175,8 @@ void destroy_impl(mapf_handle_t h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (DeviceBuf *b : {&h->s_actions, &h->s_uniforms, &h->s_local, &h->s_reward, &h->s_prob, &h->s_done,
                          &h->s_coll, &h->s_term, &h->s_mask, &h->s_ret, &h->s_epi, &h->s_ncoll, &h->x_local, &h->x_reward,
-                         &h->x_prob, &h->x_done, &h->x_coll})
+                         &h->x_prob, &h->x_done, &h->x_coll, &h->q_local, &h->q_actions, &h->q_env, &h->q_count, &h->q_next,
+                         &h->q_prob, &h->q_reward, &h->q_done, &h->q_coll})
         b->release();
     if (h->mv) (void)hipFree(h->mv);
     if (h->slip) (void)hipFree(h->slip);
@@ -477,6 +479,41 @@ int mapf_fill_random_actions(mapf_handle_t h, uint8_t *actions, uint64_t t0, uin
     if (int rc = stage_out(h, h->s_actions, actions, n, &d_actions, "actions")) return rc;
     HIP_TRY(mapf::launch_fill_actions(int(h->A), d_actions, h->c, h->env_id_offset, h->E, t0, n_steps, h->stream));
     if (int rc = fetch_out(h, d_actions, actions, n)) return rc;
+    if (!h->device_ptrs) HIP_TRY(hipStreamSynchronize(h->stream));
+    return MAPF_OK;
+}
+
+int mapf_transitions(mapf_handle_t h, uint64_t n_queries, const uint16_t *local, const uint8_t *actions,
+                     const uint32_t *env_index, uint32_t max_branches, uint32_t *out_count, uint16_t *out_next,
+                     double *out_prob, double *out_reward, uint8_t *out_done, uint8_t *out_collision) {
+    if (int rc = check_handle(h)) return rc;
+    if (!local || !actions) return fail(MAPF_EINVAL, "local / actions are null");
+    if (max_branches == 0) return fail(MAPF_EINVAL, "max_branches must be >= 1");
+    if (h->A > uint32_t(mapf::kTransitionsMaxAgents)) return fail(MAPF_EUNSUPPORTED, "mapf_transitions supports n_agents <= 16");
+    const size_t N = size_t(n_queries), NA = N * h->A, NM = N * max_branches;
+    if (!h->device_ptrs) {
+        for (size_t i = 0; i < NA; ++i) if (local[i] >= h->V) return fail(MAPF_EINVAL, "transitions: cell out of range");
+        if (env_index) for (size_t i = 0; i < N; ++i) if (env_index[i] >= h->E) return fail(MAPF_EINVAL, "transitions: env_index out of range");
+    }
+    mapf::TransitionsArgs a{};
+    a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.goal = h->goal; a.goal_broadcast = h->goal_broadcast;
+    a.n_queries = n_queries; a.max_branches = max_branches; a.n_agents = h->A;
+    if (int rc = stage_in(h, h->q_local, local, NA, &a.local, "local")) return rc;
+    if (int rc = stage_in(h, h->q_actions, actions, NA, &a.actions, "actions")) return rc;
+    if (int rc = stage_in(h, h->q_env, env_index, N, &a.env_index, "env_index")) return rc;
+    if (int rc = stage_out(h, h->q_count, out_count, N, &a.out_count, "out_count")) return rc;
+    if (int rc = stage_out(h, h->q_next, out_next, NM * h->A, &a.out_next, "out_next")) return rc;
+    if (int rc = stage_out(h, h->q_prob, out_prob, NM, &a.out_prob, "out_prob")) return rc;
+    if (int rc = stage_out(h, h->q_reward, out_reward, NM, &a.out_reward, "out_reward")) return rc;
+    if (int rc = stage_out(h, h->q_done, out_done, NM, &a.out_done, "out_done")) return rc;
+    if (int rc = stage_out(h, h->q_coll, out_collision, NM, &a.out_collision, "out_collision")) return rc;
+    HIP_TRY(mapf::launch_transitions(a, h->stream));
+    if (int rc = fetch_out(h, a.out_count, out_count, N)) return rc;
+    if (int rc = fetch_out(h, a.out_next, out_next, NM * h->A)) return rc;
+    if (int rc = fetch_out(h, a.out_prob, out_prob, NM)) return rc;
+    if (int rc = fetch_out(h, a.out_reward, out_reward, NM)) return rc;
+    if (int rc = fetch_out(h, a.out_done, out_done, NM)) return rc;
+    if (int rc = fetch_out(h, a.out_collision, out_collision, NM)) return rc;
     if (!h->device_ptrs) HIP_TRY(hipStreamSynchronize(h->stream));
     return MAPF_OK;
 }

@@ -61,6 +61,25 @@ struct RolloutArgs {
 };
 
 // routed by agent count (mapf_dispatch.hip)
+struct TransitionsArgs {
+    EnvConsts c;
+    const uint64_t *mv;
+    const SlipRow *slip;
+    const uint16_t *goal;          // [E*A] or [A]
+    const uint16_t *local;         // [N*A] query states
+    const uint8_t *actions;        // [N*A] query joint actions
+    const uint32_t *env_index;     // [N] env whose goals apply, or null (env 0)
+    uint32_t *out_count;           // [N] number of branches (product of list lengths; 1 for a terminal state)
+    uint16_t *out_next;            // [N*M*A]
+    double *out_prob, *out_reward; // [N*M]
+    uint8_t *out_done, *out_collision;
+    uint64_t n_queries;
+    uint32_t max_branches, n_agents;
+    bool goal_broadcast;
+};
+constexpr int kTransitionsMaxAgents = 16;
+hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream);
+
 hipError_t launch_step(int n_agents, const StepArgs &args, hipStream_t stream);
 hipError_t launch_rollout(int n_agents, const RolloutArgs &args, hipStream_t stream);
 hipError_t launch_reset(int n_agents, uint16_t *state, const uint16_t *start, bool start_broadcast,

@@ -1,0 +1,119 @@
+// env.P[s][a] on the device: every branch of the joint slip distribution of a (state, joint action) query
+// (reference mapf_env.py:448-478 `_get_transitions`, the enumeration planners iterate over).
+//
+// One thread per (query, branch).  Branch b of a query selects entry k_i of agent i's merged movement list
+// (single_agent_movements, :163-184) in itertools.product order -- agent 0 varies slowest -- so
+// k_i = digit i of b in the mixed radix (n_0, ..., n_{A-1}).  prob is the left-to-right float64 product of the
+// selected probabilities (functools.reduce at :467); reward / done / collision come from the same rules as
+// step() (:225-235).  A terminal state has the single branch ((1.0, False), s, 0, True) (:455-456).
+#include "mapf_kernels.hpp"
+#include "mapf_device.hpp"
+
+namespace mapf {
+
+template <int MAXA>
+__global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs p) {
+    __shared__ SlipRow slip[8];
+    stage_slip_table(p.slip, slip);
+    const uint64_t gid = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const uint64_t q = gid / p.max_branches;
+    const uint32_t b = uint32_t(gid - q * p.max_branches);
+    if (q >= p.n_queries) return;
+    const uint32_t A = p.n_agents;
+    const uint64_t env = p.env_index ? p.env_index[q] : 0;
+    const uint16_t *goal_row = p.goal + (p.goal_broadcast ? 0 : env * A);
+    const uint16_t *state_row = p.local + q * A;
+    const uint8_t *act_row = p.actions + q * A;
+
+    uint32_t prev[MAXA], goal[MAXA], act[MAXA], n[MAXA];
+    uint64_t entry[MAXA];
+    uint32_t dup_acc = 0xFFFFFFFFu, goal_acc = 0u;
+    uint64_t count = 1;
+#pragma unroll
+    for (int i = 0; i < MAXA; ++i) {
+        const bool on = uint32_t(i) < A;
+        prev[i] = on ? state_row[i] : 0x10000u + uint32_t(i);       // ghosts: unique, never equal to a real cell
+        goal[i] = on ? goal_row[i] : prev[i];
+        const uint32_t a = on ? act_row[i] : 0u;
+        act[i] = a > 4u ? 0u : a;
+        entry[i] = on ? move_entry(p.mv, p.c.n_cells, prev[i], act[i]) : 0;
+        n[i] = on ? slip[uint32_t(entry[i] >> 48) & 7u].n : 1u;
+        count *= n[i];
+        goal_acc |= prev[i] ^ goal[i];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXA; ++i)
+#pragma unroll
+        for (int j = i + 1; j < MAXA; ++j) dup_acc = min(dup_acc, prev[i] ^ prev[j]);
+    const bool terminal = dup_acc == 0u || goal_acc == 0u;           // is_terminal: mapf_env.py:210-223
+    if (terminal) count = 1;
+    if (b == 0 && p.out_count) p.out_count[q] = uint32_t(count > 0xFFFFFFFFull ? 0xFFFFFFFFull : count);
+    if (uint64_t(b) >= count) return;
+
+    const uint64_t o = q * p.max_branches + b;
+    if (terminal) {
+        if (p.out_next) for (uint32_t i = 0; i < A; ++i) p.out_next[o * A + i] = uint16_t(prev[i]);
+        if (p.out_prob) p.out_prob[o] = 1.0;
+        if (p.out_reward) p.out_reward[o] = 0.0;
+        if (p.out_done) p.out_done[o] = 1;
+        if (p.out_collision) p.out_collision[o] = 0;
+        return;
+    }
+    // digits of b, last agent fastest
+    uint32_t k[MAXA];
+    uint32_t rest = b;
+#pragma unroll
+    for (int i = MAXA - 1; i >= 0; --i) { k[i] = rest % n[i]; rest /= n[i]; }
+
+    uint32_t next[MAXA];
+    double prob = 1.0;
+    int stayed = 0;
+    uint32_t coll_acc = 0xFFFFFFFFu, goal_next_acc = 0u;
+#pragma unroll
+    for (int i = 0; i < MAXA; ++i) {
+        const bool on = uint32_t(i) < A;
+        const SlipRow &row = slip[uint32_t(entry[i] >> 48) & 7u];
+        const uint32_t lo = uint32_t(entry[i]), hi = uint32_t(entry[i] >> 32);
+        const uint32_t cell = k[i] == 0u ? (lo & 0xFFFFu) : (k[i] == 1u ? (lo >> 16) : (hi & 0xFFFFu));
+        next[i] = on ? cell : prev[i];
+        const double qv = on ? row.q[k[i]] : 1.0;
+        prob = (i == 0) ? qv : __dmul_rn(prob, qv);
+        stayed += (on && prev[i] == goal[i] && act[i] == 0u) ? 1 : 0;
+        goal_next_acc |= next[i] ^ goal[i];
+    }
+#pragma unroll
+    for (int i = 0; i < MAXA; ++i) {
+        const uint32_t fwd = prev[i] | (next[i] << 16);
+#pragma unroll
+        for (int j = i + 1; j < MAXA; ++j) {
+            // ghost cells (>= 0x10000) overflow the 16-bit packing, so test the swap on the unpacked cells
+            const bool swap = prev[i] == next[j] && prev[j] == next[i];
+            coll_acc = min(coll_acc, min(next[i] ^ next[j], swap ? 0u : 1u));
+            (void)fwd;
+        }
+    }
+    const bool coll = coll_acc == 0u, goal_next = goal_next_acc == 0u;
+    double living = p.c.r_living;
+    if (p.c.criteria == 1u) living = __dmul_rn(double(int(A) - stayed), p.c.r_living);
+    const double reward = coll ? __dadd_rn(p.c.r_clash, living) : (goal_next ? __dadd_rn(p.c.r_goal, living) : living);
+    if (p.out_next) for (uint32_t i = 0; i < A; ++i) p.out_next[o * A + i] = uint16_t(next[i]);
+    if (p.out_prob) p.out_prob[o] = prob;
+    if (p.out_reward) p.out_reward[o] = reward;
+    if (p.out_done) p.out_done[o] = (coll || goal_next) ? 1 : 0;
+    if (p.out_collision) p.out_collision[o] = coll ? 1 : 0;
+}
+
+hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream) {
+    const uint64_t threads = args.n_queries * uint64_t(args.max_branches);
+    if (threads == 0) return hipSuccess;
+    const uint64_t grid64 = (threads + 255) / 256;
+    if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const dim3 grid{unsigned(grid64)}, block{256};
+    if (args.n_agents <= 4) hipLaunchKernelGGL(transitions_kernel<4>, grid, block, 0, stream, args);
+    else if (args.n_agents <= 8) hipLaunchKernelGGL(transitions_kernel<8>, grid, block, 0, stream, args);
+    else if (args.n_agents <= 16) hipLaunchKernelGGL(transitions_kernel<16>, grid, block, 0, stream, args);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace mapf

@@ -47,6 +47,8 @@ SIGNATURES = {
     'mapf_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
     'mapf_rollout': (c_int, [c_void_p, POINTER(MapfRolloutIO)]),
     'mapf_fill_random_actions': (c_int, [c_void_p, c_void_p, c_uint64, c_uint32]),
+    'mapf_transitions': (c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p]),
     'mapf_query_terminal': (c_int, [c_void_p, c_void_p]),
     'mapf_get_state': (c_int, [c_void_p, c_void_p, POINTER(c_uint64)]),
     'mapf_set_state': (c_int, [c_void_p, c_void_p, c_uint64]),

@@ -107,6 +107,26 @@ def integer_action_to_vector(a, n_agents):
     return integer_to_vector(a, [len(ACTIONS)] * n_agents, n_agents, lambda n: ACTIONS[n])
 
 
+class _TransitionsOfState:
+    """``env.P[s]``: indexing with a joint action gives the reference's transition list."""
+
+    def __init__(self, env, state):
+        self._env, self._state = env, state
+
+    def __getitem__(self, action):
+        return self._env._get_transitions(self._state, action)
+
+
+class _TransitionModel:
+    """``env.P``: ``env.P[s][a]`` -> [((prob, collision), next_state, reward, done), ...] (reference :149, :481-483)."""
+
+    def __init__(self, env):
+        self._env = env
+
+    def __getitem__(self, state):
+        return _TransitionsOfState(self._env, state)
+
+
 class MapfEnv(_EnvBase):
     def __init__(self, grid, n_agents, start_locations, goal_locations, fail_prob,
                  reward_of_collision, reward_of_goal, reward_of_living, optimization_criteria):
@@ -129,6 +149,7 @@ class MapfEnv(_EnvBase):
         self.action_space = _make_discrete(self.nA)
         self.observation_space = _make_discrete(self.nS)
 
+        self.P = _TransitionModel(self)
         self._vec = None        # one-env VecMapfEnv, created on first use (needs the GPU)
         self._terminal = None   # is_terminal(self.s) if known
         self.reset()
@@ -190,6 +211,20 @@ class MapfEnv(_EnvBase):
         self._terminal = None if done else False   # a done state may (vertex/goal) or may not (swap) be terminal
         return self._s, float(reward[0]), done, {"prob": float(info['prob'][0]),
                                                  "collision": bool(info['collision'][0])}
+
+    def _get_transitions(self, s, a):
+        """All branches of taking joint action ``a`` in joint state ``s``, in the reference's order
+        (mapf_env.py:448-478); enumerated by the ``mapf_transitions`` kernel."""
+        n, V = self.n_agents, len(self.valid_locations)
+        local = integer_to_vector(s, [V] * n, n, lambda x: x)
+        digits = integer_to_vector(a, [len(ACTIONS)] * n, n, lambda x: x)
+        res = self._device().transitions(np.asarray([local], dtype=np.uint16), np.asarray([digits], dtype=np.uint8))
+        out = []
+        for b in range(int(res['count'][0])):
+            nxt = vector_to_integer(tuple(int(c) for c in res['next'][0, b]), [V] * n, lambda x: x)
+            out.append(((float(res['prob'][0, b]), bool(res['collision'][0, b])), nxt,
+                        float(res['reward'][0, b]), bool(res['done'][0, b])))
+        return out
 
     def render(self, mode='human'):
         """ASCII picture, same priorities as the reference (:295-322): '*' where agents share a

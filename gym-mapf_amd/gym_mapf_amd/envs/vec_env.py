@@ -250,6 +250,30 @@ class VecMapfEnv:
         nat.check(self._lib.mapf_rollout(self._h, ctypes.byref(io)))
         return res
 
+    def transitions(self, local, actions, max_branches=None, env_index=None):
+        """``env.P[s][a]`` for N (state, joint action) queries (reference mapf_env.py:448-478): every branch of the
+        joint slip distribution in the reference's order.  ``local`` uint16 [N, A], ``actions`` uint8 [N, A],
+        ``env_index`` uint32 [N] picks whose goals apply (default env 0).  Returns a dict: ``count`` uint32 [N] and,
+        padded to ``max_branches`` rows per query (default 3**A), ``next`` uint16 [N, M, A], ``prob`` / ``reward``
+        float64 [N, M], ``done`` / ``collision`` uint8 [N, M].  Rows >= count[q] are unspecified."""
+        A = self.n_agents
+        local = np.asarray(local) if not self.device_arrays else local
+        N = int(local.shape[0])
+        M = int(max_branches) if max_branches is not None else 3 ** A
+        local = self._coerce(local, np.uint16, (N, A), 'local')
+        actions = self._coerce(actions, np.uint8, (N, A), 'actions')
+        env_index = self._coerce(env_index, np.uint32, (N,), 'env_index')
+        res = {'count': self._empty((N,), np.uint32), 'next': self._empty((N, M, A), np.uint16),
+               'prob': self._empty((N, M), np.float64), 'reward': self._empty((N, M), np.float64),
+               'done': self._empty((N, M), np.uint8), 'collision': self._empty((N, M), np.uint8)}
+        nat.check(self._lib.mapf_transitions(
+            self._h, N, self._ptr(local, np.uint16, (N, A), 'local'), self._ptr(actions, np.uint8, (N, A), 'actions'),
+            self._ptr(env_index, np.uint32, (N,), 'env_index'), M, self._ptr(res['count'], np.uint32, (N,), 'count'),
+            self._ptr(res['next'], np.uint16, (N, M, A), 'next'), self._ptr(res['prob'], np.float64, (N, M), 'prob'),
+            self._ptr(res['reward'], np.float64, (N, M), 'reward'), self._ptr(res['done'], np.uint8, (N, M), 'done'),
+            self._ptr(res['collision'], np.uint8, (N, M), 'collision')))
+        return res
+
     def fill_random_actions(self, t0, n_steps, out=None):
         """Synthetic policy stream: uint8 [n_steps, E, A] uniform over the 5 actions."""
         shape = (int(n_steps), self.n_envs, self.n_agents)

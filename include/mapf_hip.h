@@ -152,6 +152,20 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io);
  * t0 .. t0+n_steps-1 from the policy stream (oracle/philox.py random_actions_np). */
 int mapf_fill_random_actions(mapf_handle_t h, uint8_t *actions, uint64_t t0, uint32_t n_steps);
 
+/*
+ * MapfEnv.P[s][a] (mapf_env.py:448-478 _get_transitions): for each of n_queries (state, joint action) pairs,
+ * every branch of the joint slip distribution, in the reference's order (itertools.product over the agents'
+ * merged movement lists, agent 0 slowest).  Does not touch the handle's env state or step index.
+ *   local u16[N*A], actions u8[N*A]; env_index u32[N] selects whose goals apply (NULL: env 0)
+ *   max_branches M: rows reserved per query (3^A always suffices); out_count u32[N] reports the true number
+ *   out_next u16[N*M*A], out_prob f64[N*M], out_reward f64[N*M], out_done u8[N*M], out_collision u8[N*M]
+ * Rows b >= out_count[q] are left untouched.  A terminal state yields one branch (prob 1.0, reward 0, done).
+ * Supported for n_agents <= 16 (the enumeration is exponential in A).  Any out_* may be NULL.
+ */
+int mapf_transitions(mapf_handle_t h, uint64_t n_queries, const uint16_t *local, const uint8_t *actions,
+                     const uint32_t *env_index, uint32_t max_branches, uint32_t *out_count, uint16_t *out_next,
+                     double *out_prob, double *out_reward, uint8_t *out_done, uint8_t *out_collision);
+
 /* MapfEnv.is_terminal (mapf_env.py:210-223) of every env's CURRENT state: out_terminal u8[E] is 1
  * where two agents share a cell or every agent is on its goal (a step there is a no-op). */
 int mapf_query_terminal(mapf_handle_t h, uint8_t *out_terminal);

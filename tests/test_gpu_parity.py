@@ -323,3 +323,57 @@ def test_config5_random64_32agents_16384_envs():
     start = np.argsort(r2.rand(E, V), axis=1)[:, :A].astype(np.uint16)      # distinct cells per env
     goal = np.argsort(r2.rand(E, V), axis=1)[:, :A].astype(np.uint16)
     assert _full_size_check(grid, nbr, A, start, goal, 0.2, OptimizationCriteria.SoC, mo.SOC, 6, 24) > 1000
+
+
+# ----------------------------------------------------------------------- env.P enumeration (mapf_transitions)
+def test_transition_tables_match_reference_on_device():
+    """env.P[s][a] from the mapf_transitions kernel == the lists the reference enumerated (order, float64
+    bits of prob and reward, flags, next cells)."""
+    for tab in load_json('transition_tables.json'):
+        A = len(tab['starts'])
+        env = VecMapfEnv(MapfGrid(tab['lines']), A, tab['starts'], tab['goals'], tab['fail_prob'], tab['r_clash'],
+                         tab['r_goal'], tab['r_living'], CRIT[tab['criteria']], n_envs=1)
+        local = np.asarray([row['local'] for row in tab['rows']], np.uint16)
+        acts = np.asarray([row['actions'] for row in tab['rows']], np.uint8)
+        res = env.transitions(local, acts)
+        for q, row in enumerate(tab['rows']):
+            exp = row['transitions']
+            assert int(res['count'][q]) == len(exp), tab['name']
+            for b, e in enumerate(exp):
+                assert res['next'][q, b].tolist() == e['next_local']
+                assert _bits(res['prob'][q, b]) == _bits(e['prob']) and _bits(res['reward'][q, b]) == _bits(e['reward'])
+                assert bool(res['done'][q, b]) == e['done'] and bool(res['collision'][q, b]) == e['collision']
+        env.close()
+
+
+@pytest.mark.parametrize('n_agents,criteria', [(1, 'SoC'), (2, 'Makespan'), (3, 'SoC'), (4, 'Makespan'), (5, 'SoC'), (6, 'SoC')])
+def test_transitions_random_queries_against_oracle(n_agents, criteria):
+    """Random (state, action) queries, including terminal and colliding states and per-query goals, against the
+    pinned Python oracle's enumeration."""
+    rs = np.random.RandomState(40 + n_agents)
+    lines = [''.join('@' if rs.rand() < 0.2 else '.' for _ in range(7)) for _ in range(6)]
+    grid = MapfGrid(lines)
+    V, A, E, N = len(grid.tables()[0]), n_agents, 5, 60
+    start = np.stack([rs.choice(V, A, replace=False) for _ in range(E)]).astype(np.uint16)
+    goal = np.stack([rs.choice(V, A, replace=False) for _ in range(E)]).astype(np.uint16)
+    fp = 0.3 if n_agents % 2 else 1.0
+    env = VecMapfEnv(grid, A, None, None, fp, -20.0, 7.5, -0.5, CRIT[criteria], start_local=start, goal_local=goal)
+    valid = grid.tables()[0]
+    oracles = [mo.OracleEnv(lines, A, [valid[c] for c in start[e]], [valid[c] for c in goal[e]], fp, -20.0, 7.5, -0.5,
+                            OCRIT[criteria]) for e in range(E)]
+    env_index = rs.randint(0, E, size=N).astype(np.uint32)
+    local = rs.randint(0, V, size=(N, A)).astype(np.uint16)           # duplicates (terminal states) do occur
+    local[:5] = goal[env_index[:5]]                                    # all-on-goal terminal states
+    acts = rs.randint(0, 5, size=(N, A)).astype(np.uint8)
+    res = env.transitions(local, acts, env_index=env_index)
+    for q in range(N):
+        exp = oracles[env_index[q]].transitions(tuple(int(c) for c in local[q]), acts[q].tolist())
+        assert int(res['count'][q]) == len(exp), q
+        for b, ((p, c), nxt, r, d) in enumerate(exp):
+            assert res['next'][q, b].tolist() == list(nxt), (q, b)
+            assert _bits(res['prob'][q, b]) == _bits(p) and _bits(res['reward'][q, b]) == _bits(r), (q, b)
+            assert bool(res['done'][q, b]) == d and bool(res['collision'][q, b]) == c, (q, b)
+    small = env.transitions(local, acts, max_branches=2, env_index=env_index)       # truncated rows, true counts
+    assert np.array_equal(small['count'], res['count'])
+    assert np.array_equal(small['next'][:, 0], res['next'][:, 0]) and np.array_equal(_bits(small['prob'][:, 0]), _bits(res['prob'][:, 0]))
+    env.close()

@@ -2,9 +2,8 @@
 
 Host-only cases run anywhere; every case that calls step() is marked gpu because the transition
 runs in the HIP kernel.  Expected values are the ones the reference's tests assert (cited per test).
-``env.P`` (the planner transition enumeration, reference mapf_env.py:448-483) is a later row of the
-hot-path scope -- its known answers are pinned on the oracle in
-test_oracle_golden.py::test_transition_tables_match_reference until the device version exists.
+``env.P`` (the planner transition enumeration, reference mapf_env.py:448-483) runs in the
+``mapf_transitions`` kernel; its cases below are therefore GPU tests too.
 """
 import os
 from copy import copy
@@ -257,3 +256,47 @@ def test_render_marks_agents_goals_and_clashes(capsys):     # mapf_env.py:295-32
     env.step(vector_action_to_integer((RIGHT, LEFT)))          # both move into (0, 1): vertex clash
     env.render()
     assert '*' in capsys.readouterr().out
+
+
+# ------------------------------------------------------------------ mapf_env_tests.py (env.P cases: GPU)
+FAIL_PROB = 0.2
+
+
+@pytest.mark.gpu
+def test_transition_function_empty_grid():                  # mapf_env_tests.py:20-71
+    grid = MapfGrid(parse_map_file(_map('empty-8-8')))
+    env = MapfEnv(grid, 2, ((0, 0), (7, 7)), ((0, 2), (5, 7)), FAIL_PROB, REWARD_OF_CLASH, REWARD_OF_GOAL,
+                  REWARD_OF_LIVING, OptimizationCriteria.Makespan)
+    lts = env.locations_to_state
+    first = {((round(p, 2), c), ns, r, d) for ((p, c), ns, r, d) in env.P[env.s][vector_action_to_integer((RIGHT, UP))]}
+    assert first == {
+        ((0.64, False), lts(((0, 1), (6, 7))), REWARD_OF_LIVING, False), ((0.08, False), lts(((1, 0), (6, 7))), REWARD_OF_LIVING, False),
+        ((0.08, False), lts(((0, 0), (6, 7))), REWARD_OF_LIVING, False), ((0.08, False), lts(((0, 1), (7, 7))), REWARD_OF_LIVING, False),
+        ((0.08, False), lts(((0, 1), (7, 6))), REWARD_OF_LIVING, False), ((0.01, False), lts(((1, 0), (7, 7))), REWARD_OF_LIVING, False),
+        ((0.01, False), lts(((1, 0), (7, 6))), REWARD_OF_LIVING, False), ((0.01, False), lts(((0, 0), (7, 7))), REWARD_OF_LIVING, False),
+        ((0.01, False), lts(((0, 0), (7, 6))), REWARD_OF_LIVING, False)}
+    wish = lts(((0, 1), (6, 7)))
+    second = {((round(p, 2), c), ns, r, d) for ((p, c), ns, r, d) in env.P[wish][vector_action_to_integer((RIGHT, UP))]}
+    assert second == {
+        ((0.64, False), lts(((0, 2), (5, 7))), REWARD_OF_LIVING + REWARD_OF_GOAL, True),
+        ((0.08, False), lts(((1, 1), (5, 7))), REWARD_OF_LIVING, False), ((0.08, False), lts(((0, 1), (5, 7))), REWARD_OF_LIVING, False),
+        ((0.08, False), lts(((0, 2), (6, 7))), REWARD_OF_LIVING, False), ((0.08, False), lts(((0, 2), (6, 6))), REWARD_OF_LIVING, False),
+        ((0.01, False), lts(((1, 1), (6, 7))), REWARD_OF_LIVING, False), ((0.01, False), lts(((1, 1), (6, 6))), REWARD_OF_LIVING, False),
+        ((0.01, False), lts(((0, 1), (6, 7))), REWARD_OF_LIVING, False), ((0.01, False), lts(((0, 1), (6, 6))), REWARD_OF_LIVING, False)}
+
+
+@pytest.mark.gpu
+def test_colliding_agents_state_is_terminal_and_negative_reward():   # mapf_env_tests.py:73-90
+    grid = MapfGrid(parse_map_file(_map('empty-8-8')))
+    env = MapfEnv(grid, 2, ((0, 0), (0, 2)), ((7, 7), (5, 5)), FAIL_PROB, REWARD_OF_CLASH, REWARD_OF_GOAL,
+                  REWARD_OF_LIVING, OptimizationCriteria.Makespan)
+    tr = {((round(p, 2), c), ns, r, d) for ((p, c), ns, r, d) in env.P[env.s][vector_action_to_integer((RIGHT, LEFT))]}
+    assert ((0.64, True), env.locations_to_state(((0, 1), (0, 1))), REWARD_OF_LIVING + REWARD_OF_CLASH, True) in tr
+
+
+@pytest.mark.gpu
+def test_similar_transitions_probability_summed():          # mapf_env_tests.py:229-236
+    env = MapfEnv(MapfGrid(['..', '..']), 1, ((0, 0),), ((1, 1),), 0.1, REWARD_OF_CLASH, REWARD_OF_GOAL,
+                  REWARD_OF_LIVING, OptimizationCriteria.Makespan)
+    a = vector_action_to_integer((STAY, STAY))
+    assert env.P[env.s][a] == [((1, False), env.s, REWARD_OF_LIVING, False)]
