@@ -21,9 +21,9 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = uint64_t(0xD2511F53u) * c0;   // one v_mad_u64_u32 gives hi and lo
         const uint64_t p1 = uint64_t(0xCD9E8D57u) * c2;
-        c0 = uint32_t(p1 >> 32) ^ c1 ^ k0;
+        c0 = __builtin_amdgcn_bitop3_b32(uint32_t(p1 >> 32), c1, k0, 0x96);   // three-input xor in one VALU op
         c1 = uint32_t(p1);
-        c2 = uint32_t(p0 >> 32) ^ c3 ^ k1;
+        c2 = __builtin_amdgcn_bitop3_b32(uint32_t(p0 >> 32), c3, k1, 0x96);
         c3 = uint32_t(p0);
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
@@ -134,9 +134,11 @@ __device__ __forceinline__ Words4 slip_words(const EnvConsts &c, uint64_t env_id
 }
 
 // address of the move-table row; cells beyond V (only reachable through a corrupted state) are clamped
+template <bool CLAMP = true>
 __device__ __forceinline__ uint64_t move_entry(const uint64_t *__restrict__ mv, uint32_t n_cells, uint32_t cell,
                                                uint32_t action) {
-    const uint32_t c = cell < n_cells ? cell : n_cells - 1u;
+    // CLAMP = false only for an LDS-resident table: an out-of-range LDS read returns zeros instead of faulting
+    const uint32_t c = (!CLAMP || cell < n_cells) ? cell : n_cells - 1u;
     return mv[c * 5u + action];
 }
 

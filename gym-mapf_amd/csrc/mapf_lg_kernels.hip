@@ -40,9 +40,12 @@ struct LaneCtx {
 };
 
 // ------------------------------------------------------------------ cross-lane moves inside a group
+// Every control word used here (quad_perm, row_ror, row_mirror, row_half_mirror) reads a lane that exists
+// and all lanes are active at the call sites, so no `old` value is needed: mov_dpp is a single v_mov_b32_dpp
+// (update_dpp with old = 0 costs an extra v_mov per use).
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
-    return uint32_t(__builtin_amdgcn_update_dpp(0, int(v), CTRL, 0xF, 0xF, false));
+    return uint32_t(__builtin_amdgcn_mov_dpp(int(v), CTRL, 0xF, 0xF, true));
 }
 
 // value held by lane (g + S) mod L of my group
@@ -220,7 +223,7 @@ struct EnvOut {
 // One transition for the group's env.  cur0/cur1: my agents' cells (ghost slots hold 0).  Every lane of the
 // group returns the same per-env results; next0/next1 are this lane's.  KNOWN_TERM: the caller already knows
 // is_terminal(prev) (rollout carries it from step to step); otherwise it is derived here.
-template <int L, bool FULL, bool EXT_UNIFORMS, bool KNOWN_TERM>
+template <int L, bool FULL, bool EXT_UNIFORMS, bool KNOWN_TERM, bool MV_IN_LDS = false>
 __device__ __forceinline__ void lg_transition(const EnvConsts &c, const uint64_t *__restrict__ mv,
                                               const SlipRow *lds_slip, const LaneCtx<L> &x, uint32_t n_agents,
                                               uint32_t cur0, uint32_t cur1, uint32_t goal0, uint32_t goal1,
@@ -236,8 +239,8 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const uint64_t
         entry0 = uint64_t(cur0 + act0) | (uint64_t(cur0) << 16) | (uint64_t(cur0 ^ 1u) << 32);
         entry1 = uint64_t(cur1 + act1) | (uint64_t(cur1) << 16) | (uint64_t(cur1 ^ 1u) << 32);
     } else {
-        entry0 = move_entry(mv, c.n_cells, cur0, act0);
-        entry1 = move_entry(mv, c.n_cells, cur1, act1);
+        entry0 = move_entry<!MV_IN_LDS>(mv, c.n_cells, cur0, act0);
+        entry1 = move_entry<!MV_IN_LDS>(mv, c.n_cells, cur1, act1);
     }
     double q0, q1;
     if (EXT_UNIFORMS) {
@@ -525,7 +528,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
         STAMP(0);   // loop top: action fetch / policy / delayed stores
         // one slip-stream call serves two steps: refresh at even t (and at an odd first step)
         if (p.c.need_rng && ((t & 1u) == 0u || s == 0u)) rng = slip_words(p.c, env_id, t >> 1, x.g, 0u);
-        lg_transition<L, FULL, false, true>(p.c, mv, slip, x, n_agents, cur0, cur1, goal0, goal1, act0, act1, 0.0, 0.0,
+        lg_transition<L, FULL, false, true, MV_LDS>(p.c, mv, slip, x, n_agents, cur0, cur1, goal0, goal1, act0, act1, 0.0, 0.0,
                                             env_id, t, rng, terminal, next0, next1, o STAMP_ARG);
         STAMP(6);   // reward / selects
         ret = __dadd_rn(ret, o.reward);
