@@ -112,14 +112,15 @@ __device__ __forceinline__ void slip_move_hi(const SlipRow *lds_slip, uint64_t e
 #else
     const SlipRow &row = lds_slip[uint32_t(entry >> 48) & 7u];
 #endif
-    const double qa = row.q[0], qb = row.q[1], qc = row.q[2];
     const uint32_t t0 = row.th[0], t1 = row.th[1], t2 = row.th[2];
     const bool b0 = hi < t0, b1 = hi < t1, b2 = hi < t2;
     ambiguous = (hi == t0) | (hi == t1) | (hi == t2);
-    const bool pick1 = !b0 && b1, pick2 = !b0 && !b1 && b2;
+    const uint32_t idx = b0 ? 0u : (b1 ? 1u : (b2 ? 2u : 0u));
+    // list slot idx of the entry: cells sit at bit 16*idx; the probability is fetched by address (one ds_read_b64
+    // instead of reading all three and selecting 64-bit values in registers)
     const uint32_t lo = uint32_t(entry), up = uint32_t(entry >> 32);
-    next = pick2 ? (up & 0xFFFFu) : (pick1 ? (lo >> 16) : (lo & 0xFFFFu));
-    q = pick2 ? qc : (pick1 ? qb : qa);
+    next = ((idx == 2u ? up : lo) >> ((idx & 1u) * 16u)) & 0xFFFFu;
+    q = row.q[idx];
 }
 
 // The four words of the slip stream that serve agents (2*pair, 2*pair+1) at steps (2h, 2h+1):

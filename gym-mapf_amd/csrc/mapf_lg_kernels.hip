@@ -194,7 +194,10 @@ __device__ __forceinline__ bool lg_is_terminal(const LaneCtx<L> &x, uint32_t n_a
     return (flags & 1u) != 0u || (flags & 2u) == 0u;
 }
 
-// ordered product over agents 0..A-1 of the sampled probabilities (ghosts hold 1.0)
+// ordered product over agents 0..A-1 of the sampled probabilities (ghosts hold 1.0).  Groups inside a quad hand
+// the running product from lane k-1 to lane k (k rotations of one double); larger groups broadcast every lane's two
+// factors and multiply redundantly.  Either way the multiplications happen in agent order, so the result rounds
+// exactly like the reference's `total_prob *= p` (mapf_env.py:257).  The product ends up in every lane.
 template <int L, int K>
 struct ProbChain {
     static __device__ __forceinline__ double run(const LaneCtx<L> &x, double q0, double q1, double p) {
@@ -213,6 +216,30 @@ struct ProbChain {
         }
     }
 };
+
+template <int L>
+__device__ __forceinline__ double prob_product(const LaneCtx<L> &x, double q0, double q1) {
+    if constexpr (L == 1) {
+        return __dmul_rn(__dmul_rn(1.0, q0), q1);
+    } else if constexpr (L == 2 || L == 4) {
+        // stage k: lane k continues the product it receives from lane k-1; afterwards lane L-1 holds the total
+        double run = __dmul_rn(__dmul_rn(1.0, q0), q1);              // correct in lane 0
+        uint32_t g = x.g;
+        asm volatile("" : "+v"(g));     // keep the lane predicates below out of loop-invariant SGPR pairs
+#pragma unroll
+        for (int k = 1; k < L; ++k) {
+            // value of lane g-1 (rotation by L-1 brings lane g+L-1 = g-1 mod L)
+            const uint32_t lo = group_rot<L, L - 1>(uint32_t(__double2loint(run)), x);
+            const uint32_t hi = group_rot<L, L - 1>(uint32_t(__double2hiint(run)), x);
+            const double cont = __dmul_rn(__dmul_rn(__hiloint2double(int(hi), int(lo)), q0), q1);
+            run = (g == uint32_t(k)) ? cont : run;
+        }
+        // total sits in lane L-1: hand it to everyone
+        return group_bcast_f64<L, L - 1>(run, x);
+    } else {
+        return ProbChain<L, 0>::run(x, q0, q1, 1.0);
+    }
+}
 
 struct EnvOut {
     double reward, prob;
@@ -284,7 +311,7 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const uint64_t
 
     STAMP(4);   // flags + group reduce
     // --- total_prob: left-to-right product over agents 0..A-1 (ghosts contribute 1.0)
-    const double p = (MAPF_ABLATE & 2) ? __dmul_rn(q0, q1) : ProbChain<L, 0>::run(x, q0, q1, 1.0);
+    const double p = (MAPF_ABLATE & 2) ? __dmul_rn(q0, q1) : prob_product<L>(x, q0, q1);
 
     STAMP(5);   // prob chain
     // _living_reward: mapf_env.py:436-446
