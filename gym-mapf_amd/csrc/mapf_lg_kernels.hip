@@ -496,13 +496,18 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     bool terminal = lg_is_terminal<L, FULL>(x, n_agents, cur0, cur1, goal0, goal1);
     const bool start_terminal = p.auto_reset ? lg_is_terminal<L, FULL>(x, n_agents, start0, start1, goal0, goal1) : false;
 
-    // per-env totals: their addresses are parked in VGPRs so the three base pointers do not occupy SGPRs
-    // across the step loop (the loop already keeps ~100 scalars live)
-    double *ret_p = p.out_returns ? at(p.out_returns, e) : nullptr;
-    uint32_t *epi_p = p.out_episodes ? at(p.out_episodes, e) : nullptr;
-    uint32_t *col_p = p.out_collisions ? at(p.out_collisions, e) : nullptr;
-    uint8_t *done_base = RECORD ? p.rec_done : nullptr, *coll_base = RECORD ? p.rec_collision : nullptr;
-    double *reward_base = RECORD ? p.rec_reward : nullptr, *prob_base = RECORD ? p.rec_prob : nullptr;
+    // per-env totals and the scalar trajectory arrays: their addresses are parked in VGPRs so that seven base
+    // pointers do not occupy SGPRs across the step loop (it already keeps ~100 scalars live).  They stay typed as
+    // GLOBAL pointers: a generic pointer would turn the stores into flat_store, which also counts on lgkmcnt and
+    // would chain every LDS wait of the loop to the stores' completion.
+    using gf64 = __attribute__((address_space(1))) double *;
+    using gu32 = __attribute__((address_space(1))) uint32_t *;
+    using gu8 = __attribute__((address_space(1))) uint8_t *;
+    gf64 ret_p = (gf64)(p.out_returns ? at(p.out_returns, e) : nullptr);
+    gu32 epi_p = (gu32)(p.out_episodes ? at(p.out_episodes, e) : nullptr);
+    gu32 col_p = (gu32)(p.out_collisions ? at(p.out_collisions, e) : nullptr);
+    gu8 done_base = (gu8)(RECORD ? p.rec_done : nullptr), coll_base = (gu8)(RECORD ? p.rec_collision : nullptr);
+    gf64 reward_base = (gf64)(RECORD ? p.rec_reward : nullptr), prob_base = (gf64)(RECORD ? p.rec_prob : nullptr);
     asm volatile("" : "+v"(ret_p), "+v"(epi_p), "+v"(col_p), "+v"(done_base), "+v"(coll_base), "+v"(reward_base),
                  "+v"(prob_base));
     double ret = (p.accumulate && ret_p && leader) ? *ret_p : 0.0;
