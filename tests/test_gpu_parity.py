@@ -377,3 +377,40 @@ def test_transitions_random_queries_against_oracle(n_agents, criteria):
     assert np.array_equal(small['count'], res['count'])
     assert np.array_equal(small['next'][:, 0], res['next'][:, 0]) and np.array_equal(_bits(small['prob'][:, 0]), _bits(res['prob'][:, 0]))
     env.close()
+
+
+# ----------------------------------------------------------------------- edge cases of the boundary
+def test_empty_batch_and_single_cell_map():
+    """E = 0 handles are legal no-ops; a 1-cell map with one agent is terminal from the start (start == goal)."""
+    grid = MapfGrid(['..', '..'])
+    empty = VecMapfEnv(grid, 2, None, None, 0.2, -1.0, 1.0, -1.0, OptimizationCriteria.SoC,
+                       start_local=np.zeros((0, 2), np.uint16), goal_local=np.zeros((0, 2), np.uint16), n_envs=0)
+    local, reward, done, info = empty.step(np.zeros((0, 2), np.uint8), auto_reset=True)
+    assert local.shape == (0, 2) and reward.shape == (0,) and empty.t == 1
+    assert empty.rollout(5)['returns'].shape == (0,) and empty.t == 6
+    empty.reset(), empty.close()
+    one = VecMapfEnv(MapfGrid(['.']), 1, ((0, 0),), ((0, 0),), 0.3, -1.0, 1.0, -1.0, OptimizationCriteria.Makespan, n_envs=3)
+    local, reward, done, info = one.step(np.full((3, 1), 2, np.uint8))
+    assert np.all(info['was_terminal'] == 1) and np.all(reward == 0) and np.all(info['prob'] == 0) and np.all(done == 1)
+    one.close()
+
+
+def test_out_of_range_actions_are_stay_and_device_pointers_must_be_aligned():
+    import torch
+    grid = MapfGrid(['....', '....'])
+    kw = dict(start_local=np.array([[0, 5]], np.uint16).repeat(64, 0), goal_local=np.array([[7, 2]], np.uint16).repeat(64, 0))
+    a = VecMapfEnv(grid, 2, None, None, 0.2, -1.0, 1.0, -1.0, OptimizationCriteria.SoC, seed=3, **kw)
+    b = VecMapfEnv(grid, 2, None, None, 0.2, -1.0, 1.0, -1.0, OptimizationCriteria.SoC, seed=3, **kw)
+    la, ra, da, ia = a.step(np.full((64, 2), 200, np.uint8))              # garbage action values ...
+    lb, rb, db, ib = b.step(np.zeros((64, 2), np.uint8))                  # ... behave like STAY
+    assert np.array_equal(la, lb) and np.array_equal(_bits(ra), _bits(rb)) and np.array_equal(_bits(ia['prob']), _bits(ib['prob']))
+    a.close(), b.close()
+    dev = VecMapfEnv(grid, 2, None, None, 0.2, -1.0, 1.0, -1.0, OptimizationCriteria.SoC, device_arrays=True, **kw)
+    buf = torch.zeros(64 * 2 + 3, dtype=torch.uint8, device='cuda')
+    with pytest.raises(Exception) as err:
+        dev.step(buf[3:].view(64, 2))                                     # data_ptr() not 16-byte aligned
+    assert 'aligned' in str(err.value)
+    local, reward, done, info = dev.step(buf[:128].view(64, 2))
+    dev.sync()
+    assert local.shape == (64, 2) and bool((info['was_terminal'] == 0).all())
+    dev.close()
