@@ -80,11 +80,7 @@ __device__ __forceinline__ void stage_slip_table(const SlipRow *__restrict__ src
 template <bool EXT_UNIFORMS>
 __device__ __forceinline__ void slip_move(const SlipRow *lds_slip, uint64_t entry, uint64_t mant, double u,
                                           uint32_t &next, double &q) {
-#if defined(MAPF_ABLATE) && (MAPF_ABLATE & 8)
-    const SlipRow &row = lds_slip[0];
-#else
     const SlipRow &row = lds_slip[uint32_t(entry >> 48) & 7u];
-#endif
     // categorical_sample (call site mapf_env.py:255): (cumsum(p) > u).argmax(), all-False -> 0.
     // cum[k] > u  <=>  mant < ceil(cum[k] * 2^53) = thr[k]; rows shorter than 3 carry thr = 0 / cum = -inf.
     // The three candidate probabilities are fetched together with the thresholds (one LDS round trip) and the
@@ -107,11 +103,7 @@ __device__ __forceinline__ void slip_move(const SlipRow *lds_slip, uint64_t entr
 // with the full 53-bit mantissa.
 __device__ __forceinline__ void slip_move_hi(const SlipRow *lds_slip, uint64_t entry, uint32_t hi, uint32_t &next,
                                              double &q, bool &ambiguous) {
-#if defined(MAPF_ABLATE) && (MAPF_ABLATE & 8)
-    const SlipRow &row = lds_slip[0];
-#else
     const SlipRow &row = lds_slip[uint32_t(entry >> 48) & 7u];
-#endif
     const uint32_t t0 = row.th[0], t1 = row.th[1], t2 = row.th[2];
     const bool b0 = hi < t0, b1 = hi < t1, b2 = hi < t2;
     ambiguous = (hi == t0) | (hi == t1) | (hi == t2);

@@ -15,10 +15,6 @@
 #include "mapf_kernels.hpp"
 #include "mapf_device.hpp"
 
-#ifndef MAPF_ABLATE
-#define MAPF_ABLATE 0          // timing experiments only (scratch builds): bit 0 no Philox, 1 no prob chain,
-#endif                         // 2 no pair tests, 3 no slip LDS rows, 4 no move-table gather
-
 #ifdef MAPF_STAMPS   // diagnostic build only: per-segment cycle sums of the rollout loop (never shipped)
 struct StampCtx { unsigned long long seg[8]; unsigned long long last; };
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); st.seg[i] += _t - st.last; st.last = _t; } while (0)
@@ -261,14 +257,8 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const uint64_t
     const bool v0 = FULL || x.v0, v1 = FULL || x.v1;
 
     // --- my two agents' moves (computed even if the env turns out terminal; discarded then)
-    uint64_t entry0, entry1;
-    if (MAPF_ABLATE & 16) {
-        entry0 = uint64_t(cur0 + act0) | (uint64_t(cur0) << 16) | (uint64_t(cur0 ^ 1u) << 32);
-        entry1 = uint64_t(cur1 + act1) | (uint64_t(cur1) << 16) | (uint64_t(cur1 ^ 1u) << 32);
-    } else {
-        entry0 = move_entry<!MV_IN_LDS>(mv, c.n_cells, cur0, act0);
-        entry1 = move_entry<!MV_IN_LDS>(mv, c.n_cells, cur1, act1);
-    }
+    const uint64_t entry0 = move_entry<!MV_IN_LDS>(mv, c.n_cells, cur0, act0);
+    const uint64_t entry1 = move_entry<!MV_IN_LDS>(mv, c.n_cells, cur1, act1);
     double q0, q1;
     if (EXT_UNIFORMS) {
         slip_move<true>(lds_slip, entry0, 0, u0, next0, q0);
@@ -295,9 +285,7 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const uint64_t
 
     STAMP(2);   // slip_move (gather wait, LDS rows, sampling)
     // --- pair tests, then per-env facts: one flag word per lane, OR-reduced over the group
-    PairAcc acc;
-    if (MAPF_ABLATE & 4) { acc.vertex = next0 ^ next1; acc.swap = cur0 ^ next1; acc.dup = cur0 ^ cur1; }
-    else acc = pair_tests<L, FULL, !KNOWN_TERM, true>(x, n_agents, cur0, cur1, next0, next1);
+    const PairAcc acc = pair_tests<L, FULL, !KNOWN_TERM, true>(x, n_agents, cur0, cur1, next0, next1);
     STAMP(3);   // pair tests
     const bool off_goal_next = (v0 && next0 != goal0) || (v1 && next1 != goal1);
     uint32_t flags = (acc.vertex == 0u ? 1u : 0u) | (acc.swap == 0u ? 2u : 0u) | (off_goal_next ? 4u : 0u);
@@ -311,7 +299,7 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const uint64_t
 
     STAMP(4);   // flags + group reduce
     // --- total_prob: left-to-right product over agents 0..A-1 (ghosts contribute 1.0)
-    const double p = (MAPF_ABLATE & 2) ? __dmul_rn(q0, q1) : prob_product<L>(x, q0, q1);
+    const double p = prob_product<L>(x, q0, q1);
 
     STAMP(5);   // prob chain
     // _living_reward: mapf_env.py:436-446

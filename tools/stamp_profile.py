@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Where does a rollout step spend its cycles?  Runs the bench workload on the DIAGNOSTIC library
+(`make -C gym-mapf_amd/csrc stamps`, s_memtime stamps around the loop's segments; the segment sums overwrite the
+episode counters, so this build's outputs are not valid results) and prints median cycles per step and segment.
+
+    make -C gym-mapf_amd/csrc stamps
+    MAPF_HIP_LIB=gym-mapf_amd/csrc/build/libmapf_hip_stamps.so python tools/stamp_profile.py
+
+Stamps serialise the segments (a fence on each side), so read the SHARES, not the total (cdna_hip_programming.md
+section 7, in-kernel stamps).
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, 'gym-mapf_amd'), ROOT]
+import bench  # noqa: E402
+from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv  # noqa: E402
+
+if 'stamps' not in os.environ.get('MAPF_HIP_LIB', ''):
+    raise SystemExit('set MAPF_HIP_LIB to the stamps build (see the docstring)')
+E, A, T = 65536, 8, 64
+grid, nbr, start, goal = bench.workload_tables(E, 0)
+env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=42,
+                 device_arrays=True, start_local=start, goal_local=goal)
+actions = env.fill_random_actions(0, T)
+env.sync()
+names = ['loop top (actions, delayed stores)', 'slip-stream Philox (every 2nd step) + gather issue', 'sampling (LDS rows)', 'pair tests',
+         'flags + group reduce', 'probability product', 'reward / selects', 'reset handling']
+for acts, label in ((actions, 'streamed actions'), (None, 'in-kernel policy')):
+    for record in (True, False):
+        env.reset()
+        env.rollout(T, actions=acts, auto_reset=True, record=record)
+        res = env.rollout(T, actions=acts, auto_reset=True, record=record)
+        env.sync()
+        seg = res['episodes'].cpu().numpy().view(np.uint32).reshape(-1, 16)[:, :8].astype(np.float64) / T
+        med = np.median(seg, axis=0)
+        print('%s, record=%s: %d cycles per wave-step' % (label, record, med.sum()))
+        for n, m in zip(names, med):
+            print('    %-36s %6.0f  (%4.1f %%)' % (n, m, 100 * m / med.sum()))
