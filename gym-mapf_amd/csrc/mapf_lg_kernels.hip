@@ -15,6 +15,8 @@
 #include "mapf_kernels.hpp"
 #include "mapf_device.hpp"
 
+#include <cstdlib>
+
 #ifdef MAPF_STAMPS   // diagnostic build only: per-segment cycle sums of the rollout loop (never shipped)
 struct StampCtx { unsigned long long seg[8]; unsigned long long last; };
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); st.seg[i] += _t - st.last; st.last = _t; } while (0)
@@ -716,11 +718,21 @@ hipError_t launch_step_lg(int n_agents, const StepArgs &args, hipStream_t stream
 // LDS budget for the move table: the CU has 160 KiB; keep room for the slip rows
 static constexpr size_t kLdsBytes = 160 * 1024, kLdsReserve = 1024;
 
+// Largest move table that is staged into LDS (tuning knob: MAPF_MV_LDS_MAX_BYTES, default = what leaves room
+// for two resident blocks per CU; a table that allows only one block per CU starves the SIMDs of waves).
+static size_t mv_lds_limit() {
+    static const size_t limit = [] {
+        const char *e = getenv("MAPF_MV_LDS_MAX_BYTES");
+        return e ? size_t(strtoull(e, nullptr, 10)) : (kLdsBytes - kLdsReserve) / 2;
+    }();
+    return limit;
+}
+
 template <int L, bool FULL, bool RECORD, bool STREAM>
 static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, hipStream_t stream) {
     const size_t mv_bytes = size_t(args.c.n_cells) * 5 * sizeof(uint64_t);
     const uint64_t threads = args.n_envs * uint64_t(L);
-    if (mv_bytes + kLdsReserve <= kLdsBytes && threads >= 64 * 256) {
+    if (mv_bytes + kLdsReserve <= mv_lds_limit() && threads >= 64 * 256) {
         // block size: as many waves as can share one table copy while >= 16 waves stay resident per CU
         const size_t copies = (kLdsBytes - kLdsReserve) / (mv_bytes + sizeof(SlipRow) * 8);   // blocks per CU by LDS
         unsigned block = copies >= 4 ? 256u : (copies >= 2 ? 512u : 1024u);
