@@ -215,20 +215,27 @@ struct ProbChain {
     }
 };
 
+// value held by the previous lane of my group (meaningless in the group's first lane)
+template <int L>
+__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
+    if constexpr (L == 2) return dpp_mov<0xB1>(v);                 // quad_perm [1,0,3,2]
+    else if constexpr (L == 4) return dpp_mov<0x93>(v);            // quad_perm [3,0,1,2]
+    else return dpp_mov<0x121>(v);                                 // row_ror:1 -- lane i <- lane i-1 of the 16-lane row
+}
+
 template <int L>
 __device__ __forceinline__ double prob_product(const LaneCtx<L> &x, double q0, double q1) {
     if constexpr (L == 1) {
         return __dmul_rn(__dmul_rn(1.0, q0), q1);
-    } else if constexpr (L == 2 || L == 4) {
+    } else if constexpr (L <= 16) {
         // stage k: lane k continues the product it receives from lane k-1; afterwards lane L-1 holds the total
         double run = __dmul_rn(__dmul_rn(1.0, q0), q1);              // correct in lane 0
         uint32_t g = x.g;
         asm volatile("" : "+v"(g));     // keep the lane predicates below out of loop-invariant SGPR pairs
 #pragma unroll
         for (int k = 1; k < L; ++k) {
-            // value of lane g-1 (rotation by L-1 brings lane g+L-1 = g-1 mod L)
-            const uint32_t lo = group_rot<L, L - 1>(uint32_t(__double2loint(run)), x);
-            const uint32_t hi = group_rot<L, L - 1>(uint32_t(__double2hiint(run)), x);
+            const uint32_t lo = from_prev_lane<L>(uint32_t(__double2loint(run)));
+            const uint32_t hi = from_prev_lane<L>(uint32_t(__double2hiint(run)));
             const double cont = __dmul_rn(__dmul_rn(__hiloint2double(int(hi), int(lo)), q0), q1);
             run = (g == uint32_t(k)) ? cont : run;
         }
