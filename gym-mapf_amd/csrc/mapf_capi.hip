@@ -489,7 +489,7 @@ int mapf_transitions(mapf_handle_t h, uint64_t n_queries, const uint16_t *local,
     if (int rc = check_handle(h)) return rc;
     if (!local || !actions) return fail(MAPF_EINVAL, "local / actions are null");
     if (max_branches == 0) return fail(MAPF_EINVAL, "max_branches must be >= 1");
-    if (h->A > uint32_t(mapf::kTransitionsMaxAgents)) return fail(MAPF_EUNSUPPORTED, "mapf_transitions supports n_agents <= 16");
+    if (h->A > uint32_t(mapf::kTransitionsMaxAgents)) return fail(MAPF_EUNSUPPORTED, "mapf_transitions supports n_agents <= 8 (3^A branches per query)");
     const size_t N = size_t(n_queries), NA = N * h->A, NM = N * max_branches;
     if (!h->device_ptrs) {
         for (size_t i = 0; i < NA; ++i) if (local[i] >= h->V) return fail(MAPF_EINVAL, "transitions: cell out of range");

@@ -77,7 +77,7 @@ struct TransitionsArgs {
     uint32_t max_branches, n_agents;
     bool goal_broadcast;
 };
-constexpr int kTransitionsMaxAgents = 16;
+constexpr int kTransitionsMaxAgents = 8;    // 3^8 = 6561 branches per query; beyond that the enumeration is impractical
 hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream);
 
 hipError_t launch_step(int n_agents, const StepArgs &args, hipStream_t stream);

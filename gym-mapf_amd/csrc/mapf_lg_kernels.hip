@@ -1,396 +1,7 @@
-// Lane-group kernels: one env is stepped by L adjacent lanes of a wavefront, two agents per lane.
-//
-// Why: with one thread per env the pair tests and the slip logic of all A agents sit in one lane's
-// registers, so 65536 envs are only 1024 waves -- one per SIMD, no latency hiding, and at A = 32 the
-// register file overflows.  Here a 64-lane wave carries 64/L envs (L = pow2 >= ceil(A/2)); each lane
-// owns agents 2g and 2g+1 of its env (g = lane % L): one Philox4x32 call yields exactly its two
-// uniforms, its two cells travel as one packed dword, and the O(A^2) pair tests become L/2 rotations of
-// that dword inside the group (DPP quad_perm / row_ror where the group fits, ds_bpermute otherwise).
-// Per-env facts are combined with wave ballots; the float64 probability product is evaluated in agent
-// order so it rounds exactly like the reference's left-to-right `total_prob *= p` (mapf_env.py:257).
-// A is a run-time value: slots >= A are ghosts that never match anything, sit "on goal" and contribute a
-// factor 1.0; FULL specialisations (A == 2L) drop all ghost bookkeeping.
-//
-// Same semantics, arguments and outputs as step_kernel / rollout_kernel in mapf_kernels.hip.
-#include "mapf_kernels.hpp"
-#include "mapf_device.hpp"
-
-#include <cstdlib>
-
-#ifdef MAPF_STAMPS   // diagnostic build only: per-segment cycle sums of the rollout loop (never shipped)
-struct StampCtx { unsigned long long seg[8]; unsigned long long last; };
-#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); __builtin_amdgcn_sched_barrier(0); st.seg[i] += _t - st.last; st.last = _t; } while (0)
-#define STAMP_PARAM , StampCtx &st
-#define STAMP_ARG , st
-#else
-#define STAMP(i)
-#define STAMP_PARAM
-#define STAMP_ARG
-#endif
+// Lane-group family: single-step kernel, run-time-A helper kernels and their launchers (device code: mapf_lg.hpp).
+#include "mapf_lg.hpp"
 
 namespace mapf {
-
-template <int L>
-struct LaneCtx {
-    uint32_t lane, g, base;      // lane in wave, position in group, first lane of the group
-    uint32_t e;                  // env index (local to the handle)
-    bool v0, v1;                 // my two agent slots exist (2g < A, 2g+1 < A)
-};
-
-// ------------------------------------------------------------------ cross-lane moves inside a group
-// Every control word used here (quad_perm, row_ror, row_mirror, row_half_mirror) reads a lane that exists
-// and all lanes are active at the call sites, so no `old` value is needed: mov_dpp is a single v_mov_b32_dpp
-// (update_dpp with old = 0 costs an extra v_mov per use).
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
-    return uint32_t(__builtin_amdgcn_mov_dpp(int(v), CTRL, 0xF, 0xF, true));
-}
-
-// value held by lane (g + S) mod L of my group
-template <int L, int S>
-__device__ __forceinline__ uint32_t group_rot(uint32_t v, const LaneCtx<L> &x) {
-    static_assert(S >= 1 && S < (L > 1 ? L : 2), "rotation out of range");
-    if constexpr (L == 2) {
-        return dpp_mov<0xB1>(v);                                   // quad_perm [1,0,3,2]
-    } else if constexpr (L == 4) {
-        constexpr int ctrl = ((0 + S) & 3) | (((1 + S) & 3) << 2) | (((2 + S) & 3) << 4) | (((3 + S) & 3) << 6);
-        return dpp_mov<ctrl>(v);                                   // quad_perm rotation
-    } else if constexpr (L == 8) {
-        const uint32_t fwd = dpp_mov<0x120 + (16 - S)>(v);         // row_ror: lane i <- lane (i + S) mod 16
-        const uint32_t wrap = dpp_mov<0x120 + (8 - S)>(v);         //          lane i <- lane (i + S - 8) mod 16
-        uint32_t g = x.g;
-        asm volatile("" : "+v"(g));                                // recompute the predicate here: hoisting it out
-        return (g + uint32_t(S) < 8u) ? fwd : wrap;                // of the step loop costs an SGPR pair per round
-    } else if constexpr (L == 16) {
-        return dpp_mov<0x120 + (16 - S)>(v);
-    } else {
-        return uint32_t(__shfl(int(v), int(x.base + ((x.g + uint32_t(S)) & uint32_t(L - 1))), 64));
-    }
-}
-
-// value held by lane K of my group
-template <int L, int K>
-__device__ __forceinline__ uint32_t group_bcast(uint32_t v, const LaneCtx<L> &x) {
-    if constexpr (L == 1) {
-        return v;
-    } else if constexpr (L == 2) {
-        return dpp_mov<(K == 0 ? 0xA0 : 0xF5)>(v);                 // quad_perm [K,K,K+2,K+2]
-    } else if constexpr (L == 4) {
-        return dpp_mov<K * 0x55>(v);                               // quad_perm [K,K,K,K]
-    } else {
-        return uint32_t(__shfl(int(v), int(x.base) + K, 64));
-    }
-}
-
-template <int L, int K>
-__device__ __forceinline__ double group_bcast_f64(double v, const LaneCtx<L> &x) {
-    const uint32_t lo = group_bcast<L, K>(uint32_t(__double2loint(v)), x);
-    const uint32_t hi = group_bcast<L, K>(uint32_t(__double2hiint(v)), x);
-    return __hiloint2double(int(hi), int(lo));
-}
-
-// OR / sum of a per-lane word over my group, result in every lane.  Butterfly of DPP steps inside a 16-lane
-// row (pairs, quads, half-row mirror, row mirror); ds_bpermute xor-partners beyond a row.
-template <int L, bool ADD>
-__device__ __forceinline__ uint32_t group_reduce(uint32_t v, const LaneCtx<L> &x) {
-    auto comb = [](uint32_t a, uint32_t b) { return ADD ? a + b : (a | b); };
-    if constexpr (L >= 2) v = comb(v, dpp_mov<0xB1>(v));           // quad_perm [1,0,3,2]
-    if constexpr (L >= 4) v = comb(v, dpp_mov<0x4E>(v));           // quad_perm [2,3,0,1]
-    if constexpr (L >= 8) v = comb(v, dpp_mov<0x141>(v));          // row_half_mirror
-    if constexpr (L >= 16) v = comb(v, dpp_mov<0x140>(v));         // row_mirror
-    if constexpr (L >= 32) v = comb(v, uint32_t(__shfl_xor(int(v), 16, 64)));
-    if constexpr (L >= 64) v = comb(v, uint32_t(__shfl_xor(int(v), 32, 64)));
-    return v;
-}
-
-// ------------------------------------------------------------------ pair tests
-// min over agent pairs of xor (0 <=> equal).  dup: prev_i == prev_j (is_terminal, mapf_env.py:210-223);
-// vertex: next_i == next_j; swap: prev_i == next_j and prev_j == next_i (mapf_env.py:378-389).
-struct PairAcc {
-    uint32_t dup = 0xFFFFFFFFu, vertex = 0xFFFFFFFFu, swap = 0xFFFFFFFFu;
-};
-
-// one rotation step: my two agents against the two agents of group position `og`, whose packed cells
-// arrive in o_prev / o_next
-template <int L, bool FULL, bool DUP, bool MOVES>
-__device__ __forceinline__ void pair_apply(const LaneCtx<L> &x, uint32_t n_agents, uint32_t cur0, uint32_t cur1,
-                                           uint32_t next0, uint32_t next1, uint32_t o_prev, uint32_t o_next,
-                                           uint32_t og, PairAcc &acc) {
-    const uint32_t op0 = o_prev & 0xFFFFu, op1 = o_prev >> 16;
-    uint32_t g0 = 0u, g1 = 0u, g2 = 0u, g3 = 0u;    // ghost masks: 1 forces "different"
-    if (!FULL) {
-        const bool o0 = 2u * og < n_agents, o1 = 2u * og + 1u < n_agents;
-        g0 = (x.v0 && o0) ? 0u : 1u; g1 = (x.v0 && o1) ? 0u : 1u;
-        g2 = (x.v1 && o0) ? 0u : 1u; g3 = (x.v1 && o1) ? 0u : 1u;
-    }
-    if (DUP) {
-        acc.dup = min(acc.dup, min((cur0 ^ op0) | g0, (cur0 ^ op1) | g1));
-        acc.dup = min(acc.dup, min((cur1 ^ op0) | g2, (cur1 ^ op1) | g3));
-    }
-    if (MOVES) {
-        const uint32_t on0 = o_next & 0xFFFFu, on1 = o_next >> 16;
-        const uint32_t fwd0 = cur0 | (next0 << 16), fwd1 = cur1 | (next1 << 16);
-        // rev_k = next_k | prev_k << 16 of the other lane: one v_perm_b32 each from the two packed words
-        const uint32_t rev0 = __builtin_amdgcn_perm(o_prev, o_next, 0x05040100u);
-        const uint32_t rev1 = __builtin_amdgcn_perm(o_prev, o_next, 0x07060302u);
-        acc.vertex = min(acc.vertex, min((next0 ^ on0) | g0, (next0 ^ on1) | g1));
-        acc.vertex = min(acc.vertex, min((next1 ^ on0) | g2, (next1 ^ on1) | g3));
-        acc.swap = min(acc.swap, min((fwd0 ^ rev0) | g0, (fwd0 ^ rev1) | g1));
-        acc.swap = min(acc.swap, min((fwd1 ^ rev0) | g2, (fwd1 ^ rev1) | g3));
-    }
-}
-
-// rotations 1..L/2: unrolled with DPP moves for groups up to 16 lanes, a rolled ds_bpermute loop beyond
-// (32 unrolled rounds would cost hundreds of registers for no gain)
-template <int L, int S, bool FULL, bool DUP, bool MOVES>
-struct PairRounds {
-    static __device__ __forceinline__ void run(const LaneCtx<L> &x, uint32_t n_agents, uint32_t cur0, uint32_t cur1,
-                                               uint32_t next0, uint32_t next1, uint32_t pk_prev, uint32_t pk_next,
-                                               PairAcc &acc) {
-        if constexpr (L >= 32) {
-#pragma unroll 2
-            for (uint32_t s = 1; s <= uint32_t(L / 2); ++s) {
-                const uint32_t og = (x.g + s) & uint32_t(L - 1);
-                const int src = int(x.base + og);
-                const uint32_t o_prev = uint32_t(__shfl(int(pk_prev), src, 64));
-                const uint32_t o_next = MOVES ? uint32_t(__shfl(int(pk_next), src, 64)) : 0u;
-                pair_apply<L, FULL, DUP, MOVES>(x, n_agents, cur0, cur1, next0, next1, o_prev, o_next, og, acc);
-            }
-        } else if constexpr (S <= L / 2 && L > 1) {
-            const uint32_t o_prev = group_rot<L, S>(pk_prev, x);
-            const uint32_t o_next = MOVES ? group_rot<L, S>(pk_next, x) : 0u;
-            pair_apply<L, FULL, DUP, MOVES>(x, n_agents, cur0, cur1, next0, next1, o_prev, o_next,
-                                            (x.g + uint32_t(S)) & uint32_t(L - 1), acc);
-            PairRounds<L, S + 1, FULL, DUP, MOVES>::run(x, n_agents, cur0, cur1, next0, next1, pk_prev, pk_next, acc);
-        }
-    }
-};
-
-// all pairs of the env: my own two agents, then rotations 1..L/2 (every unordered lane pair is met)
-template <int L, bool FULL, bool DUP, bool MOVES>
-__device__ __forceinline__ PairAcc pair_tests(const LaneCtx<L> &x, uint32_t n_agents, uint32_t cur0, uint32_t cur1,
-                                              uint32_t next0, uint32_t next1) {
-    PairAcc acc;
-    const uint32_t ghost = (FULL || x.v1) ? 0u : 1u;
-    if (DUP) acc.dup = (cur0 ^ cur1) | ghost;
-    if (MOVES) {
-        acc.vertex = (next0 ^ next1) | ghost;
-        acc.swap = ((cur0 | (next0 << 16)) ^ (next1 | (cur1 << 16))) | ghost;
-    }
-    PairRounds<L, 1, FULL, DUP, MOVES>::run(x, n_agents, cur0, cur1, next0, next1, cur0 | (cur1 << 16),
-                                             next0 | (next1 << 16), acc);
-    return acc;
-}
-
-// MapfEnv.is_terminal (mapf_env.py:210-223) of the group's env
-template <int L, bool FULL>
-__device__ __forceinline__ bool lg_is_terminal(const LaneCtx<L> &x, uint32_t n_agents, uint32_t cur0, uint32_t cur1,
-                                               uint32_t goal0, uint32_t goal1) {
-    const PairAcc acc = pair_tests<L, FULL, true, false>(x, n_agents, cur0, cur1, 0u, 0u);
-    const bool off_goal = ((FULL || x.v0) && cur0 != goal0) || ((FULL || x.v1) && cur1 != goal1);
-    const uint32_t flags = group_reduce<L, false>((acc.dup == 0u ? 1u : 0u) | (off_goal ? 2u : 0u), x);
-    return (flags & 1u) != 0u || (flags & 2u) == 0u;
-}
-
-// ordered product over agents 0..A-1 of the sampled probabilities (ghosts hold 1.0).  Groups inside a quad hand
-// the running product from lane k-1 to lane k (k rotations of one double); larger groups broadcast every lane's two
-// factors and multiply redundantly.  Either way the multiplications happen in agent order, so the result rounds
-// exactly like the reference's `total_prob *= p` (mapf_env.py:257).  The product ends up in every lane.
-template <int L, int K>
-struct ProbChain {
-    static __device__ __forceinline__ double run(const LaneCtx<L> &x, double q0, double q1, double p) {
-        if constexpr (L >= 32) {
-#pragma unroll 4
-            for (int k = 0; k < L; ++k) {
-                const double a = __shfl(q0, int(x.base) + k, 64), b = __shfl(q1, int(x.base) + k, 64);
-                p = __dmul_rn(__dmul_rn(p, a), b);
-            }
-            return p;
-        } else if constexpr (K < L) {
-            const double a = group_bcast_f64<L, K>(q0, x), b = group_bcast_f64<L, K>(q1, x);
-            return ProbChain<L, K + 1>::run(x, q0, q1, __dmul_rn(__dmul_rn(p, a), b));
-        } else {
-            return p;
-        }
-    }
-};
-
-// value held by the previous lane of my group (meaningless in the group's first lane)
-template <int L>
-__device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
-    if constexpr (L == 2) return dpp_mov<0xB1>(v);                 // quad_perm [1,0,3,2]
-    else if constexpr (L == 4) return dpp_mov<0x93>(v);            // quad_perm [3,0,1,2]
-    else return dpp_mov<0x121>(v);                                 // row_ror:1 -- lane i <- lane i-1 of the 16-lane row
-}
-
-template <int L>
-__device__ __forceinline__ double prob_product(const LaneCtx<L> &x, double q0, double q1) {
-    if constexpr (L == 1) {
-        return __dmul_rn(__dmul_rn(1.0, q0), q1);
-    } else if constexpr (L <= 16) {
-        // stage k: lane k continues the product it receives from lane k-1; afterwards lane L-1 holds the total
-        double run = __dmul_rn(__dmul_rn(1.0, q0), q1);              // correct in lane 0
-        uint32_t g = x.g;
-        asm volatile("" : "+v"(g));     // keep the lane predicates below out of loop-invariant SGPR pairs
-#pragma unroll
-        for (int k = 1; k < L; ++k) {
-            const uint32_t lo = from_prev_lane<L>(uint32_t(__double2loint(run)));
-            const uint32_t hi = from_prev_lane<L>(uint32_t(__double2hiint(run)));
-            const double cont = __dmul_rn(__dmul_rn(__hiloint2double(int(hi), int(lo)), q0), q1);
-            run = (g == uint32_t(k)) ? cont : run;
-        }
-        // total sits in lane L-1: hand it to everyone
-        return group_bcast_f64<L, L - 1>(run, x);
-    } else {
-        return ProbChain<L, 0>::run(x, q0, q1, 1.0);
-    }
-}
-
-struct EnvOut {
-    double reward, prob;
-    bool done, collision, was_terminal;
-    bool next_terminal;          // is_terminal of the state step() returned (used by the rollout loop)
-};
-
-// One transition for the group's env.  cur0/cur1: my agents' cells (ghost slots hold 0).  Every lane of the
-// group returns the same per-env results; next0/next1 are this lane's.  KNOWN_TERM: the caller already knows
-// is_terminal(prev) (rollout carries it from step to step); otherwise it is derived here.
-template <int L, bool FULL, bool EXT_UNIFORMS, bool KNOWN_TERM, bool MV_IN_LDS = false>
-__device__ __forceinline__ void lg_transition(const EnvConsts &c, const uint64_t *__restrict__ mv,
-                                              const SlipRow *lds_slip, const LaneCtx<L> &x, uint32_t n_agents,
-                                              uint32_t cur0, uint32_t cur1, uint32_t goal0, uint32_t goal1,
-                                              uint32_t act0_in, uint32_t act1_in, double u0, double u1,
-                                              uint64_t env_id, uint64_t t, const Words4 rng, bool prev_terminal,
-                                              uint32_t &next0, uint32_t &next1, EnvOut &out STAMP_PARAM) {
-    const uint32_t act0 = act0_in > 4u ? 0u : act0_in, act1 = act1_in > 4u ? 0u : act1_in;
-    const bool v0 = FULL || x.v0, v1 = FULL || x.v1;
-
-    // --- my two agents' moves (computed even if the env turns out terminal; discarded then)
-    const uint64_t entry0 = move_entry<!MV_IN_LDS>(mv, c.n_cells, cur0, act0);
-    const uint64_t entry1 = move_entry<!MV_IN_LDS>(mv, c.n_cells, cur1, act1);
-    double q0, q1;
-    if (EXT_UNIFORMS) {
-        slip_move<true>(lds_slip, entry0, 0, u0, next0, q0);
-        slip_move<true>(lds_slip, entry1, 0, u1, next1, q1);
-    } else {
-        // words of this step: 2*(t&1) and 2*(t&1)+1 of the call shared by steps 2h and 2h+1
-        const bool odd = (t & 1u) != 0u;
-        const uint32_t hi0 = (odd ? rng.w2 : rng.w0) >> 5, hi1 = (odd ? rng.w3 : rng.w1) >> 5;
-        STAMP(1);   // philox + gather issue
-        bool amb0, amb1;
-        slip_move_hi(lds_slip, entry0, hi0, next0, q0, amb0);
-        slip_move_hi(lds_slip, entry1, hi1, next1, q1, amb1);
-        if (__builtin_expect(__any((amb0 || amb1) && c.need_rng), 0)) {
-            // a top-27-bit tie somewhere in the wave (~2^-25 per agent-step): redo with all 53 bits
-            const Words4 wr = slip_words(c, env_id, t >> 1, x.g, 1u);
-            const uint64_t mant0 = (uint64_t(hi0) << 26) | uint64_t((odd ? wr.w2 : wr.w0) >> 6);
-            const uint64_t mant1 = (uint64_t(hi1) << 26) | uint64_t((odd ? wr.w3 : wr.w1) >> 6);
-            slip_move<false>(lds_slip, entry0, mant0, 0.0, next0, q0);
-            slip_move<false>(lds_slip, entry1, mant1, 0.0, next1, q1);
-        }
-    }
-    if (!v0) { next0 = cur0; q0 = 1.0; }
-    if (!v1) { next1 = cur1; q1 = 1.0; }
-
-    STAMP(2);   // slip_move (gather wait, LDS rows, sampling)
-    // --- pair tests, then per-env facts: one flag word per lane, OR-reduced over the group
-    const PairAcc acc = pair_tests<L, FULL, !KNOWN_TERM, true>(x, n_agents, cur0, cur1, next0, next1);
-    STAMP(3);   // pair tests
-    const bool off_goal_next = (v0 && next0 != goal0) || (v1 && next1 != goal1);
-    uint32_t flags = (acc.vertex == 0u ? 1u : 0u) | (acc.swap == 0u ? 2u : 0u) | (off_goal_next ? 4u : 0u);
-    if (!KNOWN_TERM) {
-        const bool off_goal = (v0 && cur0 != goal0) || (v1 && cur1 != goal1);
-        flags |= (acc.dup == 0u ? 8u : 0u) | (off_goal ? 16u : 0u);
-    }
-    flags = group_reduce<L, false>(flags, x);
-    bool was_terminal = prev_terminal;
-    if (!KNOWN_TERM) was_terminal = (flags & 8u) != 0u || (flags & 16u) == 0u;
-
-    STAMP(4);   // flags + group reduce
-    // --- total_prob: left-to-right product over agents 0..A-1 (ghosts contribute 1.0)
-    const double p = prob_product<L>(x, q0, q1);
-
-    STAMP(5);   // prob chain
-    // _living_reward: mapf_env.py:436-446
-    double living = c.r_living;
-    if (c.criteria == 1u) {
-        const uint32_t mine = ((v0 && cur0 == goal0 && act0 == 0u) ? 1u : 0u) + ((v1 && cur1 == goal1 && act1 == 0u) ? 1u : 0u);
-        const int stayed = int(group_reduce<L, true>(mine, x));
-        living = __dmul_rn(double(int(n_agents) - stayed), c.r_living);
-    }
-    // calc_transition_reward_from_local_states: mapf_env.py:225-235 (collision before goal)
-    const bool vertex = (flags & 1u) != 0u, coll = (flags & 3u) != 0u, goal_next = (flags & 4u) == 0u;
-    out.was_terminal = was_terminal;
-    if (was_terminal) {   // mapf_env.py:239-240 -- (s, 0, True, {"prob": 0}), nothing drawn
-        next0 = cur0; next1 = cur1;
-        out.reward = 0.0; out.prob = 0.0; out.done = true; out.collision = false;
-        out.next_terminal = true;
-    } else {
-        out.prob = p;
-        out.collision = coll;
-        out.done = coll || goal_next;
-        out.reward = coll ? __dadd_rn(c.r_clash, living) : (goal_next ? __dadd_rn(c.r_goal, living) : living);
-        out.next_terminal = vertex || goal_next;   // a swap leaves a non-terminal state (mapf_env.py:210-223)
-    }
-}
-
-// ---- memory access.  All element indices are 32-bit and turned into 32-bit BYTE offsets from a uniform base
-// pointer, so every access uses the SGPR-base + VGPR-offset addressing form (no 64-bit address arithmetic per
-// lane).  The C ABI rejects calls whose largest array would exceed 4 GiB (mapf_capi.hip: check_extent).
-template <typename T>
-__device__ __forceinline__ const T *at(const T *base, uint32_t index) {
-    return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + index * uint32_t(sizeof(T)));
-}
-template <typename T>
-__device__ __forceinline__ T *at(T *base, uint32_t index) {
-    return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + index * uint32_t(sizeof(T)));
-}
-
-// A lane's two slots of row `row`.  A even: one dword (cells) / one short (actions) per lane, fully coalesced
-// (4 B x 64 lanes).
-template <typename T>
-__device__ __forceinline__ void load_pair(const T *base, uint32_t row, uint32_t n_agents, uint32_t g, bool v0, bool v1,
-                                          uint32_t &a, uint32_t &b) {
-    const T *p = at(base, row * n_agents + 2u * g);
-    a = 0u; b = 0u;
-    if ((n_agents & 1u) == 0u) {
-        if (v0) {
-            if (sizeof(T) == 2) { const uint32_t w = *reinterpret_cast<const uint32_t *>(p); a = w & 0xFFFFu; b = w >> 16; }
-            else { const uint32_t w = *reinterpret_cast<const uint16_t *>(p); a = w & 0xFFu; b = w >> 8; }
-        }
-    } else {
-        if (v0) a = p[0];
-        if (v1) b = p[1];
-    }
-}
-
-template <bool EVEN = false>
-__device__ __forceinline__ void store_cells(uint16_t *base, uint32_t row, uint32_t n_agents, uint32_t g, bool v0, bool v1,
-                                            uint32_t a, uint32_t b) {
-    uint16_t *p = at(base, row * n_agents + 2u * g);
-    if (EVEN || (n_agents & 1u) == 0u) {
-        if (v0) *reinterpret_cast<uint32_t *>(p) = a | (b << 16);
-    } else {
-        if (v0) p[0] = uint16_t(a);
-        if (v1) p[1] = uint16_t(b);
-    }
-}
-
-template <int L>
-__device__ __forceinline__ LaneCtx<L> lane_ctx(uint32_t n_agents, uint64_t n_envs, bool &live) {
-    LaneCtx<L> x;
-    x.lane = threadIdx.x & 63u;
-    x.g = x.lane & uint32_t(L - 1);
-    x.base = x.lane & ~uint32_t(L - 1);
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    x.e = wave * uint32_t(64 / L) + (x.lane / uint32_t(L));
-    // envs past the end keep their lanes alive (cross-lane moves are wave-wide) but own no agents
-    live = x.e < uint32_t(n_envs);
-    x.v0 = live && 2u * x.g < n_agents;
-    x.v1 = live && 2u * x.g + 1u < n_agents;
-    if (!live) x.e = 0;
-    return x;
-}
 
 template <int L, bool FULL, bool EXT_UNIFORMS>
 __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const uint32_t n_agents) {
@@ -437,163 +48,6 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
         store_cells(p.state, e, n_agents, x.g, x.v0, x.v1, s0, s1);
     } else if (!o.was_terminal) {
         store_cells(p.state, e, n_agents, x.g, x.v0, x.v1, next0, next1);
-    }
-}
-
-// Largest block a rollout kernel may be launched with: groups of 16 lanes unroll 8 rotation rounds and need more
-// than the 128 registers a 1024-thread block leaves per lane.
-template <int L> constexpr unsigned rollout_max_block() { return L == 16 ? 512u : 1024u; }
-
-// raw (still packed) action bytes of a lane's two slots: byte 0 = agent 2g, byte 1 = agent 2g+1.  Kept packed so
-// that a prefetch issued one step ahead is not forced to complete by an unpack.
-template <bool EVEN>
-__device__ __forceinline__ uint32_t load_actions_raw(const uint8_t *base, uint32_t row, uint32_t n_agents, uint32_t g,
-                                                     bool v0, bool v1) {
-    const uint8_t *p = at(base, row * n_agents + 2u * g);
-    uint32_t raw = 0u;
-    if (EVEN || (n_agents & 1u) == 0u) {
-        if (v0) raw = *reinterpret_cast<const uint16_t *>(p);
-    } else {
-        uint32_t lo = 0u, hi = 0u;
-        if (v0) lo = p[0];
-        if (v1) hi = p[1];
-        raw = lo | (hi << 8);
-    }
-    return raw;
-}
-
-// MV_LDS: the whole move table (V*5 entries of 8 B) is staged into LDS once per block and the two gathers of
-// every step become ds_read_b64 (a random 64-lane gather through the vector-memory pipe touches up to 64 cache
-// lines).  RECORD: all five trajectory arrays are written every step (the C ABI substitutes scratch for absent
-// ones), STREAM: actions come from memory, else from the in-kernel policy stream.  Both are compile-time so the
-// loop body has no branches around its memory operations: the compiler can then wait for the action word that
-// was prefetched one step ahead with a counted vmcnt(N) instead of draining every store (vmcnt(0)).  Start
-// cells stay in two registers per lane, so an auto-reset touches no memory.
-template <int L, bool FULL, bool MV_LDS, bool RECORD, bool STREAM>
-__global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
-    __shared__ SlipRow slip[8];
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds_mv[];
-    bool live;
-    const LaneCtx<L> x = lane_ctx<L>(n_agents, p.n_envs, live);
-    const uint32_t e = x.e;
-    const bool leader = live && x.g == 0u;
-
-    uint32_t cur0, cur1, goal0, goal1, start0 = 0u, start1 = 0u;
-    load_pair<uint16_t>(p.state, e, n_agents, x.g, x.v0, x.v1, cur0, cur1);
-    load_pair<uint16_t>(p.goal, p.goal_broadcast ? 0 : e, n_agents, x.g, x.v0, x.v1, goal0, goal1);
-    if (p.auto_reset) load_pair<uint16_t>(p.start, p.start_broadcast ? 0 : e, n_agents, x.g, x.v0, x.v1, start0, start1);
-    if (MV_LDS) {
-        const uint32_t n_words = p.c.n_cells * 5u;
-        for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) lds_mv[w] = p.mv[w];
-    }
-    stage_slip_table(p.slip, slip);   // ends with __syncthreads()
-    const uint64_t *mv = MV_LDS ? lds_mv : p.mv;
-
-    // is_terminal is carried from step to step instead of re-deriving it from the cells every step
-    bool terminal = lg_is_terminal<L, FULL>(x, n_agents, cur0, cur1, goal0, goal1);
-    const bool start_terminal = p.auto_reset ? lg_is_terminal<L, FULL>(x, n_agents, start0, start1, goal0, goal1) : false;
-
-    // per-env totals and the scalar trajectory arrays: their addresses are parked in VGPRs so that seven base
-    // pointers do not occupy SGPRs across the step loop (it already keeps ~100 scalars live).  They stay typed as
-    // GLOBAL pointers: a generic pointer would turn the stores into flat_store, which also counts on lgkmcnt and
-    // would chain every LDS wait of the loop to the stores' completion.
-    using gf64 = __attribute__((address_space(1))) double *;
-    using gu32 = __attribute__((address_space(1))) uint32_t *;
-    using gu8 = __attribute__((address_space(1))) uint8_t *;
-    gf64 ret_p = (gf64)(p.out_returns ? at(p.out_returns, e) : nullptr);
-    gu32 epi_p = (gu32)(p.out_episodes ? at(p.out_episodes, e) : nullptr);
-    gu32 col_p = (gu32)(p.out_collisions ? at(p.out_collisions, e) : nullptr);
-    gu8 done_base = (gu8)(RECORD ? p.rec_done : nullptr), coll_base = (gu8)(RECORD ? p.rec_collision : nullptr);
-    gf64 reward_base = (gf64)(RECORD ? p.rec_reward : nullptr), prob_base = (gf64)(RECORD ? p.rec_prob : nullptr);
-    asm volatile("" : "+v"(ret_p), "+v"(epi_p), "+v"(col_p), "+v"(done_base), "+v"(coll_base), "+v"(reward_base),
-                 "+v"(prob_base));
-    double ret = (p.accumulate && ret_p && leader) ? *ret_p : 0.0;
-    uint32_t episodes = (p.accumulate && epi_p && leader) ? *epi_p : 0u;
-    uint32_t collisions = (p.accumulate && col_p && leader) ? *col_p : 0u;
-    const uint64_t env_id = p.env_id_offset + e;
-    const uint32_t n_envs = uint32_t(p.n_envs);
-
-#ifdef MAPF_STAMPS
-    StampCtx st{};
-    { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); st.last = _t; }
-#endif
-    // Software pipeline of the loop's memory operations.  The compiler waits for the prefetched action word with
-    // vmcnt(0), i.e. for EVERYTHING outstanding, so each iteration is ordered: (1) use the word loaded one
-    // iteration ago, (2) only then issue the next load and the PREVIOUS step's trajectory stores, (3) compute.
-    // Whatever the wait at (1) sees was issued a whole transition earlier and has long completed.
-    uint32_t raw = 0u;
-    if (STREAM && p.n_steps > 0) raw = load_actions_raw<FULL>(p.actions, e, n_agents, x.g, x.v0, x.v1);
-    Words4 rng{0u, 0u, 0u, 0u};
-    uint32_t d_next0 = 0u, d_next1 = 0u, d_row = 0u, d_flags = 0u;   // step s-1's results, stored during step s
-    double d_reward = 0.0, d_prob = 0.0;
-
-    for (uint32_t s = 0; s < p.n_steps; ++s) {
-        const uint64_t t = p.t + s;
-        const uint32_t row = s * n_envs + e;
-        uint32_t act0, act1;
-        if (STREAM) {
-            act0 = raw & 0xFFu; act1 = raw >> 8;
-            asm volatile("" : "+v"(act0), "+v"(act1));       // (1) pins the wait for `raw` here, ahead of (2)
-            if (s + 1 < p.n_steps) raw = load_actions_raw<FULL>(p.actions, row + n_envs, n_agents, x.g, x.v0, x.v1);
-        } else {   // policy stream: one Philox call covers agents 4q..4q+3; this lane needs words 2(g&1), 2(g&1)+1
-            uint32_t w[4];
-            const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | ((x.g >> 1) << 24);
-            philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, p.c.pol_lo, p.c.pol_hi, w);
-            const bool hi = (x.g & 1u) != 0u;
-            act0 = __umulhi(hi ? w[2] : w[0], 5u);
-            act1 = __umulhi(hi ? w[3] : w[1], 5u);
-        }
-        if (RECORD && s > 0) {                               // (2) the previous step's outputs
-            if (live) store_cells<FULL>(p.rec_local, d_row, n_agents, x.g, x.v0, x.v1, d_next0, d_next1);
-            if (leader) {
-                reward_base[d_row] = d_reward;
-                prob_base[d_row] = d_prob;
-                done_base[d_row] = uint8_t(d_flags & 1u);
-                coll_base[d_row] = uint8_t(d_flags >> 1);
-            }
-        }
-        uint32_t next0, next1;
-        EnvOut o;
-        STAMP(0);   // loop top: action fetch / policy / delayed stores
-        // one slip-stream call serves two steps: refresh at even t (and at an odd first step)
-        if (p.c.need_rng && ((t & 1u) == 0u || s == 0u)) rng = slip_words(p.c, env_id, t >> 1, x.g, 0u);
-        lg_transition<L, FULL, false, true, MV_LDS>(p.c, mv, slip, x, n_agents, cur0, cur1, goal0, goal1, act0, act1, 0.0, 0.0,
-                                            env_id, t, rng, terminal, next0, next1, o STAMP_ARG);
-        STAMP(6);   // reward / selects
-        ret = __dadd_rn(ret, o.reward);
-        episodes += o.done ? 1u : 0u;
-        collisions += o.collision ? 1u : 0u;
-        if (RECORD) {
-            d_next0 = next0; d_next1 = next1; d_row = row; d_reward = o.reward; d_prob = o.prob;
-            d_flags = (o.done ? 1u : 0u) | (o.collision ? 2u : 0u);
-        }
-        const bool back = p.auto_reset && o.done;          // MapfEnv.reset(): start cells, no reseed
-        cur0 = back ? start0 : next0;
-        cur1 = back ? start1 : next1;
-        terminal = back ? start_terminal : o.next_terminal;
-        STAMP(7);   // reset handling
-    }
-    if (RECORD && p.n_steps > 0) {                           // flush the last step's outputs
-        if (live) store_cells<FULL>(p.rec_local, d_row, n_agents, x.g, x.v0, x.v1, d_next0, d_next1);
-        if (leader) {
-            reward_base[d_row] = d_reward;
-            prob_base[d_row] = d_prob;
-            done_base[d_row] = uint8_t(d_flags & 1u);
-            coll_base[d_row] = uint8_t(d_flags >> 1);
-        }
-    }
-#ifdef MAPF_STAMPS
-    if (live && x.lane == 0u && epi_p) {   // diagnostic build: segment sums replace the episode counts
-        for (int k = 0; k < 8; ++k) epi_p[k] = uint32_t(st.seg[k]);
-        return;
-    }
-#endif
-    if (!live) return;
-    store_cells<FULL>(p.state, e, n_agents, x.g, x.v0, x.v1, cur0, cur1);
-    if (leader) {
-        if (ret_p) *ret_p = ret;
-        if (epi_p) *epi_p = episodes;
-        if (col_p) *col_p = collisions;
     }
 }
 
@@ -688,15 +142,6 @@ int lg_group_size(int n_agents) {
     return L;
 }
 
-static inline void lg_geometry(int L, uint64_t n_envs, unsigned &grid, unsigned &block) {
-    const uint64_t threads = n_envs * uint64_t(L);
-    block = threads <= (uint64_t(1) << 19) ? 64u : 256u;       // keep >= ~2 blocks per CU at small sizes
-    const uint64_t per_block = block / unsigned(L);
-    grid = unsigned((n_envs + per_block - 1) / per_block);
-}
-
-#define MAPF_FOR_EACH_L(X) X(1) X(2) X(4) X(8) X(16) X(32) X(64)
-
 hipError_t launch_step_lg(int n_agents, const StepArgs &args, hipStream_t stream) {
     if (args.n_envs == 0) return hipSuccess;
     const int L = lg_group_size(n_agents);
@@ -720,72 +165,6 @@ hipError_t launch_step_lg(int n_agents, const StepArgs &args, hipStream_t stream
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
-}
-
-// LDS budget for the move table: the CU has 160 KiB; keep room for the slip rows
-static constexpr size_t kLdsBytes = 160 * 1024, kLdsReserve = 1024;
-
-// Largest move table that is staged into LDS (tuning knob: MAPF_MV_LDS_MAX_BYTES, default = what leaves room
-// for two resident blocks per CU; a table that allows only one block per CU starves the SIMDs of waves).
-static size_t mv_lds_limit() {
-    static const size_t limit = [] {
-        const char *e = getenv("MAPF_MV_LDS_MAX_BYTES");
-        return e ? size_t(strtoull(e, nullptr, 10)) : (kLdsBytes - kLdsReserve) / 2;
-    }();
-    return limit;
-}
-
-template <int L, bool FULL, bool RECORD, bool STREAM>
-static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, hipStream_t stream) {
-    const size_t mv_bytes = size_t(args.c.n_cells) * 5 * sizeof(uint64_t);
-    const uint64_t threads = args.n_envs * uint64_t(L);
-    if (mv_bytes + kLdsReserve <= mv_lds_limit() && threads >= 64 * 256) {
-        // block size: as many waves as can share one table copy while >= 16 waves stay resident per CU
-        const size_t copies = (kLdsBytes - kLdsReserve) / (mv_bytes + sizeof(SlipRow) * 8);   // blocks per CU by LDS
-        unsigned block = copies >= 4 ? 256u : (copies >= 2 ? 512u : 1024u);
-        if (block > rollout_max_block<L>()) block = rollout_max_block<L>();
-        const uint64_t per_block = block / unsigned(L);
-        const unsigned grid = unsigned((args.n_envs + per_block - 1) / per_block);
-        auto kern = lg_rollout_kernel<L, FULL, true, RECORD, STREAM>;
-        static bool raised = false;    // one flag per instantiation: allow dynamic LDS beyond 64 KiB
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsBytes - kLdsReserve));
-            if (e != hipSuccess) return e;
-            raised = true;
-        }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), mv_bytes, stream, args, A);
-    } else {
-        unsigned grid, block;
-        lg_geometry(L, args.n_envs, grid, block);
-        hipLaunchKernelGGL((lg_rollout_kernel<L, FULL, false, RECORD, STREAM>), dim3(grid), dim3(block), 0, stream, args, A);
-    }
-    return hipGetLastError();
-}
-
-hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, hipStream_t stream) {
-    if (args.n_envs == 0) return hipSuccess;
-    const int L = lg_group_size(n_agents);
-    const bool full = n_agents == 2 * L;
-    const uint32_t A = uint32_t(n_agents);
-    // the record variant writes all five trajectory arrays: the C ABI passes either all of them or none
-    const bool record = args.rec_local != nullptr, stream_actions = args.actions != nullptr;
-    if (record && !(args.rec_reward && args.rec_prob && args.rec_done && args.rec_collision)) return hipErrorInvalidValue;
-    switch (L) {
-#define X(N)                                                                                                         \
-    case N:                                                                                                          \
-        if (full) return record ? (stream_actions ? launch_rollout_lg_impl<N, true, true, true>(args, A, stream)          \
-                                                  : launch_rollout_lg_impl<N, true, true, false>(args, A, stream))        \
-                                : (stream_actions ? launch_rollout_lg_impl<N, true, false, true>(args, A, stream)         \
-                                                  : launch_rollout_lg_impl<N, true, false, false>(args, A, stream));      \
-        return record ? (stream_actions ? launch_rollout_lg_impl<N, false, true, true>(args, A, stream)                   \
-                                        : launch_rollout_lg_impl<N, false, true, false>(args, A, stream))                 \
-                      : (stream_actions ? launch_rollout_lg_impl<N, false, false, true>(args, A, stream)                  \
-                                        : launch_rollout_lg_impl<N, false, false, false>(args, A, stream));
-        MAPF_FOR_EACH_L(X)
-#undef X
-        default: return hipErrorInvalidValue;
-    }
 }
 
 }  // namespace mapf

@@ -1,0 +1,231 @@
+// Lane-group family: fused T-step rollout kernel and its launcher (device code: mapf_lg.hpp).
+#include "mapf_lg.hpp"
+
+#include <cstdlib>
+
+namespace mapf {
+
+// Largest block a rollout kernel may be launched with: groups of 16 lanes unroll 8 rotation rounds and need more
+// than the 128 registers a 1024-thread block leaves per lane.
+template <int L> constexpr unsigned rollout_max_block() { return L == 16 ? 512u : 1024u; }
+
+// raw (still packed) action bytes of a lane's two slots: byte 0 = agent 2g, byte 1 = agent 2g+1.  Kept packed so
+// that a prefetch issued one step ahead is not forced to complete by an unpack.
+template <bool EVEN>
+__device__ __forceinline__ uint32_t load_actions_raw(const uint8_t *base, uint32_t row, uint32_t n_agents, uint32_t g,
+                                                     bool v0, bool v1) {
+    const uint8_t *p = at(base, row * n_agents + 2u * g);
+    uint32_t raw = 0u;
+    if (EVEN || (n_agents & 1u) == 0u) {
+        if (v0) raw = *reinterpret_cast<const uint16_t *>(p);
+    } else {
+        uint32_t lo = 0u, hi = 0u;
+        if (v0) lo = p[0];
+        if (v1) hi = p[1];
+        raw = lo | (hi << 8);
+    }
+    return raw;
+}
+
+// MV_LDS: the whole move table (V*5 entries of 8 B) is staged into LDS once per block and the two gathers of
+// every step become ds_read_b64 (a random 64-lane gather through the vector-memory pipe touches up to 64 cache
+// lines).  RECORD: all five trajectory arrays are written every step (the C ABI substitutes scratch for absent
+// ones), STREAM: actions come from memory, else from the in-kernel policy stream.  Both are compile-time so the
+// loop body has no branches around its memory operations: the compiler can then wait for the action word that
+// was prefetched one step ahead with a counted vmcnt(N) instead of draining every store (vmcnt(0)).  Start
+// cells stay in two registers per lane, so an auto-reset touches no memory.
+template <int L, bool FULL, bool MV_LDS, bool RECORD, bool STREAM>
+__global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
+    __shared__ SlipRow slip[8];
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds_mv[];
+    bool live;
+    const LaneCtx<L> x = lane_ctx<L>(n_agents, p.n_envs, live);
+    const uint32_t e = x.e;
+    const bool leader = live && x.g == 0u;
+
+    uint32_t cur0, cur1, goal0, goal1, start0 = 0u, start1 = 0u;
+    load_pair<uint16_t>(p.state, e, n_agents, x.g, x.v0, x.v1, cur0, cur1);
+    load_pair<uint16_t>(p.goal, p.goal_broadcast ? 0 : e, n_agents, x.g, x.v0, x.v1, goal0, goal1);
+    if (p.auto_reset) load_pair<uint16_t>(p.start, p.start_broadcast ? 0 : e, n_agents, x.g, x.v0, x.v1, start0, start1);
+    if (MV_LDS) {
+        const uint32_t n_words = p.c.n_cells * 5u;
+        for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) lds_mv[w] = p.mv[w];
+    }
+    stage_slip_table(p.slip, slip);   // ends with __syncthreads()
+    const uint64_t *mv = MV_LDS ? lds_mv : p.mv;
+
+    // is_terminal is carried from step to step instead of re-deriving it from the cells every step
+    bool terminal = lg_is_terminal<L, FULL>(x, n_agents, cur0, cur1, goal0, goal1);
+    const bool start_terminal = p.auto_reset ? lg_is_terminal<L, FULL>(x, n_agents, start0, start1, goal0, goal1) : false;
+
+    // per-env totals and the scalar trajectory arrays: their addresses are parked in VGPRs so that seven base
+    // pointers do not occupy SGPRs across the step loop (it already keeps ~100 scalars live).  They stay typed as
+    // GLOBAL pointers: a generic pointer would turn the stores into flat_store, which also counts on lgkmcnt and
+    // would chain every LDS wait of the loop to the stores' completion.
+    using gf64 = __attribute__((address_space(1))) double *;
+    using gu32 = __attribute__((address_space(1))) uint32_t *;
+    using gu8 = __attribute__((address_space(1))) uint8_t *;
+    gf64 ret_p = (gf64)(p.out_returns ? at(p.out_returns, e) : nullptr);
+    gu32 epi_p = (gu32)(p.out_episodes ? at(p.out_episodes, e) : nullptr);
+    gu32 col_p = (gu32)(p.out_collisions ? at(p.out_collisions, e) : nullptr);
+    gu8 done_base = (gu8)(RECORD ? p.rec_done : nullptr), coll_base = (gu8)(RECORD ? p.rec_collision : nullptr);
+    gf64 reward_base = (gf64)(RECORD ? p.rec_reward : nullptr), prob_base = (gf64)(RECORD ? p.rec_prob : nullptr);
+    asm volatile("" : "+v"(ret_p), "+v"(epi_p), "+v"(col_p), "+v"(done_base), "+v"(coll_base), "+v"(reward_base),
+                 "+v"(prob_base));
+    double ret = (p.accumulate && ret_p && leader) ? *ret_p : 0.0;
+    uint32_t episodes = (p.accumulate && epi_p && leader) ? *epi_p : 0u;
+    uint32_t collisions = (p.accumulate && col_p && leader) ? *col_p : 0u;
+    const uint64_t env_id = p.env_id_offset + e;
+    const uint32_t n_envs = uint32_t(p.n_envs);
+
+#ifdef MAPF_STAMPS
+    StampCtx st{};
+    { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); st.last = _t; }
+#endif
+    // Software pipeline of the loop's memory operations.  The compiler waits for the prefetched action word with
+    // vmcnt(0), i.e. for EVERYTHING outstanding, so each iteration is ordered: (1) use the word loaded one
+    // iteration ago, (2) only then issue the next load and the PREVIOUS step's trajectory stores, (3) compute.
+    // Whatever the wait at (1) sees was issued a whole transition earlier and has long completed.
+    uint32_t raw = 0u;
+    if (STREAM && p.n_steps > 0) raw = load_actions_raw<FULL>(p.actions, e, n_agents, x.g, x.v0, x.v1);
+    Words4 rng{0u, 0u, 0u, 0u};
+    uint32_t d_next0 = 0u, d_next1 = 0u, d_row = 0u, d_flags = 0u;   // step s-1's results, stored during step s
+    double d_reward = 0.0, d_prob = 0.0;
+
+    for (uint32_t s = 0; s < p.n_steps; ++s) {
+        const uint64_t t = p.t + s;
+        const uint32_t row = s * n_envs + e;
+        uint32_t act0, act1;
+        if (STREAM) {
+            act0 = raw & 0xFFu; act1 = raw >> 8;
+            asm volatile("" : "+v"(act0), "+v"(act1));       // (1) pins the wait for `raw` here, ahead of (2)
+            if (s + 1 < p.n_steps) raw = load_actions_raw<FULL>(p.actions, row + n_envs, n_agents, x.g, x.v0, x.v1);
+        } else {   // policy stream: one Philox call covers agents 4q..4q+3; this lane needs words 2(g&1), 2(g&1)+1
+            uint32_t w[4];
+            const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | ((x.g >> 1) << 24);
+            philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, p.c.pol_lo, p.c.pol_hi, w);
+            const bool hi = (x.g & 1u) != 0u;
+            act0 = __umulhi(hi ? w[2] : w[0], 5u);
+            act1 = __umulhi(hi ? w[3] : w[1], 5u);
+        }
+        if (RECORD && s > 0) {                               // (2) the previous step's outputs
+            if (live) store_cells<FULL>(p.rec_local, d_row, n_agents, x.g, x.v0, x.v1, d_next0, d_next1);
+            if (leader) {
+                reward_base[d_row] = d_reward;
+                prob_base[d_row] = d_prob;
+                done_base[d_row] = uint8_t(d_flags & 1u);
+                coll_base[d_row] = uint8_t(d_flags >> 1);
+            }
+        }
+        uint32_t next0, next1;
+        EnvOut o;
+        STAMP(0);   // loop top: action fetch / policy / delayed stores
+        // one slip-stream call serves two steps: refresh at even t (and at an odd first step)
+        if (p.c.need_rng && ((t & 1u) == 0u || s == 0u)) rng = slip_words(p.c, env_id, t >> 1, x.g, 0u);
+        lg_transition<L, FULL, false, true, MV_LDS>(p.c, mv, slip, x, n_agents, cur0, cur1, goal0, goal1, act0, act1, 0.0, 0.0,
+                                            env_id, t, rng, terminal, next0, next1, o STAMP_ARG);
+        STAMP(6);   // reward / selects
+        ret = __dadd_rn(ret, o.reward);
+        episodes += o.done ? 1u : 0u;
+        collisions += o.collision ? 1u : 0u;
+        if (RECORD) {
+            d_next0 = next0; d_next1 = next1; d_row = row; d_reward = o.reward; d_prob = o.prob;
+            d_flags = (o.done ? 1u : 0u) | (o.collision ? 2u : 0u);
+        }
+        const bool back = p.auto_reset && o.done;          // MapfEnv.reset(): start cells, no reseed
+        cur0 = back ? start0 : next0;
+        cur1 = back ? start1 : next1;
+        terminal = back ? start_terminal : o.next_terminal;
+        STAMP(7);   // reset handling
+    }
+    if (RECORD && p.n_steps > 0) {                           // flush the last step's outputs
+        if (live) store_cells<FULL>(p.rec_local, d_row, n_agents, x.g, x.v0, x.v1, d_next0, d_next1);
+        if (leader) {
+            reward_base[d_row] = d_reward;
+            prob_base[d_row] = d_prob;
+            done_base[d_row] = uint8_t(d_flags & 1u);
+            coll_base[d_row] = uint8_t(d_flags >> 1);
+        }
+    }
+#ifdef MAPF_STAMPS
+    if (live && x.lane == 0u && epi_p) {   // diagnostic build: segment sums replace the episode counts
+        for (int k = 0; k < 8; ++k) epi_p[k] = uint32_t(st.seg[k]);
+        return;
+    }
+#endif
+    if (!live) return;
+    store_cells<FULL>(p.state, e, n_agents, x.g, x.v0, x.v1, cur0, cur1);
+    if (leader) {
+        if (ret_p) *ret_p = ret;
+        if (epi_p) *epi_p = episodes;
+        if (col_p) *col_p = collisions;
+    }
+}
+
+// LDS budget for the move table: the CU has 160 KiB; keep room for the slip rows
+static constexpr size_t kLdsBytes = 160 * 1024, kLdsReserve = 1024;
+
+// Largest move table that is staged into LDS (tuning knob: MAPF_MV_LDS_MAX_BYTES, default = what leaves room
+// for two resident blocks per CU; a table that allows only one block per CU starves the SIMDs of waves).
+static size_t mv_lds_limit() {
+    static const size_t limit = [] {
+        const char *e = getenv("MAPF_MV_LDS_MAX_BYTES");
+        return e ? size_t(strtoull(e, nullptr, 10)) : (kLdsBytes - kLdsReserve) / 2;
+    }();
+    return limit;
+}
+
+template <int L, bool FULL, bool RECORD, bool STREAM>
+static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, hipStream_t stream) {
+    const size_t mv_bytes = size_t(args.c.n_cells) * 5 * sizeof(uint64_t);
+    const uint64_t threads = args.n_envs * uint64_t(L);
+    if (mv_bytes + kLdsReserve <= mv_lds_limit() && threads >= 64 * 256) {
+        // block size: as many waves as can share one table copy while >= 16 waves stay resident per CU
+        const size_t copies = (kLdsBytes - kLdsReserve) / (mv_bytes + sizeof(SlipRow) * 8);   // blocks per CU by LDS
+        unsigned block = copies >= 4 ? 256u : (copies >= 2 ? 512u : 1024u);
+        if (block > rollout_max_block<L>()) block = rollout_max_block<L>();
+        const uint64_t per_block = block / unsigned(L);
+        const unsigned grid = unsigned((args.n_envs + per_block - 1) / per_block);
+        auto kern = lg_rollout_kernel<L, FULL, true, RECORD, STREAM>;
+        static bool raised = false;    // one flag per instantiation: allow dynamic LDS beyond 64 KiB
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsBytes - kLdsReserve));
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), mv_bytes, stream, args, A);
+    } else {
+        unsigned grid, block;
+        lg_geometry(L, args.n_envs, grid, block);
+        hipLaunchKernelGGL((lg_rollout_kernel<L, FULL, false, RECORD, STREAM>), dim3(grid), dim3(block), 0, stream, args, A);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, hipStream_t stream) {
+    if (args.n_envs == 0) return hipSuccess;
+    const int L = lg_group_size(n_agents);
+    const bool full = n_agents == 2 * L;
+    const uint32_t A = uint32_t(n_agents);
+    // the record variant writes all five trajectory arrays: the C ABI passes either all of them or none
+    const bool record = args.rec_local != nullptr, stream_actions = args.actions != nullptr;
+    if (record && !(args.rec_reward && args.rec_prob && args.rec_done && args.rec_collision)) return hipErrorInvalidValue;
+    switch (L) {
+#define X(N)                                                                                                         \
+    case N:                                                                                                          \
+        if (full) return record ? (stream_actions ? launch_rollout_lg_impl<N, true, true, true>(args, A, stream)          \
+                                                  : launch_rollout_lg_impl<N, true, true, false>(args, A, stream))        \
+                                : (stream_actions ? launch_rollout_lg_impl<N, true, false, true>(args, A, stream)         \
+                                                  : launch_rollout_lg_impl<N, true, false, false>(args, A, stream));      \
+        return record ? (stream_actions ? launch_rollout_lg_impl<N, false, true, true>(args, A, stream)                   \
+                                        : launch_rollout_lg_impl<N, false, true, false>(args, A, stream))                 \
+                      : (stream_actions ? launch_rollout_lg_impl<N, false, false, true>(args, A, stream)                  \
+                                        : launch_rollout_lg_impl<N, false, false, false>(args, A, stream));
+        MAPF_FOR_EACH_L(X)
+#undef X
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace mapf

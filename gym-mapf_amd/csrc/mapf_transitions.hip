@@ -83,13 +83,13 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
     }
 #pragma unroll
     for (int i = 0; i < MAXA; ++i) {
-        const uint32_t fwd = prev[i] | (next[i] << 16);
 #pragma unroll
         for (int j = i + 1; j < MAXA; ++j) {
-            // ghost cells (>= 0x10000) overflow the 16-bit packing, so test the swap on the unpacked cells
-            const bool swap = prev[i] == next[j] && prev[j] == next[i];
-            coll_acc = min(coll_acc, min(next[i] ^ next[j], swap ? 0u : 1u));
-            (void)fwd;
+            // vertex: next_i == next_j; swap: prev_i == next_j and prev_j == next_i.  Integer min-of-xor accumulators
+            // (no wave-mask booleans: those cost an SGPR pair per pair test); ghost cells are >= 0x10000 and unique,
+            // so they never produce a zero.
+            const uint32_t swap = (prev[i] ^ next[j]) | (prev[j] ^ next[i]);
+            coll_acc = min(coll_acc, min(next[i] ^ next[j], swap));
         }
     }
     const bool coll = coll_acc == 0u, goal_next = goal_next_acc == 0u;
@@ -111,7 +111,6 @@ hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream) {
     const dim3 grid{unsigned(grid64)}, block{256};
     if (args.n_agents <= 4) hipLaunchKernelGGL(transitions_kernel<4>, grid, block, 0, stream, args);
     else if (args.n_agents <= 8) hipLaunchKernelGGL(transitions_kernel<8>, grid, block, 0, stream, args);
-    else if (args.n_agents <= 16) hipLaunchKernelGGL(transitions_kernel<16>, grid, block, 0, stream, args);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -160,7 +160,8 @@ int mapf_fill_random_actions(mapf_handle_t h, uint8_t *actions, uint64_t t0, uin
  *   max_branches M: rows reserved per query (3^A always suffices); out_count u32[N] reports the true number
  *   out_next u16[N*M*A], out_prob f64[N*M], out_reward f64[N*M], out_done u8[N*M], out_collision u8[N*M]
  * Rows b >= out_count[q] are left untouched.  A terminal state yields one branch (prob 1.0, reward 0, done).
- * Supported for n_agents <= 16 (the enumeration is exponential in A).  Any out_* may be NULL.
+ * Supported for n_agents <= 8 (3^A branches per query; planners decompose larger problems with
+ * get_local_view).  Any out_* may be NULL.
  */
 int mapf_transitions(mapf_handle_t h, uint64_t n_queries, const uint16_t *local, const uint8_t *actions,
                      const uint32_t *env_index, uint32_t max_branches, uint32_t *out_count, uint16_t *out_next,
