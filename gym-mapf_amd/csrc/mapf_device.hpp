@@ -1,11 +1,9 @@
-// Device-side building blocks of the batched MapfEnv.step() path (gfx950 only).
-//
-// One thread owns one env for a whole transition: its A cells, actions and the
-// A(A-1)/2 pair tests live in registers, so the only memory traffic is the
-// env-major rows themselves (16 B per lane at A = 8 -- one global_load_dwordx4).
-// Float64 arithmetic follows the reference operation by operation
-// (mapf_env.py:163-184, :225-266, :436-446); every add/mul that decides a bit is
-// an explicit round-to-nearest intrinsic so no FMA contraction can change it.
+// Device-side building blocks shared by both kernel families of the batched MapfEnv.step() path (gfx950 only):
+// Philox4x32-10 and the slip-stream layout, env-major row I/O, the per-agent slip sampling against the host-built
+// tables (move table + slip rows), and the thread-per-env transition (one lane owns all A agents of an env; the
+// lane-group transition lives in mapf_lg.hpp).
+// Float64 arithmetic follows the reference operation by operation (mapf_env.py:163-184, :225-266, :436-446); every
+// add/mul that decides a bit is an explicit round-to-nearest intrinsic so no FMA contraction can change it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -1,4 +1,6 @@
-// HIP kernels of the batched MapfEnv.step() path and their launchers (gfx950).
+// Thread-per-env kernel family (A <= 16, opt-in with MAPF_FLAG_THREAD_PER_ENV; the default family is the
+// lane-group one in mapf_lg_kernels.hip / mapf_lg_rollout.hip).  Kept as an independent implementation of the same
+// semantics that the parity tests cross-check against the lane-group kernels.
 //
 //   step_kernel<A>      one transition per env per launch; every output written to HBM
 //                       (MapfEnv.step, mapf_env.py:237-266) + optional fused auto-reset
