@@ -187,12 +187,10 @@ static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, hi
         const uint64_t per_block = block / unsigned(L);
         const unsigned grid = unsigned((args.n_envs + per_block - 1) / per_block);
         auto kern = lg_rollout_kernel<L, FULL, true, RECORD, STREAM>;
-        static bool raised = false;    // one flag per instantiation: allow dynamic LDS beyond 64 KiB
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+        if (mv_bytes > 32 * 1024) {   // dynamic LDS beyond the default cap needs an explicit opt-in;
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),   // per device, so not cached
                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsBytes - kLdsReserve));
             if (e != hipSuccess) return e;
-            raised = true;
         }
         hipLaunchKernelGGL(kern, dim3(grid), dim3(block), mv_bytes, stream, args, A);
     } else {

@@ -414,3 +414,24 @@ def test_out_of_range_actions_are_stay_and_device_pointers_must_be_aligned():
     dev.sync()
     assert local.shape == (64, 2) and bool((info['was_terminal'] == 0).all())
     dev.close()
+
+
+def test_rollout_with_large_lds_move_table():
+    """A 40x40 map (V ~ 1440): the move table is ~57 KB, i.e. LDS-resident but beyond the default dynamic-LDS cap
+    (needs the explicit opt-in) -- fused rollout against the C oracle, 4 and 8 agents."""
+    rs = np.random.RandomState(77)
+    lines = [''.join('@' if rs.rand() < 0.1 else '.' for _ in range(40)) for _ in range(40)]
+    grid = MapfGrid(lines)
+    valid, _, nbr = grid.tables()
+    V, E = len(valid), 8192
+    assert 32 * 1024 < V * 40 < 80 * 1024
+    for A in (4, 8):
+        start = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+        goal = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+        env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.SoC, seed=9,
+                         start_local=start, goal_local=goal)
+        co = c_oracle.COracle(nbr, A, start, goal, 0.2, -1000.0, 100.0, -1.0, mo.SOC, seed=9)
+        res, ref = env.rollout(40, auto_reset=True, record=True), co.rollout(40, auto_reset=True)
+        assert np.array_equal(_bits(res['returns']), _bits(ref['returns'])) and np.array_equal(res['episodes'], ref['episodes'])
+        assert np.array_equal(env.get_state()[0], co.state)
+        env.close()
