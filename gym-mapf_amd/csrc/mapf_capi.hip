@@ -155,7 +155,7 @@ bool build_slip_table(double fail_prob, mapf::SlipRow (&rows)[8]) {
                 row.q[k] = q[k];
                 const double scaled = std::ceil(std::ldexp(run, 53));          // exact: power-of-two scaling
                 row.thr[k] = scaled >= 9007199254740992.0 ? (uint64_t(1) << 53) : (scaled <= 0 ? 0 : uint64_t(scaled));
-                row.th[k] = uint32_t(row.thr[k] >> 26);
+                row.th[k] = uint32_t(row.thr[k] >> 37);
                 row.src |= uint32_t(src[k]) << (8 * k);
             } else {
                 row.cum[k] = -HUGE_VAL;

@@ -81,30 +81,28 @@ __device__ __forceinline__ void slip_move(const SlipRow *lds_slip, uint64_t entr
     const SlipRow &row = lds_slip[uint32_t(entry >> 48) & 7u];
     // categorical_sample (call site mapf_env.py:255): (cumsum(p) > u).argmax(), all-False -> 0.
     // cum[k] > u  <=>  mant < ceil(cum[k] * 2^53) = thr[k]; rows shorter than 3 carry thr = 0 / cum = -inf.
-    // The three candidate probabilities are fetched together with the thresholds (one LDS round trip) and the
-    // sampled one is picked in registers.
-    const double qa = row.q[0], qb = row.q[1], qc = row.q[2];
     bool b0, b1, b2;
     if (EXT_UNIFORMS) {
         b0 = row.cum[0] > u; b1 = row.cum[1] > u; b2 = row.cum[2] > u;
     } else {
         b0 = mant < row.thr[0]; b1 = mant < row.thr[1]; b2 = mant < row.thr[2];
     }
-    const bool pick1 = !b0 && b1, pick2 = !b0 && !b1 && b2;
-    const uint32_t lo = uint32_t(entry), hi = uint32_t(entry >> 32);
-    next = pick2 ? (hi & 0xFFFFu) : (pick1 ? (lo >> 16) : (lo & 0xFFFFu));
-    q = pick2 ? qc : (pick1 ? qb : qa);
+    // the index is turned into an integer at once (wave-mask booleans that stay live cost an SGPR pair each)
+    const uint32_t idx = b0 ? 0u : (b1 ? 1u : (b2 ? 2u : 0u));
+    const uint32_t lo = uint32_t(entry), up = uint32_t(entry >> 32);
+    next = ((idx == 2u ? up : lo) >> ((idx & 1u) * 16u)) & 0xFFFFu;
+    q = row.q[idx];
 }
 
-// Fast path of the same sampling with only the top 27 bits of the uniform (hi = mant >> 26): hi < th[k] decides
-// mant < thr[k] unless hi == th[k]; `ambiguous` is set in that (rare) case and the caller repeats the move
+// Fast path of the same sampling with only the top 16 bits of the uniform (hi = mant >> 37): hi < th[k] decides
+// mant < thr[k] unless hi == th[k]; `tie_dist` is 0 in that (rare) case and the caller repeats the move
 // with the full 53-bit mantissa.
 __device__ __forceinline__ void slip_move_hi(const SlipRow *lds_slip, uint64_t entry, uint32_t hi, uint32_t &next,
-                                             double &q, bool &ambiguous) {
+                                             double &q, uint32_t &tie_dist) {
     const SlipRow &row = lds_slip[uint32_t(entry >> 48) & 7u];
     const uint32_t t0 = row.th[0], t1 = row.th[1], t2 = row.th[2];
     const bool b0 = hi < t0, b1 = hi < t1, b2 = hi < t2;
-    ambiguous = (hi == t0) | (hi == t1) | (hi == t2);
+    tie_dist = min(hi ^ t0, min(hi ^ t1, hi ^ t2));   // 0 <=> hi ties with a threshold (integer, no wave-mask booleans)
     const uint32_t idx = b0 ? 0u : (b1 ? 1u : (b2 ? 2u : 0u));
     // list slot idx of the entry: cells sit at bit 16*idx; the probability is fetched by address (one ds_read_b64
     // instead of reading all three and selecting 64-bit values in registers)
@@ -113,18 +111,33 @@ __device__ __forceinline__ void slip_move_hi(const SlipRow *lds_slip, uint64_t e
     q = row.q[idx];
 }
 
-// The four words of the slip stream that serve agents (2*pair, 2*pair+1) at steps (2h, 2h+1):
-// word 2*(t&1) + (agent&1).  refine = 0: source of the uniforms' top 27 bits; refine = 1: of their low 26 bits.
+// Slip stream (oracle/philox.py): one call with rslot = refine = 0 yields the four words that serve agents
+// (2*pair, 2*pair+1) at steps 4h .. 4h+3 -- word (t & 3): low half = top 16 bits of agent 2*pair's uniform, high
+// half = agent 2*pair+1's.  The low 37 bits of a slot's uniform come from a separate call (refine = 1, rslot =
+// 2*(t & 3) + (agent & 1)), needed only when the top 16 bits tie with a threshold.
 struct Words4 { uint32_t w0, w1, w2, w3; };
 
-__device__ __forceinline__ Words4 slip_words(const EnvConsts &c, uint64_t env_id, uint64_t h, uint32_t pair, uint32_t refine) {
-    const uint32_t c3 = (uint32_t(h >> 32) & 0x00FFFFFFu) | (pair << 24) | (refine << 31);
+__device__ __forceinline__ Words4 slip_words(const EnvConsts &c, uint64_t env_id, uint64_t h, uint32_t pair, uint32_t rslot,
+                                             uint32_t refine) {
+    const uint32_t c3 = (uint32_t(h >> 32) & 0xFFFFu) | (pair << 16) | (rslot << 23) | (refine << 31);
     uint32_t w[4];
     philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(h), c3, c.seed_lo, c.seed_hi, w);
     return Words4{w[0], w[1], w[2], w[3]};
 }
 
-// address of the move-table row; cells beyond V (only reachable through a corrupted state) are clamped
+// word (t & 3) of a call
+__device__ __forceinline__ uint32_t step_word(const Words4 &w, uint64_t t) {
+    const uint32_t k = uint32_t(t) & 3u;
+    return k == 0u ? w.w0 : (k == 1u ? w.w1 : (k == 2u ? w.w2 : w.w3));
+}
+
+// full 53-bit mantissa of (t, agent) given the top 16 bits: one refinement call
+__device__ __forceinline__ uint64_t refine_mantissa(const EnvConsts &c, uint64_t env_id, uint64_t t, uint32_t agent, uint32_t hi16) {
+    const Words4 r = slip_words(c, env_id, t >> 2, agent >> 1, 2u * (uint32_t(t) & 3u) + (agent & 1u), 1u);
+    return (uint64_t(hi16) << 37) | (uint64_t(r.w0 & 0x1Fu) << 32) | uint64_t(r.w1);
+}
+
+// move-table row of (cell, action); cells beyond V (only reachable through a corrupted state) are clamped
 template <bool CLAMP = true>
 __device__ __forceinline__ uint64_t move_entry(const uint64_t *__restrict__ mv, uint32_t n_cells, uint32_t cell,
                                                uint32_t action) {
@@ -168,26 +181,39 @@ __device__ __forceinline__ void env_transition(const EnvConsts &c, const uint64_
     for (int i = 0; i < A; ++i) entry[i] = move_entry(mv, c.n_cells, prev[i], act[i]);
 
     double prob = 1.0;
-    Words4 wh{0u, 0u, 0u, 0u}, wl{0u, 0u, 0u, 0u};
+    if (EXT_UNIFORMS) {
 #pragma unroll
-    for (int i = 0; i < A; ++i) {
-        uint64_t mant = 0;
-        double u = 0.0;
-        if (EXT_UNIFORMS) {
-            u = ext_u[i];
-        } else if (c.need_rng) {  // uniform branch: a single surviving candidate needs no draw
-            if ((i & 1) == 0) {   // this family always evaluates both halves of the 53-bit uniform
-                wh = slip_words(c, env_id, t >> 1, uint32_t(i >> 1), 0u);
-                wl = slip_words(c, env_id, t >> 1, uint32_t(i >> 1), 1u);
-            }
-            const bool odd = (t & 1u) != 0u;
-            const uint32_t hi = (i & 1) ? (odd ? wh.w3 : wh.w1) : (odd ? wh.w2 : wh.w0);
-            const uint32_t lo = (i & 1) ? (odd ? wl.w3 : wl.w1) : (odd ? wl.w2 : wl.w0);
-            mant = mantissa53(hi, lo);
+        for (int i = 0; i < A; ++i) {
+            double pr;
+            slip_move<true>(lds_slip, entry[i], 0, ext_u[i], out.next[i], pr);
+            prob = (i == 0) ? pr : __dmul_rn(prob, pr);  // total_prob *= p, agent order (:257)
         }
-        double pr;
-        slip_move<EXT_UNIFORMS>(lds_slip, entry[i], mant, u, out.next[i], pr);
-        prob = (i == 0) ? pr : __dmul_rn(prob, pr);  // total_prob *= p, agent order (:257)
+    } else {
+        // fast path on the top 16 bits of every agent's uniform; the (rare) wave with a tie redoes all its agents
+        // with the full 53-bit mantissas
+        uint32_t hi[A];
+        uint32_t tie = 0xFFFFFFFFu;
+        Words4 w{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < A; ++i) {
+            if ((i & 1) == 0 && c.need_rng) w = slip_words(c, env_id, t >> 2, uint32_t(i >> 1), 0u, 0u);
+            const uint32_t word = step_word(w, t);
+            hi[i] = (i & 1) ? (word >> 16) : (word & 0xFFFFu);
+            double pr;
+            uint32_t dist;
+            slip_move_hi(lds_slip, entry[i], hi[i], out.next[i], pr, dist);
+            tie = min(tie, dist);
+            prob = (i == 0) ? pr : __dmul_rn(prob, pr);
+        }
+        if (__builtin_expect(__any(tie == 0u && c.need_rng), 0)) {
+            prob = 1.0;
+#pragma unroll
+            for (int i = 0; i < A; ++i) {
+                double pr;
+                slip_move<false>(lds_slip, entry[i], refine_mantissa(c, env_id, t, uint32_t(i), hi[i]), 0.0, out.next[i], pr);
+                prob = (i == 0) ? pr : __dmul_rn(prob, pr);
+            }
+        }
     }
     out.prob = prob;
 

@@ -11,7 +11,7 @@ namespace mapf {
 // cells in first-seen order with old + new, then cumsum left to right.
 struct SlipRow {
     double q[3];                   // merged probabilities, list order
-    uint32_t th[3];                // thr[k] >> 26: top 27 bits of the thresholds (fast path, see slip_move_hi)
+    uint32_t th[3];                // thr[k] >> 37: top 16 bits of the thresholds (fast path, see slip_move_hi)
     uint32_t n;                    // list length, 1..3
     uint64_t thr[3];               // ceil(cum[k] * 2^53): cum[k] > u  <=>  mant(u) < thr[k]; 0 past the list end
     double cum[3];                 // running float64 sums (for caller-supplied uniforms); -inf past the list end
@@ -92,7 +92,7 @@ hipError_t launch_query_terminal(int n_agents, const uint16_t *state, const uint
 
 // lane-group family (mapf_lg_kernels.hip): any A up to 128, run-time A
 constexpr int kTpeMaxAgents = 16;         // thread-per-env step kernels are specialised for A = 1..16
-constexpr int kTpeRolloutMaxAgents = 7;   // ... their rollout form is dispatched only where it is spill-free
+constexpr int kTpeRolloutMaxAgents = 6;   // ... their rollout form is dispatched only where it is spill-free
 hipError_t launch_step_lg(int n_agents, const StepArgs &args, hipStream_t stream);
 hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, hipStream_t stream);
 int lg_group_size(int n_agents);

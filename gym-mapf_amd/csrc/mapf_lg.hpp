@@ -273,20 +273,17 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const uint64_t
         slip_move<true>(lds_slip, entry0, 0, u0, next0, q0);
         slip_move<true>(lds_slip, entry1, 0, u1, next1, q1);
     } else {
-        // words of this step: 2*(t&1) and 2*(t&1)+1 of the call shared by steps 2h and 2h+1
-        const bool odd = (t & 1u) != 0u;
-        const uint32_t hi0 = (odd ? rng.w2 : rng.w0) >> 5, hi1 = (odd ? rng.w3 : rng.w1) >> 5;
+        // this step's word of the call shared by steps 4h .. 4h+3: low half for agent 2g, high half for agent 2g+1
+        const uint32_t word = step_word(rng, t);
+        const uint32_t hi0 = word & 0xFFFFu, hi1 = word >> 16;
         STAMP(1);   // philox + gather issue
-        bool amb0, amb1;
-        slip_move_hi(lds_slip, entry0, hi0, next0, q0, amb0);
-        slip_move_hi(lds_slip, entry1, hi1, next1, q1, amb1);
-        if (__builtin_expect(__any((amb0 || amb1) && c.need_rng), 0)) {
-            // a top-27-bit tie somewhere in the wave (~2^-25 per agent-step): redo with all 53 bits
-            const Words4 wr = slip_words(c, env_id, t >> 1, x.g, 1u);
-            const uint64_t mant0 = (uint64_t(hi0) << 26) | uint64_t((odd ? wr.w2 : wr.w0) >> 6);
-            const uint64_t mant1 = (uint64_t(hi1) << 26) | uint64_t((odd ? wr.w3 : wr.w1) >> 6);
-            slip_move<false>(lds_slip, entry0, mant0, 0.0, next0, q0);
-            slip_move<false>(lds_slip, entry1, mant1, 0.0, next1, q1);
+        uint32_t tie0, tie1;
+        slip_move_hi(lds_slip, entry0, hi0, next0, q0, tie0);
+        slip_move_hi(lds_slip, entry1, hi1, next1, q1, tie1);
+        if (__builtin_expect(__any(min(tie0, tie1) == 0u && c.need_rng), 0)) {
+            // a top-16-bit tie somewhere in the wave (~2^-8 of wave-steps): redo with all 53 bits
+            slip_move<false>(lds_slip, entry0, refine_mantissa(c, env_id, t, 2u * x.g, hi0), 0.0, next0, q0);
+            slip_move<false>(lds_slip, entry1, refine_mantissa(c, env_id, t, 2u * x.g + 1u, hi1), 0.0, next1, q1);
         }
     }
     if (!v0) { next0 = cur0; q0 = 1.0; }

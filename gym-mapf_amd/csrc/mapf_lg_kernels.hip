@@ -29,7 +29,7 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
     StampCtx st{};
 #endif
     Words4 rng{0u, 0u, 0u, 0u};
-    if (!EXT_UNIFORMS && p.c.need_rng) rng = slip_words(p.c, p.env_id_offset + e, p.t >> 1, x.g, 0u);
+    if (!EXT_UNIFORMS && p.c.need_rng) rng = slip_words(p.c, p.env_id_offset + e, p.t >> 2, x.g, 0u, 0u);
     lg_transition<L, FULL, EXT_UNIFORMS, false>(p.c, p.mv, rows, x, n_agents, cur0, cur1, goal0, goal1, act0, act1,
                                                 u0, u1, p.env_id_offset + e, p.t, rng, false, next0, next1, o STAMP_ARG);
     if (!live) return;

@@ -120,8 +120,8 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
         uint32_t next0, next1;
         EnvOut o;
         STAMP(0);   // loop top: action fetch / policy / delayed stores
-        // one slip-stream call serves two steps: refresh at even t (and at an odd first step)
-        if (p.c.need_rng && ((t & 1u) == 0u || s == 0u)) rng = slip_words(p.c, env_id, t >> 1, x.g, 0u);
+        // one slip-stream call serves four steps: refresh when t is a multiple of 4 (and at the first step)
+        if (p.c.need_rng && ((t & 3u) == 0u || s == 0u)) rng = slip_words(p.c, env_id, t >> 2, x.g, 0u, 0u);
         lg_transition<L, FULL, false, true, MV_LDS>(p.c, mv, slip, x, n_agents, cur0, cur1, goal0, goal1, act0, act1, 0.0, 0.0,
                                             env_id, t, rng, terminal, next0, next1, o STAMP_ARG);
         STAMP(6);   // reward / selects

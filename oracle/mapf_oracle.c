@@ -33,15 +33,16 @@ static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 }
 
 static double slip_uniform(uint64_t seed, uint64_t env_id, uint64_t t, uint32_t agent) {
-    const uint64_t h = t >> 1;
-    const uint32_t c3 = ((uint32_t)(h >> 32) & 0x00FFFFFFu) | (((agent >> 1) & 0x7Fu) << 24);
-    const uint32_t slot = 2u * (uint32_t)(t & 1) + (agent & 1u);
-    uint32_t a[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)h, c3};
-    uint32_t b[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)h, c3 | 0x80000000u};   /* refine */
-    philox4x32_10(a, (uint32_t)seed, (uint32_t)(seed >> 32));
-    philox4x32_10(b, (uint32_t)seed, (uint32_t)(seed >> 32));
-    uint64_t mant = ((uint64_t)(a[slot] >> 5) << 26) | (uint64_t)(b[slot] >> 6);
-    return (double)mant / 9007199254740992.0;
+    const uint64_t h = t >> 2;
+    const uint32_t slot = 2u * (uint32_t)(t & 3) + (agent & 1u);
+    const uint32_t c3 = ((uint32_t)(h >> 32) & 0xFFFFu) | (((agent >> 1) & 0x7Fu) << 16);
+    uint32_t w[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)h, c3};
+    uint32_t r[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)h, c3 | (slot << 23) | 0x80000000u};
+    philox4x32_10(w, (uint32_t)seed, (uint32_t)(seed >> 32));
+    philox4x32_10(r, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const uint64_t hi16 = (w[slot >> 1] >> (16u * (slot & 1u))) & 0xFFFFu;
+    const uint64_t lo37 = ((uint64_t)(r[0] & 0x1Fu) << 32) | (uint64_t)r[1];
+    return (double)((hi16 << 37) | lo37) / 9007199254740992.0;
 }
 
 static uint8_t policy_action(uint64_t seed, uint64_t env_id, uint64_t t, uint32_t agent) {

@@ -17,21 +17,23 @@ vectors in tests/test_philox.py.
 
 Stream layout (shared with include/mapf_hip.h):
 
-    key  = (seed & 0xffffffff, seed >> 32)
-    h    = t >> 1                                   # one Philox call serves two consecutive steps
-    ctr  = (env_id & 0xffffffff,
-            env_id >> 32,
-            h & 0xffffffff,
-            ((h >> 32) & 0x00ffffff) | ((agent >> 1) << 24) | (refine << 31))
-    slot = 2 * (t & 1) + (agent & 1)                # which of the four 32-bit output words
-    hi27 = philox4x32_10(ctr with refine = 0, key)[slot] >> 5
-    lo26 = philox4x32_10(ctr with refine = 1, key)[slot] >> 6
-    u    = (hi27 * 2**26 + lo26) / 2**53            # 53-bit, in [0, 1) -- the resolution of RandomState.rand()
+    key   = (seed & 0xffffffff, seed >> 32)
+    h     = t >> 2                                  # one Philox call serves FOUR consecutive steps of an agent pair
+    slot  = 2 * (t & 3) + (agent & 1)               # 0..7
+    ctr   = (env_id & 0xffffffff,
+             env_id >> 32,
+             h & 0xffffffff,
+             ((h >> 32) & 0xffff) | ((agent >> 1) << 16) | (rslot << 23) | (refine << 31))
+    W     = philox4x32_10(ctr with rslot = 0, refine = 0, key)
+    hi16  = (W[slot >> 1] >> (16 * (slot & 1))) & 0xffff          # word t & 3: low half agent 2p, high half agent 2p+1
+    R     = philox4x32_10(ctr with rslot = slot, refine = 1, key)
+    lo37  = ((R[0] & 0x1f) << 32) | R[1]
+    u     = (hi16 * 2**37 + lo37) / 2**53            # 53-bit, in [0, 1) -- the resolution of RandomState.rand()
 
-A 53-bit uniform is thus split over two counters.  The kernel compares hi27 against the top 27 bits of
-its thresholds and evaluates the refine = 1 call only in the (probability ~2^-25) case where those bits
-tie, so the common path costs one Philox call per agent pair per TWO steps while the value compared is
-exactly the u above.  The CPU oracle simply computes both words every time.
+A 53-bit uniform is thus split over two counters.  The kernel compares hi16 against the top 16 bits of its
+thresholds and evaluates the refine = 1 call only in the (probability ~2^-15 per agent-step) case where those
+bits tie, so the common path costs one Philox call per agent pair per FOUR steps while the value compared is
+exactly the u above.  The CPU oracle simply computes both calls every time.
 
 ``t`` is the handle-global step index (number of ``step`` calls so far), so a terminal-state step simply
 leaves its counters unused -- equivalent to the reference's "no draw on terminal steps" because nothing
@@ -86,39 +88,49 @@ def philox4x32_10_np(c0, c1, c2, c3, k0, k1):
 
 
 def _ctr_words(env_id, t, agent, refine):
-    h = t >> 1
+    h = t >> 2
+    slot = 2 * (t & 3) + (agent & 1)
     c0 = env_id & MASK32
     c1 = (env_id >> 32) & MASK32
     c2 = h & MASK32
-    c3 = ((h >> 32) & 0x00FFFFFF) | (((agent >> 1) & 0x7F) << 24) | ((refine & 1) << 31)
+    c3 = ((h >> 32) & 0xFFFF) | (((agent >> 1) & 0x7F) << 16)
+    if refine:
+        c3 |= (slot << 23) | (1 << 31)
     return c0, c1, c2, c3
 
 
 def slip_uniform(seed, env_id, t, agent):
     """The 53-bit uniform the slip model of (env_id, step t, agent) consumes."""
     key = (seed & MASK32, (seed >> 32) & MASK32)
-    slot = 2 * (int(t) & 1) + (int(agent) & 1)
-    hi = philox4x32_10(_ctr_words(int(env_id), int(t), int(agent), 0), key)[slot] >> 5
-    lo = philox4x32_10(_ctr_words(int(env_id), int(t), int(agent), 1), key)[slot] >> 6
-    return (hi * 67108864 + lo) / 9007199254740992.0
+    t, agent = int(t), int(agent)
+    slot = 2 * (t & 3) + (agent & 1)
+    w = philox4x32_10(_ctr_words(int(env_id), t, agent, 0), key)
+    r = philox4x32_10(_ctr_words(int(env_id), t, agent, 1), key)
+    hi16 = (w[slot >> 1] >> (16 * (slot & 1))) & 0xFFFF
+    lo37 = ((r[0] & 0x1F) << 32) | r[1]
+    return ((hi16 << 37) | lo37) / 9007199254740992.0
 
 
 def slip_uniforms_np(seed, env_ids, t, n_agents):
     """u[E, A] float64 for global env ids ``env_ids`` at step ``t``."""
     env_ids = np.asarray(env_ids, dtype=np.uint64).reshape(-1, 1)
-    pairs = (np.arange(n_agents, dtype=np.uint64) >> np.uint64(1)).reshape(1, -1)
+    E = env_ids.shape[0]
+    agents = np.arange(n_agents, dtype=np.uint64).reshape(1, -1)
+    pairs = agents >> np.uint64(1)
     t = int(t)
-    h = t >> 1
+    h = t >> 2
+    slot = np.uint64(2 * (t & 3)) + (agents & np.uint64(1))                    # [1, A]
     c0 = env_ids & np.uint64(MASK32)
     c1 = env_ids >> np.uint64(32)
     c2 = np.uint64(h & MASK32)
-    c3 = np.uint64((h >> 32) & 0x00FFFFFF) | (pairs << np.uint64(24))
+    c3 = np.uint64((h >> 32) & 0xFFFF) | (pairs << np.uint64(16))
     k0, k1 = seed & MASK32, (seed >> 32) & MASK32
-    slot = 2 * (t & 1) + (np.arange(n_agents) & 1).reshape(1, -1)
-    slot = np.broadcast_to(slot, (env_ids.shape[0], n_agents))
-    hi = np.choose(slot, philox4x32_10_np(c0, c1, c2, c3, k0, k1)) >> np.uint64(5)
-    lo = np.choose(slot, philox4x32_10_np(c0, c1, c2, c3 | np.uint64(1 << 31), k0, k1)) >> np.uint64(6)
-    mant = hi * np.uint64(67108864) + lo
+    w = philox4x32_10_np(c0, c1, c2, c3, k0, k1)
+    word = np.choose(np.broadcast_to((slot >> np.uint64(1)).astype(np.int64), (E, n_agents)), w)
+    hi16 = (word >> (np.uint64(16) * (slot & np.uint64(1)))) & np.uint64(0xFFFF)
+    r = philox4x32_10_np(c0, c1, c2, c3 | (slot << np.uint64(23)) | np.uint64(1 << 31), k0, k1)
+    lo37 = ((r[0] & np.uint64(0x1F)) << np.uint64(32)) | r[1]
+    mant = (hi16 << np.uint64(37)) | lo37
     return mant.astype(np.float64) / 9007199254740992.0
 
 
