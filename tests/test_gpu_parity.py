@@ -306,6 +306,13 @@ def test_config3_room32_8agents_65536_envs():
     every step against the C oracle, both criteria."""
     import bench
     grid, nbr, start, goal = bench.workload_tables(65536, 0)
+    # the run below is large enough to take the kernel's tie path (top 16 bits of a uniform equal to those of a
+    # threshold -> 53-bit refinement) many times: thresholds 0.8 and 0.9 have top-16-bit values 52428 and 58982
+    ties = 0
+    for t in range(12):
+        hi16 = np.floor(philox.slip_uniforms_np(42, np.arange(65536), t, 8) * 65536.0).astype(np.int64)
+        ties += int(np.isin(hi16, (52428, 58982)).sum())
+    assert ties > 50
     assert _full_size_check(grid, nbr, 8, start, goal, 0.2, OptimizationCriteria.Makespan, mo.MAKESPAN, 12, 48) > 0
     assert _full_size_check(grid, nbr, 8, start, goal, 0.2, OptimizationCriteria.SoC, mo.SOC, 4, 24, 'thread_per_env') > 0
 
