@@ -57,7 +57,7 @@ struct mapf_handle_s {
     bool lane_group_rollout = false;
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    uint64_t *mv = nullptr;
+    mapf::MoveEntry *mv = nullptr;
     mapf::SlipRow *slip = nullptr;
     uint16_t *state = nullptr, *start = nullptr, *goal = nullptr;
     // host-pointer mode staging
@@ -282,7 +282,7 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
     const double rf_ = d->fail_prob / 2, lf_ = d->fail_prob / 2;
     const bool keep[3] = {((1 - rf_) - lf_) > 0, rf_ > 0, lf_ > 0};
     static const uint8_t kSlipRight[5] = {0, 2, 3, 4, 1}, kSlipLeft[5] = {0, 4, 1, 2, 3};   // __init__.py:19-25
-    std::vector<uint64_t> packed(size_t(V) * 5);
+    std::vector<mapf::MoveEntry> packed(size_t(V) * 5);
     for (uint32_t v = 0; v < V; ++v) {
         const uint16_t *r = d->nbr + uint64_t(v) * 5;
         for (uint32_t a = 0; a < 5; ++a) {
@@ -296,17 +296,22 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
                 for (int j = 0; j < n; ++j) seen |= (cells[j] == cand[k]);
                 if (!seen) cells[n++] = cand[k];
             }
-            packed[size_t(v) * 5 + a] = uint64_t(cells[0]) | (uint64_t(cells[1]) << 16) | (uint64_t(cells[2]) << 32) | (code << 48);
+            // top 16 bits of the list's cumulative thresholds, saturated (see MoveEntry)
+            uint32_t t16[3];
+            for (int k = 0; k < 3; ++k) t16[k] = slip_host[code].th[k] > 65535u ? 65535u : slip_host[code].th[k];
+            packed[size_t(v) * 5 + a] = make_uint4(uint32_t(cells[0]) | (uint32_t(cells[1]) << 16),
+                                                    uint32_t(cells[2]) | (uint32_t(code) << 16),
+                                                    t16[0] | (t16[1] << 16), t16[2]);
         }
     }
     const size_t row = size_t(A) * sizeof(uint16_t);
-    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->mv), packed.size() * sizeof(uint64_t)));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->mv), packed.size() * sizeof(mapf::MoveEntry)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->state), (E ? E : 1) * row));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->start), (sb ? 1 : (E ? E : 1)) * row));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->goal), (gb ? 1 : (E ? E : 1)) * row));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->slip), sizeof(slip_host)));
     CREATE_TRY(hipMemcpy(h->slip, slip_host, sizeof(slip_host), hipMemcpyHostToDevice));
-    CREATE_TRY(hipMemcpy(h->mv, packed.data(), packed.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->mv, packed.data(), packed.size() * sizeof(mapf::MoveEntry), hipMemcpyHostToDevice));
     if (n_start) CREATE_TRY(hipMemcpy(h->start, d->start, n_start * sizeof(uint16_t), hipMemcpyHostToDevice));
     if (n_goal) CREATE_TRY(hipMemcpy(h->goal, d->goal, n_goal * sizeof(uint16_t), hipMemcpyHostToDevice));
     CREATE_TRY(mapf::launch_reset(int(A), h->state, h->start, sb, nullptr, E, h->stream));

@@ -75,10 +75,15 @@ __device__ __forceinline__ void stage_slip_table(const SlipRow *__restrict__ src
 // (c0 | c1 << 16 | c2 << 32) and the equality code of its three candidates (bits 48..50) -- the code picks
 // the LDS row holding that list's probabilities and cumulative thresholds.  `mant` is the 53-bit integer
 // of the uniform (u = mant * 2^-53), used when !EXT_UNIFORMS.
+__device__ __forceinline__ uint32_t entry_cell(const MoveEntry &entry, uint32_t idx) {   // list slot idx = 0, 1, 2
+    return ((idx == 2u ? entry.y : entry.x) >> ((idx & 1u) * 16u)) & 0xFFFFu;
+}
+__device__ __forceinline__ uint32_t entry_code(const MoveEntry &entry) { return (entry.y >> 16) & 7u; }
+
 template <bool EXT_UNIFORMS>
-__device__ __forceinline__ void slip_move(const SlipRow *lds_slip, uint64_t entry, uint64_t mant, double u,
+__device__ __forceinline__ void slip_move(const SlipRow *lds_slip, const MoveEntry &entry, uint64_t mant, double u,
                                           uint32_t &next, double &q) {
-    const SlipRow &row = lds_slip[uint32_t(entry >> 48) & 7u];
+    const SlipRow &row = lds_slip[entry_code(entry)];
     // categorical_sample (call site mapf_env.py:255): (cumsum(p) > u).argmax(), all-False -> 0.
     // cum[k] > u  <=>  mant < ceil(cum[k] * 2^53) = thr[k]; rows shorter than 3 carry thr = 0 / cum = -inf.
     bool b0, b1, b2;
@@ -89,26 +94,22 @@ __device__ __forceinline__ void slip_move(const SlipRow *lds_slip, uint64_t entr
     }
     // the index is turned into an integer at once (wave-mask booleans that stay live cost an SGPR pair each)
     const uint32_t idx = b0 ? 0u : (b1 ? 1u : (b2 ? 2u : 0u));
-    const uint32_t lo = uint32_t(entry), up = uint32_t(entry >> 32);
-    next = ((idx == 2u ? up : lo) >> ((idx & 1u) * 16u)) & 0xFFFFu;
+    next = entry_cell(entry, idx);
     q = row.q[idx];
 }
 
 // Fast path of the same sampling with only the top 16 bits of the uniform (hi = mant >> 37): hi < th[k] decides
 // mant < thr[k] unless hi == th[k]; `tie_dist` is 0 in that (rare) case and the caller repeats the move
 // with the full 53-bit mantissa.
-__device__ __forceinline__ void slip_move_hi(const SlipRow *lds_slip, uint64_t entry, uint32_t hi, uint32_t &next,
+__device__ __forceinline__ void slip_move_hi(const SlipRow *lds_slip, const MoveEntry &entry, uint32_t hi, uint32_t &next,
                                              double &q, uint32_t &tie_dist) {
-    const SlipRow &row = lds_slip[uint32_t(entry >> 48) & 7u];
-    const uint32_t t0 = row.th[0], t1 = row.th[1], t2 = row.th[2];
+    // the thresholds travel with the move-table row: no LDS access until the sampled probability is fetched
+    const uint32_t t0 = entry.z & 0xFFFFu, t1 = entry.z >> 16, t2 = entry.w & 0xFFFFu;
     const bool b0 = hi < t0, b1 = hi < t1, b2 = hi < t2;
     tie_dist = min(hi ^ t0, min(hi ^ t1, hi ^ t2));   // 0 <=> hi ties with a threshold (integer, no wave-mask booleans)
     const uint32_t idx = b0 ? 0u : (b1 ? 1u : (b2 ? 2u : 0u));
-    // list slot idx of the entry: cells sit at bit 16*idx; the probability is fetched by address (one ds_read_b64
-    // instead of reading all three and selecting 64-bit values in registers)
-    const uint32_t lo = uint32_t(entry), up = uint32_t(entry >> 32);
-    next = ((idx == 2u ? up : lo) >> ((idx & 1u) * 16u)) & 0xFFFFu;
-    q = row.q[idx];
+    next = entry_cell(entry, idx);
+    q = lds_slip[entry_code(entry)].q[idx];
 }
 
 // Slip stream (oracle/philox.py): one call with rslot = refine = 0 yields the four words that serve agents
@@ -139,15 +140,15 @@ __device__ __forceinline__ uint64_t refine_mantissa(const EnvConsts &c, uint64_t
 
 // move-table row of (cell, action); cells beyond V (only reachable through a corrupted state) are clamped
 template <bool CLAMP = true>
-__device__ __forceinline__ uint64_t move_entry(const uint64_t *__restrict__ mv, uint32_t n_cells, uint32_t cell,
-                                               uint32_t action) {
+__device__ __forceinline__ MoveEntry move_entry(const MoveEntry *__restrict__ mv, uint32_t n_cells, uint32_t cell,
+                                                uint32_t action) {
     // CLAMP = false only for an LDS-resident table: an out-of-range LDS read returns zeros instead of faulting
     const uint32_t c = (!CLAMP || cell < n_cells) ? cell : n_cells - 1u;
     return mv[c * 5u + action];
 }
 
 template <int A, bool EXT_UNIFORMS>
-__device__ __forceinline__ void env_transition(const EnvConsts &c, const uint64_t *__restrict__ mv,
+__device__ __forceinline__ void env_transition(const EnvConsts &c, const MoveEntry *__restrict__ mv,
                                                const SlipRow *lds_slip,
                                                const uint32_t (&prev)[A], const uint32_t (&goal)[A],
                                                const uint32_t (&act_in)[A], const double *ext_u,
@@ -176,7 +177,7 @@ __device__ __forceinline__ void env_transition(const EnvConsts &c, const uint64_
     for (int i = 0; i < A; ++i) act[i] = act_in[i] > 4u ? 0u : act_in[i];
 
     // the table rows of all agents are independent gathers: issue them together
-    uint64_t entry[A];
+    MoveEntry entry[A];
 #pragma unroll
     for (int i = 0; i < A; ++i) entry[i] = move_entry(mv, c.n_cells, prev[i], act[i]);
 

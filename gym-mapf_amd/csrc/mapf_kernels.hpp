@@ -9,6 +9,14 @@ namespace mapf {
 // (m = intended move, r = right slip, l = left slip; code = (m==r) | (m==l) << 1 | (r==l) << 2).
 // Built on the host by replaying single_agent_movements (mapf_env.py:163-184): drop p <= 0, merge equal
 // cells in first-seen order with old + new, then cumsum left to right.
+// Move table row of one (cell, action): everything the fast sampling path needs in ONE 16-byte read.
+//   x = c0 | c1 << 16, y = c2 | code << 16 : the merged movement list's cells in list order + the equality code of
+//       the three candidates (selects the SlipRow with the list's probabilities / full-width thresholds);
+//   z = t0 | t1 << 16, w = t2              : top 16 bits of the cumulative thresholds, saturated to 65535 (0 past the
+//       end of the list).  hi16 < t_k decides `cum[k] > u` unless hi16 == t_k; that tie (which the saturation makes
+//       slightly more frequent: hi16 = 65535 against a threshold of 1.0) is resolved by the exact 53-bit path.
+using MoveEntry = uint4;
+
 struct SlipRow {
     double q[3];                   // merged probabilities, list order
     uint32_t th[3];                // thr[k] >> 37: top 16 bits of the thresholds (fast path, see slip_move_hi)
@@ -30,7 +38,7 @@ struct EnvConsts {
 
 struct StepArgs {
     EnvConsts c;
-    const uint64_t *mv;            // [V*5] move table: list cells c0 | c1<<16 | c2<<32, equality code << 48
+    const MoveEntry *mv;           // [V*5] move table (see MoveEntry)
     const SlipRow *slip;           // [8] device copy of the slip table
     uint16_t *state;               // [E*A] persistent env state
     const uint16_t *start, *goal;  // [E*A] or [A]
@@ -45,7 +53,7 @@ struct StepArgs {
 
 struct RolloutArgs {
     EnvConsts c;
-    const uint64_t *mv;
+    const MoveEntry *mv;
     const SlipRow *slip;
     uint16_t *state;
     const uint16_t *start, *goal;
@@ -63,7 +71,7 @@ struct RolloutArgs {
 // routed by agent count (mapf_dispatch.hip)
 struct TransitionsArgs {
     EnvConsts c;
-    const uint64_t *mv;
+    const MoveEntry *mv;
     const SlipRow *slip;
     const uint16_t *goal;          // [E*A] or [A]
     const uint16_t *local;         // [N*A] query states

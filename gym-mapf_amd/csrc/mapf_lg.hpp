@@ -256,7 +256,7 @@ struct EnvOut {
 // group returns the same per-env results; next0/next1 are this lane's.  KNOWN_TERM: the caller already knows
 // is_terminal(prev) (rollout carries it from step to step); otherwise it is derived here.
 template <int L, bool FULL, bool EXT_UNIFORMS, bool KNOWN_TERM, bool MV_IN_LDS = false>
-__device__ __forceinline__ void lg_transition(const EnvConsts &c, const uint64_t *__restrict__ mv,
+__device__ __forceinline__ void lg_transition(const EnvConsts &c, const MoveEntry *__restrict__ mv,
                                               const SlipRow *lds_slip, const LaneCtx<L> &x, uint32_t n_agents,
                                               uint32_t cur0, uint32_t cur1, uint32_t goal0, uint32_t goal1,
                                               uint32_t act0_in, uint32_t act1_in, double u0, double u1,
@@ -266,8 +266,8 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const uint64_t
     const bool v0 = FULL || x.v0, v1 = FULL || x.v1;
 
     // --- my two agents' moves (computed even if the env turns out terminal; discarded then)
-    const uint64_t entry0 = move_entry<!MV_IN_LDS>(mv, c.n_cells, cur0, act0);
-    const uint64_t entry1 = move_entry<!MV_IN_LDS>(mv, c.n_cells, cur1, act1);
+    const MoveEntry entry0 = move_entry<!MV_IN_LDS>(mv, c.n_cells, cur0, act0);
+    const MoveEntry entry1 = move_entry<!MV_IN_LDS>(mv, c.n_cells, cur1, act1);
     double q0, q1;
     if (EXT_UNIFORMS) {
         slip_move<true>(lds_slip, entry0, 0, u0, next0, q0);

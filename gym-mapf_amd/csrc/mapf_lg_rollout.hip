@@ -27,8 +27,8 @@ __device__ __forceinline__ uint32_t load_actions_raw(const uint8_t *base, uint32
     return raw;
 }
 
-// MV_LDS: the whole move table (V*5 entries of 8 B) is staged into LDS once per block and the two gathers of
-// every step become ds_read_b64 (a random 64-lane gather through the vector-memory pipe touches up to 64 cache
+// MV_LDS: the whole move table (V*5 entries of 16 B) is staged into LDS once per block and the two gathers of
+// every step become ds_read_b128 (a random 64-lane gather through the vector-memory pipe touches up to 64 cache
 // lines).  RECORD: all five trajectory arrays are written every step (the C ABI substitutes scratch for absent
 // ones), STREAM: actions come from memory, else from the in-kernel policy stream.  Both are compile-time so the
 // loop body has no branches around its memory operations: the compiler can then wait for the action word that
@@ -37,7 +37,7 @@ __device__ __forceinline__ uint32_t load_actions_raw(const uint8_t *base, uint32
 template <int L, bool FULL, bool MV_LDS, bool RECORD, bool STREAM>
 __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
     __shared__ SlipRow slip[8];
-    extern __shared__ __attribute__((aligned(16))) uint64_t lds_mv[];
+    extern __shared__ __attribute__((aligned(16))) MoveEntry lds_mv[];
     bool live;
     const LaneCtx<L> x = lane_ctx<L>(n_agents, p.n_envs, live);
     const uint32_t e = x.e;
@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
         for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) lds_mv[w] = p.mv[w];
     }
     stage_slip_table(p.slip, slip);   // ends with __syncthreads()
-    const uint64_t *mv = MV_LDS ? lds_mv : p.mv;
+    const MoveEntry *mv = MV_LDS ? lds_mv : p.mv;
 
     // is_terminal is carried from step to step instead of re-deriving it from the cells every step
     bool terminal = lg_is_terminal<L, FULL>(x, n_agents, cur0, cur1, goal0, goal1);
@@ -177,7 +177,7 @@ static size_t mv_lds_limit() {
 
 template <int L, bool FULL, bool RECORD, bool STREAM>
 static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, hipStream_t stream) {
-    const size_t mv_bytes = size_t(args.c.n_cells) * 5 * sizeof(uint64_t);
+    const size_t mv_bytes = size_t(args.c.n_cells) * 5 * sizeof(MoveEntry);
     const uint64_t threads = args.n_envs * uint64_t(L);
     if (mv_bytes + kLdsReserve <= mv_lds_limit() && threads >= 64 * 256) {
         // block size: as many waves as can share one table copy while >= 16 waves stay resident per CU

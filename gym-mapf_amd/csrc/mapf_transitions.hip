@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
     const uint8_t *act_row = p.actions + q * A;
 
     uint32_t prev[MAXA], goal[MAXA], act[MAXA], n[MAXA];
-    uint64_t entry[MAXA];
+    MoveEntry entry[MAXA];
     uint32_t dup_acc = 0xFFFFFFFFu, goal_acc = 0u;
     uint64_t count = 1;
 #pragma unroll
@@ -36,8 +36,8 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
         goal[i] = on ? goal_row[i] : prev[i];
         const uint32_t a = on ? act_row[i] : 0u;
         act[i] = a > 4u ? 0u : a;
-        entry[i] = on ? move_entry(p.mv, p.c.n_cells, prev[i], act[i]) : 0;
-        n[i] = on ? slip[uint32_t(entry[i] >> 48) & 7u].n : 1u;
+        entry[i] = on ? move_entry(p.mv, p.c.n_cells, prev[i], act[i]) : MoveEntry{0u, 0u, 0u, 0u};
+        n[i] = on ? slip[entry_code(entry[i])].n : 1u;
         count *= n[i];
         goal_acc |= prev[i] ^ goal[i];
     }
@@ -72,9 +72,8 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
 #pragma unroll
     for (int i = 0; i < MAXA; ++i) {
         const bool on = uint32_t(i) < A;
-        const SlipRow &row = slip[uint32_t(entry[i] >> 48) & 7u];
-        const uint32_t lo = uint32_t(entry[i]), hi = uint32_t(entry[i] >> 32);
-        const uint32_t cell = k[i] == 0u ? (lo & 0xFFFFu) : (k[i] == 1u ? (lo >> 16) : (hi & 0xFFFFu));
+        const SlipRow &row = slip[entry_code(entry[i])];
+        const uint32_t cell = entry_cell(entry[i], k[i]);
         next[i] = on ? cell : prev[i];
         const double qv = on ? row.q[k[i]] : 1.0;
         prob = (i == 0) ? qv : __dmul_rn(prob, qv);
