@@ -27,7 +27,7 @@ env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCri
                  device_arrays=True, start_local=start, goal_local=goal)
 actions = env.fill_random_actions(0, T)
 env.sync()
-names = ['loop top (actions, delayed stores)', 'slip-stream Philox (every 2nd step) + gather issue', 'sampling (LDS rows)', 'pair tests',
+names = ['loop top (actions, delayed stores)', 'slip Philox (1 step in 4) + table read', 'sampling + probability read', 'pair tests',
          'flags + group reduce', 'probability product', 'reward / selects', 'reset handling']
 for acts, label in ((actions, 'streamed actions'), (None, 'in-kernel policy')):
     for record in (True, False):
