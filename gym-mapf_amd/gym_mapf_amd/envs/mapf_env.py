@@ -151,6 +151,7 @@ class MapfEnv(_EnvBase):
 
         self.P = _TransitionModel(self)
         self._vec = None        # one-env VecMapfEnv, created on first use (needs the GPU)
+        self._single = None     # one-agent helper env for single_agent_movements
         self._terminal = None   # is_terminal(self.s) if known
         self.reset()
         self.locations_to_state(self.agents_goals)   # KeyError if a goal is an obstacle
@@ -180,12 +181,15 @@ class MapfEnv(_EnvBase):
         twin = object.__new__(type(self))
         twin.__dict__.update(self.__dict__)   # shares grid and np_random like the reference's copy
         twin._vec = None                      # ... but owns its own device state
+        twin._single = None
         return twin
 
     def close(self):
-        if self._vec is not None:
-            self._vec.close()
-            self._vec = None
+        for name in ('_vec', '_single'):
+            dev = getattr(self, name)
+            if dev is not None:
+                dev.close()
+                setattr(self, name, None)
 
     # ------------------------------------------------------------------ gym surface
     def reset(self):
@@ -225,6 +229,50 @@ class MapfEnv(_EnvBase):
             out.append(((float(res['prob'][0, b]), bool(res['collision'][0, b])), nxt,
                         float(res['reward'][0, b]), bool(res['done'][0, b])))
         return out
+
+    def is_terminal(self, s):
+        """``s``: tuple of agent locations.  True when two agents share a cell or every agent is on its goal
+        (reference :210-223).  Answered by the device: an all-STAY query of a non-terminal state can neither
+        collide nor reach the goal state, so ``done`` of its single branch is exactly the terminal test."""
+        n = self.n_agents
+        local = [self.loc_to_int[tuple(loc)] for loc in s]
+        res = self._device().transitions(np.asarray([local], dtype=np.uint16), np.zeros((1, n), dtype=np.uint8),
+                                         max_branches=1)
+        return bool(res['done'][0, 0])
+
+    def single_agent_movements(self, local_state, a):
+        """Merged movement list of one agent: ``[(local_state, next_state, prob), ...]`` for action index ``a`` with
+        slips to the right/left of it, entries reaching the same cell summed in first-seen order (reference
+        :163-184).  Read off the device tables through a one-agent transition query."""
+        if self._single is None:
+            V = len(self.valid_locations)
+            if V < 2:
+                raise NotImplementedError('single_agent_movements needs a map with at least two free cells')
+            # two one-agent envs with different goals: query the one whose goal is not the asked cell, so the
+            # state is never terminal
+            self._single = VecMapfEnv(self.grid, 1, None, None, self.fail_prob, self.reward_of_clash, self.reward_of_goal,
+                                      self.reward_of_living, self.optimization_criteria,
+                                      start_local=np.array([[0], [1]], np.uint16), goal_local=np.array([[0], [1]], np.uint16))
+        env_index = np.array([1 if local_state == 0 else 0], dtype=np.uint32)
+        res = self._single.transitions(np.array([[local_state]], np.uint16), np.array([[a]], np.uint8), env_index=env_index)
+        return [(local_state, int(res['next'][0, b, 0]), float(res['prob'][0, b])) for b in range(int(res['count'][0]))]
+
+    def get_possible_actions(self, a):
+        """Every noised version of the joint action ``a`` (tuple of action names) with its probability, in the
+        reference's order (:186-208): the last agent's three alternatives (right slip, left slip, intended) are the
+        seed and each earlier agent multiplies the list by three."""
+        rf, lf = self.right_fail, self.left_fail
+        stay_on_course = 1.0 - rf - lf
+        right, left = POSSIBILITIES[a[-1]]
+        combos = [(rf, (right,)), (lf, (left,)), (stay_on_course, (a[-1],))]
+        for head in reversed(a[:-1]):
+            right, left = POSSIBILITIES[head]
+            widened = []
+            for prob, noised in combos:
+                widened += [(rf * prob, (right,) + noised), (lf * prob, (left,) + noised),
+                            (stay_on_course * prob, (head,) + noised)]
+            combos = widened
+        return combos
 
     def render(self, mode='human'):
         """ASCII picture, same priorities as the reference (:295-322): '*' where agents share a

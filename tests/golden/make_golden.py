@@ -404,6 +404,19 @@ def host_api_cases():
         err = repr(ex.args[0])
     out['render_obstacles'] = dict(lines=['..@.', '....', '.@..'], starts=[[0, 0], [1, 2]], goals=[[2, 2], [0, 0]],
                                    render=buf.getvalue(), render_with_policy_keyerror=err)
+    gpa = []
+    for fp in (0.2, 0.1, 0.0):
+        e = MapfEnv(MapfGrid(['....', '....']), 3, ((0, 0), (0, 1), (1, 3)), ((1, 0), (1, 1), (0, 3)), fp, R_CLASH, R_GOAL, -1,
+                    CRITERIA['SoC'])
+        for joint in (('UP',), ('STAY', 'LEFT'), ('RIGHT', 'DOWN', 'STAY')):
+            gpa.append(dict(fail_prob=fp, action=list(joint),
+                            result=[[float(p), list(a)] for p, a in e.get_possible_actions(joint)]))
+    out['get_possible_actions'] = gpa
+    term = []
+    e = MapfEnv(MapfGrid(['..@.', '....', '.@..']), 2, ((0, 0), (1, 2)), ((2, 2), (0, 0)), 0.1, R_CLASH, R_GOAL, -1, CRITERIA['SoC'])
+    for locs in (((0, 0), (1, 2)), ((2, 2), (0, 0)), ((1, 1), (1, 1)), ((2, 2), (1, 0)), ((0, 3), (0, 3))):
+        term.append(dict(locs=[list(l) for l in locs], terminal=bool(e.is_terminal(locs))))
+    out['is_terminal'] = dict(lines=['..@.', '....', '.@..'], starts=[[0, 0], [1, 2]], goals=[[2, 2], [0, 0]], cases=term)
     with open(os.path.join(HERE, 'host_api_cases.json'), 'w') as f:
         json.dump(out, f, indent=0)
     print('host api cases: %d sanity, %d views, %d predecessor envs, %d render frames' % (len(san), len(views), len(preds), len(rend)))

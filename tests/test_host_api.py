@@ -86,3 +86,11 @@ def test_render_with_policy_matches_reference_text():       # mapf_env.py:324-35
     with pytest.raises(KeyError) as err, contextlib.redirect_stdout(io.StringIO()):
         env.render_with_policy(0, lambda st: 0)
     assert repr(err.value.args[0]) == ro['render_with_policy_keyerror']
+
+
+def test_get_possible_actions_matches_reference():          # mapf_env.py:186-208
+    for case in G['get_possible_actions']:
+        env = MapfEnv(MapfGrid(['....', '....']), 3, ((0, 0), (0, 1), (1, 3)), ((1, 0), (1, 1), (0, 3)), case['fail_prob'],
+                      -1000.0, 100.0, -1, SOC)
+        got = env.get_possible_actions(tuple(case['action']))
+        assert [[p, list(a)] for p, a in got] == case['result']      # same order, same float64 products

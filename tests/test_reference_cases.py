@@ -300,3 +300,29 @@ def test_similar_transitions_probability_summed():          # mapf_env_tests.py:
                   REWARD_OF_LIVING, OptimizationCriteria.Makespan)
     a = vector_action_to_integer((STAY, STAY))
     assert env.P[env.s][a] == [((1, False), env.s, REWARD_OF_LIVING, False)]
+
+
+@pytest.mark.gpu
+def test_is_terminal_and_single_agent_movements_match_reference():      # mapf_env.py:210-223, :163-184
+    import numpy as np
+    from conftest import load_json, load_trajectory_set
+    t = load_json('host_api_cases.json')['is_terminal']
+    env = MapfEnv(MapfGrid(t['lines']), 2, tuple(map(tuple, t['starts'])), tuple(map(tuple, t['goals'])), 0.1,
+                  REWARD_OF_CLASH, REWARD_OF_GOAL, REWARD_OF_LIVING, OptimizationCriteria.SoC)
+    for case in t['cases']:
+        assert env.is_terminal(tuple(map(tuple, case['locs']))) == case['terminal']
+    env.close()
+    # the reference's own single_agent_movements tables (recorded per map in the trajectory goldens)
+    for name in ('tiny_a3_slip03_noreset', 'maze32_a5_slip05', 'tiny_a1_slip1'):
+        meta, g = load_trajectory_set(name)
+        env = MapfEnv(MapfGrid(meta['lines']), meta['n_agents'], tuple(map(tuple, g['start_loc'][0].tolist())),
+                      tuple(map(tuple, g['goal_loc'][0].tolist())), meta['fail_prob'], meta['r_clash'], meta['r_goal'],
+                      meta['r_living'], OptimizationCriteria.SoC)
+        V = len(env.valid_locations)
+        for v in list(range(0, V, max(1, V // 40))) + [V - 1]:
+            for a in range(5):
+                got = env.single_agent_movements(v, a)
+                n = int(g['mv_n'][v, a])
+                assert [m[0] for m in got] == [v] * n and [m[1] for m in got] == g['mv_next'][v, a, :n].tolist()
+                assert np.array_equal(np.asarray([m[2] for m in got]).view(np.uint64), g['mv_prob'][v, a, :n].view(np.uint64))
+        env.close()
