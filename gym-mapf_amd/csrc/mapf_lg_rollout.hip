@@ -31,15 +31,21 @@ __device__ __forceinline__ uint32_t load_actions_raw(const uint8_t *base, uint32
 // every step become ds_read_b128 (a random 64-lane gather through the vector-memory pipe touches up to 64 cache
 // lines).  RECORD: all five trajectory arrays are written every step (the C ABI substitutes scratch for absent
 // ones), STREAM: actions come from memory, else from the in-kernel policy stream.  Both are compile-time so the
-// loop body has no branches around its memory operations: the compiler can then wait for the action word that
-// was prefetched one step ahead with a counted vmcnt(N) instead of draining every store (vmcnt(0)).  Start
-// cells stay in two registers per lane, so an auto-reset touches no memory.
-template <int L, bool FULL, bool MV_LDS, bool RECORD, bool STREAM>
+// loop body has no uniform branches around its memory operations.  DENSE (A == 2L and the env count fills every
+// block) additionally removes the per-lane predicates: every lane owns two real agents, the action prefetch is
+// clamped instead of guarded, and the four per-env scalars are stored by ALL lanes with per-lane addresses (even
+// lanes of a group write reward and done, odd lanes prob and collision -- duplicates carry identical data), so the
+// loop contains no exec-masked memory operation and the compiler can wait for the prefetched action word with a
+// counted vmcnt(N) instead of draining every store.  Start cells stay in two registers per lane, so an
+// auto-reset touches no memory.
+template <int L, bool FULL, bool MV_LDS, bool RECORD, bool STREAM, bool DENSE>
 __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
     __shared__ SlipRow slip[8];
     extern __shared__ __attribute__((aligned(16))) MoveEntry lds_mv[];
-    bool live;
-    const LaneCtx<L> x = lane_ctx<L>(n_agents, p.n_envs, live);
+    bool live_rt;
+    LaneCtx<L> x = lane_ctx<L>(n_agents, p.n_envs, live_rt);
+    const bool live = DENSE || live_rt;
+    if (DENSE) { x.v0 = true; x.v1 = true; }
     const uint32_t e = x.e;
     const bool leader = live && x.g == 0u;
 
@@ -65,6 +71,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     using gf64 = __attribute__((address_space(1))) double *;
     using gu32 = __attribute__((address_space(1))) uint32_t *;
     using gu8 = __attribute__((address_space(1))) uint8_t *;
+    using gu16 = __attribute__((address_space(1))) uint16_t *;
     gf64 ret_p = (gf64)(p.out_returns ? at(p.out_returns, e) : nullptr);
     gu32 epi_p = (gu32)(p.out_episodes ? at(p.out_episodes, e) : nullptr);
     gu32 col_p = (gu32)(p.out_collisions ? at(p.out_collisions, e) : nullptr);
@@ -88,18 +95,74 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     // Whatever the wait at (1) sees was issued a whole transition earlier and has long completed.
     uint32_t raw = 0u;
     if (STREAM && p.n_steps > 0) raw = load_actions_raw<FULL>(p.actions, e, n_agents, x.g, x.v0, x.v1);
+    // consume the first word here, so that the wait at the loop head is the back edge's counted one
+    if (DENSE) asm volatile("" : "+v"(raw));
     Words4 rng{0u, 0u, 0u, 0u};
-    uint32_t d_next0 = 0u, d_next1 = 0u, d_row = 0u, d_flags = 0u;   // step s-1's results, stored during step s
+    // step s-1's results, stored during step s (DENSE: the very first store writes zeros into step 0's row, which
+    // step 1 then overwrites with the real values)
+    uint32_t d_next0 = 0u, d_next1 = 0u, d_flags = 0u;
     double d_reward = 0.0, d_prob = 0.0;
+    // Addresses advance by one step's worth of elements per iteration (wave-uniform strides added to per-lane
+    // pointers) -- no per-step row * width multiplications.
+    const uint64_t step_rows = n_envs, step_cells = uint64_t(n_envs) * n_agents;
+    const uint32_t last_step = p.n_steps ? p.n_steps - 1u : 0u;
+    const bool odd = (x.g & 1u) != 0u;
+    const uint32_t lane_cell = e * n_agents + 2u * x.g;
+    gf64 reward_lane = reward_base + e, prob_lane = prob_base + e;      // the delayed step's row
+    gu8 done_lane = done_base + e, coll_lane = coll_base + e;
+    gu16 rec_lane = (gu16)(RECORD ? p.rec_local : nullptr) + lane_cell;
+    if (DENSE && L > 1) {   // even lanes of a group write reward and done, odd lanes prob and collision
+        reward_lane = odd ? prob_lane : reward_lane;
+        done_lane = odd ? coll_lane : done_lane;
+    }
+    asm volatile("" : "+v"(reward_lane), "+v"(prob_lane), "+v"(done_lane), "+v"(coll_lane), "+v"(rec_lane));
+
+    auto store_record = [&]() __attribute__((always_inline)) {
+        const uint32_t cells = d_next0 | (d_next1 << 16);
+        if (DENSE) {
+            *(gu32)rec_lane = cells;
+            *reward_lane = (L > 1 && odd) ? d_prob : d_reward;
+            *done_lane = uint8_t((L > 1 && odd) ? (d_flags >> 1) : (d_flags & 1u));
+            if (L == 1) {
+                *prob_lane = d_prob;
+                *coll_lane = uint8_t(d_flags >> 1);
+            }
+        } else {
+            if (FULL || (n_agents & 1u) == 0u) {
+                if (x.v0) *(gu32)rec_lane = cells;
+            } else {
+                if (x.v0) rec_lane[0] = uint16_t(d_next0);
+                if (x.v1) rec_lane[1] = uint16_t(d_next1);
+            }
+            if (leader) {
+                *reward_lane = d_reward;
+                *prob_lane = d_prob;
+                *done_lane = uint8_t(d_flags & 1u);
+                *coll_lane = uint8_t(d_flags >> 1);
+            }
+        }
+    };
+    auto advance_record = [&]() __attribute__((always_inline)) {
+        rec_lane += step_cells;
+        reward_lane += step_rows;
+        done_lane += step_rows;
+        if (!(DENSE && L > 1)) { prob_lane += step_rows; coll_lane += step_rows; }
+    };
+    const uint8_t *act_lane = STREAM ? p.actions + lane_cell : nullptr;   // the row being prefetched
 
     for (uint32_t s = 0; s < p.n_steps; ++s) {
         const uint64_t t = p.t + s;
-        const uint32_t row = s * n_envs + e;
         uint32_t act0, act1;
         if (STREAM) {
             act0 = raw & 0xFFu; act1 = raw >> 8;
             asm volatile("" : "+v"(act0), "+v"(act1));       // (1) pins the wait for `raw` here, ahead of (2)
-            if (s + 1 < p.n_steps) raw = load_actions_raw<FULL>(p.actions, row + n_envs, n_agents, x.g, x.v0, x.v1);
+            if (DENSE) {                                     // clamped, not guarded: the last step re-reads its own row
+                act_lane += (s + 1u < p.n_steps) ? step_cells : 0u;
+                raw = *reinterpret_cast<const uint16_t *>(act_lane);
+            } else if (s + 1 < p.n_steps) {
+                act_lane += step_cells;
+                raw = load_actions_raw<FULL>(act_lane, 0u, 0u, 0u, x.v0, x.v1);
+            }
         } else {   // policy stream: one Philox call covers agents 4q..4q+3; this lane needs words 2(g&1), 2(g&1)+1
             uint32_t w[4];
             const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | ((x.g >> 1) << 24);
@@ -108,14 +171,9 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
             act0 = __umulhi(hi ? w[2] : w[0], 5u);
             act1 = __umulhi(hi ? w[3] : w[1], 5u);
         }
-        if (RECORD && s > 0) {                               // (2) the previous step's outputs
-            if (live) store_cells<FULL>(p.rec_local, d_row, n_agents, x.g, x.v0, x.v1, d_next0, d_next1);
-            if (leader) {
-                reward_base[d_row] = d_reward;
-                prob_base[d_row] = d_prob;
-                done_base[d_row] = uint8_t(d_flags & 1u);
-                coll_base[d_row] = uint8_t(d_flags >> 1);
-            }
+        if (RECORD && (DENSE || s > 0)) {                    // (2) the previous step's outputs
+            store_record();
+            if (!DENSE || s > 0) advance_record();
         }
         uint32_t next0, next1;
         EnvOut o;
@@ -129,7 +187,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
         episodes += o.done ? 1u : 0u;
         collisions += o.collision ? 1u : 0u;
         if (RECORD) {
-            d_next0 = next0; d_next1 = next1; d_row = row; d_reward = o.reward; d_prob = o.prob;
+            d_next0 = next0; d_next1 = next1; d_reward = o.reward; d_prob = o.prob;
             d_flags = (o.done ? 1u : 0u) | (o.collision ? 2u : 0u);
         }
         const bool back = p.auto_reset && o.done;          // MapfEnv.reset(): start cells, no reseed
@@ -138,15 +196,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
         terminal = back ? start_terminal : o.next_terminal;
         STAMP(7);   // reset handling
     }
-    if (RECORD && p.n_steps > 0) {                           // flush the last step's outputs
-        if (live) store_cells<FULL>(p.rec_local, d_row, n_agents, x.g, x.v0, x.v1, d_next0, d_next1);
-        if (leader) {
-            reward_base[d_row] = d_reward;
-            prob_base[d_row] = d_prob;
-            done_base[d_row] = uint8_t(d_flags & 1u);
-            coll_base[d_row] = uint8_t(d_flags >> 1);
-        }
-    }
+    if (RECORD && p.n_steps > 0) store_record();             // flush the last step's outputs
 #ifdef MAPF_STAMPS
     if (live && x.lane == 0u && epi_p) {   // diagnostic build: segment sums replace the episode counts
         for (int k = 0; k < 8; ++k) epi_p[k] = uint32_t(st.seg[k]);
@@ -186,7 +236,8 @@ static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, hi
         if (block > rollout_max_block<L>()) block = rollout_max_block<L>();
         const uint64_t per_block = block / unsigned(L);
         const unsigned grid = unsigned((args.n_envs + per_block - 1) / per_block);
-        auto kern = lg_rollout_kernel<L, FULL, true, RECORD, STREAM>;
+        const bool dense = FULL && args.n_envs % per_block == 0;
+        auto kern = dense ? lg_rollout_kernel<L, FULL, true, RECORD, STREAM, FULL> : lg_rollout_kernel<L, FULL, true, RECORD, STREAM, false>;
         if (mv_bytes > 32 * 1024) {   // dynamic LDS beyond the default cap needs an explicit opt-in;
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),   // per device, so not cached
                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsBytes - kLdsReserve));
@@ -196,7 +247,10 @@ static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, hi
     } else {
         unsigned grid, block;
         lg_geometry(L, args.n_envs, grid, block);
-        hipLaunchKernelGGL((lg_rollout_kernel<L, FULL, false, RECORD, STREAM>), dim3(grid), dim3(block), 0, stream, args, A);
+        if (FULL && args.n_envs % (block / unsigned(L)) == 0)
+            hipLaunchKernelGGL((lg_rollout_kernel<L, FULL, false, RECORD, STREAM, FULL>), dim3(grid), dim3(block), 0, stream, args, A);
+        else
+            hipLaunchKernelGGL((lg_rollout_kernel<L, FULL, false, RECORD, STREAM, false>), dim3(grid), dim3(block), 0, stream, args, A);
     }
     return hipGetLastError();
 }
