@@ -1,0 +1,57 @@
+"""Derive profiles/traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py
+--no-cpu-baseline`.  usage: python tools/derive_traffic.py <fetch counter_collection.csv> <write ...csv> [out.json]
+
+hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per dispatch: the counters are KB per dispatch and gfx950 tallies
+128-byte read requests at 64 B (MI355X_MICROARCH.md, HBM / rocprofv3 section).  reset_kernel and
+fill_actions_kernel move known byte counts and are kept in the output as the calibration of that rule.
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+E, A, T = 65536, 8, 64
+BYTES_PER_AGENT_STEP = 5.0 + 18.0 / A   # SURVEY.md 8(d), same figure as bench.py bytes_per_agent_step
+ALGORITHMIC = {"lg_rollout_kernel": int(T * E * A * BYTES_PER_AGENT_STEP), "lg_step_kernel": int(E * A * BYTES_PER_AGENT_STEP)}
+
+
+def per_kernel(path, counter):
+    total, count, names = collections.Counter(), collections.Counter(), {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"]
+            for key in ("lg_rollout_kernel", "lg_step_kernel", "reset_kernel", "fill_actions_kernel"):
+                if key in name:
+                    total[key] += float(r["Counter_Value"])
+                    count[key] += 1
+                    names[key] = name
+    return {k: (total[k] / count[k], count[k], names[k]) for k in total}
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    out = {"_how": __doc__.strip().split("\n\n", 1)[1].replace("\n", " "), "kernels": {}}
+    for k in ("lg_rollout_kernel", "lg_step_kernel", "reset_kernel", "fill_actions_kernel"):
+        if k not in fetch or k not in write:
+            continue
+        f_kb, n, name = fetch[k]
+        w_kb = write[k][0]
+        entry = {"instance": name.split("(")[0].replace("void ", ""), "dispatches": n,
+                 "FETCH_SIZE_KB": round(f_kb, 2), "WRITE_SIZE_KB": round(w_kb, 2),
+                 "hbm_bytes_per_launch": int(round((2 * f_kb + w_kb) * 1024))}
+        if k in ALGORITHMIC:
+            entry["algorithmic_bytes_per_launch"] = ALGORITHMIC[k]
+        out["kernels"][k] = entry
+    dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "traffic.json")
+    with open(dst, "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out["kernels"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
