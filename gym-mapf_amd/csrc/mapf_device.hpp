@@ -144,7 +144,7 @@ __device__ __forceinline__ MoveEntry move_entry(const MoveEntry *__restrict__ mv
                                                 uint32_t action) {
     // CLAMP = false only for an LDS-resident table: an out-of-range LDS read returns zeros instead of faulting
     const uint32_t c = (!CLAMP || cell < n_cells) ? cell : n_cells - 1u;
-    return mv[c * 5u + action];
+    return mv[__umul24(c, 5u) + action];   // cells are 16-bit: one v_mad_u32_u24
 }
 
 template <int A, bool EXT_UNIFORMS>

@@ -106,37 +106,68 @@ __device__ __forceinline__ uint32_t group_reduce(uint32_t v, const LaneCtx<L> &x
 // ------------------------------------------------------------------ pair tests
 // min over agent pairs of xor (0 <=> equal).  dup: prev_i == prev_j (is_terminal, mapf_env.py:210-223);
 // vertex: next_i == next_j; swap: prev_i == next_j and prev_j == next_i (mapf_env.py:378-389).
+// PK = false: one 32-bit minimum per fact.  PK = true (every slot of the group is a real agent): each
+// accumulator is TWO 16-bit minima, one per half-word, fed by packed xors of the lane's cell pair against the
+// other lane's pair (straight and half-swapped) -- four agent pairs per v_pk_min_u16.
+template <bool PK>
 struct PairAcc {
     uint32_t dup = 0xFFFFFFFFu, vertex = 0xFFFFFFFFu, swap = 0xFFFFFFFFu;
+    static __device__ __forceinline__ bool hit(uint32_t acc) {
+        return PK ? ((acc & 0xFFFFu) == 0u || (acc >> 16) == 0u) : acc == 0u;
+    }
 };
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b)));
+}
+__device__ __forceinline__ uint32_t swap_halves(uint32_t v) { return __builtin_amdgcn_alignbit(v, v, 16); }
+
+// one rotation step, packed form: my cell pair (pk_prev, pk_next) against the pair of another group position
+template <bool DUP, bool MOVES>
+__device__ __forceinline__ void pair_apply_packed(uint32_t pk_prev, uint32_t pk_next, uint32_t o_prev, uint32_t o_next,
+                                                  PairAcc<true> &acc) {
+    const uint32_t o_prev_sw = swap_halves(o_prev);
+    if (DUP) acc.dup = pk_min_u16(acc.dup, pk_min_u16(pk_prev ^ o_prev, pk_prev ^ o_prev_sw));
+    if (MOVES) {
+        const uint32_t o_next_sw = swap_halves(o_next);
+        acc.vertex = pk_min_u16(acc.vertex, pk_min_u16(pk_next ^ o_next, pk_next ^ o_next_sw));
+        // half h of (next ^ o_prev) | (prev ^ o_next) is zero <=> my agent h and the other lane's agent h swap
+        const uint32_t same = (pk_next ^ o_prev) | (pk_prev ^ o_next);
+        const uint32_t cross = (pk_next ^ o_prev_sw) | (pk_prev ^ o_next_sw);
+        acc.swap = pk_min_u16(acc.swap, pk_min_u16(same, cross));
+    }
+}
 
 // one rotation step: my two agents against the two agents of group position `og`, whose packed cells
 // arrive in o_prev / o_next
 template <int L, bool FULL, bool DUP, bool MOVES>
 __device__ __forceinline__ void pair_apply(const LaneCtx<L> &x, uint32_t n_agents, uint32_t cur0, uint32_t cur1,
                                            uint32_t next0, uint32_t next1, uint32_t o_prev, uint32_t o_next,
-                                           uint32_t og, PairAcc &acc) {
-    const uint32_t op0 = o_prev & 0xFFFFu, op1 = o_prev >> 16;
-    uint32_t g0 = 0u, g1 = 0u, g2 = 0u, g3 = 0u;    // ghost masks: 1 forces "different"
-    if (!FULL) {
+                                           uint32_t og, PairAcc<FULL> &acc) {
+    if constexpr (FULL) {
+        pair_apply_packed<DUP, MOVES>(cur0 | (cur1 << 16), next0 | (next1 << 16), o_prev, o_next, acc);
+    } else {
+        const uint32_t op0 = o_prev & 0xFFFFu, op1 = o_prev >> 16;
+        // ghost masks: 1 forces "different"
         const bool o0 = 2u * og < n_agents, o1 = 2u * og + 1u < n_agents;
-        g0 = (x.v0 && o0) ? 0u : 1u; g1 = (x.v0 && o1) ? 0u : 1u;
-        g2 = (x.v1 && o0) ? 0u : 1u; g3 = (x.v1 && o1) ? 0u : 1u;
-    }
-    if (DUP) {
-        acc.dup = min(acc.dup, min((cur0 ^ op0) | g0, (cur0 ^ op1) | g1));
-        acc.dup = min(acc.dup, min((cur1 ^ op0) | g2, (cur1 ^ op1) | g3));
-    }
-    if (MOVES) {
-        const uint32_t on0 = o_next & 0xFFFFu, on1 = o_next >> 16;
-        const uint32_t fwd0 = cur0 | (next0 << 16), fwd1 = cur1 | (next1 << 16);
-        // rev_k = next_k | prev_k << 16 of the other lane: one v_perm_b32 each from the two packed words
-        const uint32_t rev0 = __builtin_amdgcn_perm(o_prev, o_next, 0x05040100u);
-        const uint32_t rev1 = __builtin_amdgcn_perm(o_prev, o_next, 0x07060302u);
-        acc.vertex = min(acc.vertex, min((next0 ^ on0) | g0, (next0 ^ on1) | g1));
-        acc.vertex = min(acc.vertex, min((next1 ^ on0) | g2, (next1 ^ on1) | g3));
-        acc.swap = min(acc.swap, min((fwd0 ^ rev0) | g0, (fwd0 ^ rev1) | g1));
-        acc.swap = min(acc.swap, min((fwd1 ^ rev0) | g2, (fwd1 ^ rev1) | g3));
+        const uint32_t g0 = (x.v0 && o0) ? 0u : 1u, g1 = (x.v0 && o1) ? 0u : 1u;
+        const uint32_t g2 = (x.v1 && o0) ? 0u : 1u, g3 = (x.v1 && o1) ? 0u : 1u;
+        if (DUP) {
+            acc.dup = min(acc.dup, min((cur0 ^ op0) | g0, (cur0 ^ op1) | g1));
+            acc.dup = min(acc.dup, min((cur1 ^ op0) | g2, (cur1 ^ op1) | g3));
+        }
+        if (MOVES) {
+            const uint32_t on0 = o_next & 0xFFFFu, on1 = o_next >> 16;
+            const uint32_t fwd0 = cur0 | (next0 << 16), fwd1 = cur1 | (next1 << 16);
+            // rev_k = next_k | prev_k << 16 of the other lane: one v_perm_b32 each from the two packed words
+            const uint32_t rev0 = __builtin_amdgcn_perm(o_prev, o_next, 0x05040100u);
+            const uint32_t rev1 = __builtin_amdgcn_perm(o_prev, o_next, 0x07060302u);
+            acc.vertex = min(acc.vertex, min((next0 ^ on0) | g0, (next0 ^ on1) | g1));
+            acc.vertex = min(acc.vertex, min((next1 ^ on0) | g2, (next1 ^ on1) | g3));
+            acc.swap = min(acc.swap, min((fwd0 ^ rev0) | g0, (fwd0 ^ rev1) | g1));
+            acc.swap = min(acc.swap, min((fwd1 ^ rev0) | g2, (fwd1 ^ rev1) | g3));
+        }
     }
 }
 
@@ -146,7 +177,7 @@ template <int L, int S, bool FULL, bool DUP, bool MOVES>
 struct PairRounds {
     static __device__ __forceinline__ void run(const LaneCtx<L> &x, uint32_t n_agents, uint32_t cur0, uint32_t cur1,
                                                uint32_t next0, uint32_t next1, uint32_t pk_prev, uint32_t pk_next,
-                                               PairAcc &acc) {
+                                               PairAcc<FULL> &acc) {
         if constexpr (L >= 32) {
 #pragma unroll 2
             for (uint32_t s = 1; s <= uint32_t(L / 2); ++s) {
@@ -168,17 +199,26 @@ struct PairRounds {
 
 // all pairs of the env: my own two agents, then rotations 1..L/2 (every unordered lane pair is met)
 template <int L, bool FULL, bool DUP, bool MOVES>
-__device__ __forceinline__ PairAcc pair_tests(const LaneCtx<L> &x, uint32_t n_agents, uint32_t cur0, uint32_t cur1,
-                                              uint32_t next0, uint32_t next1) {
-    PairAcc acc;
-    const uint32_t ghost = (FULL || x.v1) ? 0u : 1u;
-    if (DUP) acc.dup = (cur0 ^ cur1) | ghost;
-    if (MOVES) {
-        acc.vertex = (next0 ^ next1) | ghost;
-        acc.swap = ((cur0 | (next0 << 16)) ^ (next1 | (cur1 << 16))) | ghost;
+__device__ __forceinline__ PairAcc<FULL> pair_tests(const LaneCtx<L> &x, uint32_t n_agents, uint32_t cur0, uint32_t cur1,
+                                                    uint32_t next0, uint32_t next1) {
+    PairAcc<FULL> acc;
+    const uint32_t pk_prev = cur0 | (cur1 << 16), pk_next = next0 | (next1 << 16);
+    if constexpr (FULL) {   // my own pair: both halves carry the same test
+        const uint32_t prev_sw = swap_halves(pk_prev), next_sw = swap_halves(pk_next);
+        if (DUP) acc.dup = pk_prev ^ prev_sw;
+        if (MOVES) {
+            acc.vertex = pk_next ^ next_sw;
+            acc.swap = (pk_next ^ prev_sw) | (pk_prev ^ next_sw);
+        }
+    } else {
+        const uint32_t ghost = x.v1 ? 0u : 1u;
+        if (DUP) acc.dup = (cur0 ^ cur1) | ghost;
+        if (MOVES) {
+            acc.vertex = (next0 ^ next1) | ghost;
+            acc.swap = ((cur0 | (next0 << 16)) ^ (next1 | (cur1 << 16))) | ghost;
+        }
     }
-    PairRounds<L, 1, FULL, DUP, MOVES>::run(x, n_agents, cur0, cur1, next0, next1, cur0 | (cur1 << 16),
-                                             next0 | (next1 << 16), acc);
+    PairRounds<L, 1, FULL, DUP, MOVES>::run(x, n_agents, cur0, cur1, next0, next1, pk_prev, pk_next, acc);
     return acc;
 }
 
@@ -186,9 +226,9 @@ __device__ __forceinline__ PairAcc pair_tests(const LaneCtx<L> &x, uint32_t n_ag
 template <int L, bool FULL>
 __device__ __forceinline__ bool lg_is_terminal(const LaneCtx<L> &x, uint32_t n_agents, uint32_t cur0, uint32_t cur1,
                                                uint32_t goal0, uint32_t goal1) {
-    const PairAcc acc = pair_tests<L, FULL, true, false>(x, n_agents, cur0, cur1, 0u, 0u);
+    const PairAcc<FULL> acc = pair_tests<L, FULL, true, false>(x, n_agents, cur0, cur1, 0u, 0u);
     const bool off_goal = ((FULL || x.v0) && cur0 != goal0) || ((FULL || x.v1) && cur1 != goal1);
-    const uint32_t flags = group_reduce<L, false>((acc.dup == 0u ? 1u : 0u) | (off_goal ? 2u : 0u), x);
+    const uint32_t flags = group_reduce<L, false>((PairAcc<FULL>::hit(acc.dup) ? 1u : 0u) | (off_goal ? 2u : 0u), x);
     return (flags & 1u) != 0u || (flags & 2u) == 0u;
 }
 
@@ -228,16 +268,15 @@ __device__ __forceinline__ double prob_product(const LaneCtx<L> &x, double q0, d
     if constexpr (L == 1) {
         return __dmul_rn(__dmul_rn(1.0, q0), q1);
     } else if constexpr (L <= 16) {
-        // stage k: lane k continues the product it receives from lane k-1; afterwards lane L-1 holds the total
+        // stage k: every lane continues the product it receives from the lane before it.  Lane k's value is the
+        // true prefix after stage k (by induction from lane 0's stage-0 value; what other lanes hold at that point
+        // is never read by a lane that matters), so after stage L-1 lane L-1 holds the total -- no selects.
         double run = __dmul_rn(__dmul_rn(1.0, q0), q1);              // correct in lane 0
-        uint32_t g = x.g;
-        asm volatile("" : "+v"(g));     // keep the lane predicates below out of loop-invariant SGPR pairs
 #pragma unroll
         for (int k = 1; k < L; ++k) {
             const uint32_t lo = from_prev_lane<L>(uint32_t(__double2loint(run)));
             const uint32_t hi = from_prev_lane<L>(uint32_t(__double2hiint(run)));
-            const double cont = __dmul_rn(__dmul_rn(__hiloint2double(int(hi), int(lo)), q0), q1);
-            run = (g == uint32_t(k)) ? cont : run;
+            run = __dmul_rn(__dmul_rn(__hiloint2double(int(hi), int(lo)), q0), q1);
         }
         // total sits in lane L-1: hand it to everyone
         return group_bcast_f64<L, L - 1>(run, x);
@@ -291,13 +330,13 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const MoveEntr
 
     STAMP(2);   // slip_move (gather wait, LDS rows, sampling)
     // --- pair tests, then per-env facts: one flag word per lane, OR-reduced over the group
-    const PairAcc acc = pair_tests<L, FULL, !KNOWN_TERM, true>(x, n_agents, cur0, cur1, next0, next1);
+    const PairAcc<FULL> acc = pair_tests<L, FULL, !KNOWN_TERM, true>(x, n_agents, cur0, cur1, next0, next1);
     STAMP(3);   // pair tests
     const bool off_goal_next = (v0 && next0 != goal0) || (v1 && next1 != goal1);
-    uint32_t flags = (acc.vertex == 0u ? 1u : 0u) | (acc.swap == 0u ? 2u : 0u) | (off_goal_next ? 4u : 0u);
+    uint32_t flags = (PairAcc<FULL>::hit(acc.vertex) ? 1u : 0u) | (PairAcc<FULL>::hit(acc.swap) ? 2u : 0u) | (off_goal_next ? 4u : 0u);
     if (!KNOWN_TERM) {
         const bool off_goal = (v0 && cur0 != goal0) || (v1 && cur1 != goal1);
-        flags |= (acc.dup == 0u ? 8u : 0u) | (off_goal ? 16u : 0u);
+        flags |= (PairAcc<FULL>::hit(acc.dup) ? 8u : 0u) | (off_goal ? 16u : 0u);
     }
     flags = group_reduce<L, false>(flags, x);
     bool was_terminal = prev_terminal;
