@@ -287,16 +287,52 @@ __device__ __forceinline__ double prob_product(const LaneCtx<L> &x, double q0, d
 
 struct EnvOut {
     double reward, prob;
-    bool done, collision, was_terminal;
-    bool next_terminal;          // is_terminal of the state step() returned (used by the rollout loop)
+    uint32_t status;             // kDone | kCollision | kNextTerminal
+    bool was_terminal;
+    __device__ __forceinline__ bool done() const { return (status & 1u) != 0u; }
+    __device__ __forceinline__ bool collision() const { return (status & 2u) != 0u; }
+    // is_terminal of the state step() returned (the rollout loop carries it to the next step)
+    __device__ __forceinline__ bool next_terminal() const { return (status & 4u) != 0u; }
 };
+
+// Outcome of a transition as a function of the group's reduced facts f = vertex | swap << 1 | off_goal_next << 2
+// (calc_transition_reward_from_local_states, mapf_env.py:225-235: collision before goal; is_terminal,
+// :210-223: a swap alone leaves a non-terminal state): status bits done | collision << 1 | next_terminal << 2.
+__host__ __device__ constexpr uint32_t outcome_status(uint32_t f) {
+    const bool vertex = (f & 1u) != 0u, coll = (f & 3u) != 0u, goal_next = (f & 4u) == 0u;
+    return ((coll || goal_next) ? 1u : 0u) | (coll ? 2u : 0u) | ((vertex || goal_next) ? 4u : 0u);
+}
+__host__ __device__ constexpr uint32_t outcome_status_table() {   // 3 bits per f
+    uint32_t t = 0u;
+    for (uint32_t f = 0; f < 8u; ++f) t |= outcome_status(f) << (3u * f);
+    return t;
+}
+constexpr uint32_t kTerminalStatus = 5u;   // a step from a terminal state: done, no collision, still terminal
+
+// LDS outcome table of the rollout kernel (Makespan: the living reward is a constant, so the whole reward is a
+// function of f): rows 0..7 = f, rows 8..15 = "the state was terminal" (mapf_env.py:239-240: reward 0, done).
+struct OutcomeRow {
+    double reward;
+    uint32_t status, pad;
+};
+__device__ __forceinline__ void stage_outcome_table(const EnvConsts &c, OutcomeRow *lds) {   // before a __syncthreads()
+    const uint32_t i = threadIdx.x;
+    if (i < 16u) {
+        const uint32_t st = outcome_status(i & 7u);
+        const double r = (st & 2u) ? __dadd_rn(c.r_clash, c.r_living) : ((st & 1u) ? __dadd_rn(c.r_goal, c.r_living) : c.r_living);
+        lds[i].reward = i < 8u ? r : 0.0;
+        lds[i].status = i < 8u ? st : kTerminalStatus;
+        lds[i].pad = 0u;
+    }
+}
 
 // One transition for the group's env.  cur0/cur1: my agents' cells (ghost slots hold 0).  Every lane of the
 // group returns the same per-env results; next0/next1 are this lane's.  KNOWN_TERM: the caller already knows
 // is_terminal(prev) (rollout carries it from step to step); otherwise it is derived here.
-template <int L, bool FULL, bool EXT_UNIFORMS, bool KNOWN_TERM, bool MV_IN_LDS = false>
+template <int L, bool FULL, bool EXT_UNIFORMS, bool KNOWN_TERM, bool MV_IN_LDS = false, bool OUTCOME_LDS = false>
 __device__ __forceinline__ void lg_transition(const EnvConsts &c, const MoveEntry *__restrict__ mv,
-                                              const SlipRow *lds_slip, const LaneCtx<L> &x, uint32_t n_agents,
+                                              const SlipRow *lds_slip, const OutcomeRow *lds_outcome,
+                                              const LaneCtx<L> &x, uint32_t n_agents,
                                               uint32_t cur0, uint32_t cur1, uint32_t goal0, uint32_t goal1,
                                               uint32_t act0_in, uint32_t act1_in, double u0, double u1,
                                               uint64_t env_id, uint64_t t, const Words4 rng, bool prev_terminal,
@@ -347,27 +383,28 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const MoveEntr
     const double p = prob_product<L>(x, q0, q1);
 
     STAMP(5);   // prob chain
-    // _living_reward: mapf_env.py:436-446
-    double living = c.r_living;
-    if (c.criteria == 1u) {
-        const uint32_t mine = ((v0 && cur0 == goal0 && act0 == 0u) ? 1u : 0u) + ((v1 && cur1 == goal1 && act1 == 0u) ? 1u : 0u);
-        const int stayed = int(group_reduce<L, true>(mine, x));
-        living = __dmul_rn(double(int(n_agents) - stayed), c.r_living);
-    }
-    // calc_transition_reward_from_local_states: mapf_env.py:225-235 (collision before goal)
-    const bool vertex = (flags & 1u) != 0u, coll = (flags & 3u) != 0u, goal_next = (flags & 4u) == 0u;
+    const uint32_t f = flags & 7u;
     out.was_terminal = was_terminal;
-    if (was_terminal) {   // mapf_env.py:239-240 -- (s, 0, True, {"prob": 0}), nothing drawn
-        next0 = cur0; next1 = cur1;
-        out.reward = 0.0; out.prob = 0.0; out.done = true; out.collision = false;
-        out.next_terminal = true;
+    if (OUTCOME_LDS && c.criteria == 0u) {
+        const OutcomeRow row = lds_outcome[f | (was_terminal ? 8u : 0u)];
+        out.reward = row.reward;
+        out.status = row.status;
     } else {
-        out.prob = p;
-        out.collision = coll;
-        out.done = coll || goal_next;
-        out.reward = coll ? __dadd_rn(c.r_clash, living) : (goal_next ? __dadd_rn(c.r_goal, living) : living);
-        out.next_terminal = vertex || goal_next;   // a swap leaves a non-terminal state (mapf_env.py:210-223)
+        // _living_reward: mapf_env.py:436-446
+        double living = c.r_living;
+        if (c.criteria == 1u) {
+            const uint32_t mine = ((v0 && cur0 == goal0 && act0 == 0u) ? 1u : 0u) + ((v1 && cur1 == goal1 && act1 == 0u) ? 1u : 0u);
+            const int stayed = int(group_reduce<L, true>(mine, x));
+            living = __dmul_rn(double(int(n_agents) - stayed), c.r_living);
+        }
+        // calc_transition_reward_from_local_states: mapf_env.py:225-235 (collision before goal)
+        const uint32_t st = (outcome_status_table() >> (3u * f)) & 7u;
+        const double r = (st & 2u) ? __dadd_rn(c.r_clash, living) : ((st & 1u) ? __dadd_rn(c.r_goal, living) : living);
+        out.reward = was_terminal ? 0.0 : r;           // mapf_env.py:239-240 -- (s, 0, True, {"prob": 0}), nothing drawn
+        out.status = was_terminal ? kTerminalStatus : st;
     }
+    out.prob = was_terminal ? 0.0 : p;
+    if (was_terminal) { next0 = cur0; next1 = cur1; }
 }
 
 // ---- memory access.  All element indices are 32-bit and turned into 32-bit BYTE offsets from a uniform base

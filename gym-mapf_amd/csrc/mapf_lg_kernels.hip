@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
 #endif
     Words4 rng{0u, 0u, 0u, 0u};
     if (!EXT_UNIFORMS && p.c.need_rng) rng = slip_words(p.c, p.env_id_offset + e, p.t >> 2, x.g, 0u, 0u);
-    lg_transition<L, FULL, EXT_UNIFORMS, false>(p.c, p.mv, rows, x, n_agents, cur0, cur1, goal0, goal1, act0, act1,
+    lg_transition<L, FULL, EXT_UNIFORMS, false>(p.c, p.mv, rows, nullptr, x, n_agents, cur0, cur1, goal0, goal1, act0, act1,
                                                 u0, u1, p.env_id_offset + e, p.t, rng, false, next0, next1, o STAMP_ARG);
     if (!live) return;
 
@@ -38,11 +38,11 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
     if (x.g == 0u) {
         if (p.out_reward) *at(p.out_reward, e) = o.reward;
         if (p.out_prob) *at(p.out_prob, e) = o.prob;
-        if (p.out_done) *at(p.out_done, e) = o.done ? 1 : 0;
-        if (p.out_collision) *at(p.out_collision, e) = o.collision ? 1 : 0;
+        if (p.out_done) *at(p.out_done, e) = o.done() ? 1 : 0;
+        if (p.out_collision) *at(p.out_collision, e) = o.collision() ? 1 : 0;
         if (p.out_was_terminal) *at(p.out_was_terminal, e) = o.was_terminal ? 1 : 0;
     }
-    if (p.auto_reset && o.done) {
+    if (p.auto_reset && o.done()) {
         uint32_t s0, s1;
         load_pair<uint16_t>(p.start, p.start_broadcast ? 0 : e, n_agents, x.g, x.v0, x.v1, s0, s1);
         store_cells(p.state, e, n_agents, x.g, x.v0, x.v1, s0, s1);

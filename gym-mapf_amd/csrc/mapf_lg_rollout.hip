@@ -41,6 +41,7 @@ __device__ __forceinline__ uint32_t load_actions_raw(const uint8_t *base, uint32
 template <int L, bool FULL, bool MV_LDS, bool RECORD, bool STREAM, bool DENSE>
 __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
     __shared__ SlipRow slip[8];
+    __shared__ OutcomeRow outcome[16];
     extern __shared__ __attribute__((aligned(16))) MoveEntry lds_mv[];
     bool live_rt;
     LaneCtx<L> x = lane_ctx<L>(n_agents, p.n_envs, live_rt);
@@ -57,12 +58,13 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
         const uint32_t n_words = p.c.n_cells * 5u;
         for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) lds_mv[w] = p.mv[w];
     }
+    stage_outcome_table(p.c, outcome);
     stage_slip_table(p.slip, slip);   // ends with __syncthreads()
     const MoveEntry *mv = MV_LDS ? lds_mv : p.mv;
 
     // is_terminal is carried from step to step instead of re-deriving it from the cells every step
-    bool terminal = lg_is_terminal<L, FULL>(x, n_agents, cur0, cur1, goal0, goal1);
-    const bool start_terminal = p.auto_reset ? lg_is_terminal<L, FULL>(x, n_agents, start0, start1, goal0, goal1) : false;
+    uint32_t terminal = lg_is_terminal<L, FULL>(x, n_agents, cur0, cur1, goal0, goal1) ? 1u : 0u;   // an integer: no wave-mask phi
+    const uint32_t start_terminal = (p.auto_reset && lg_is_terminal<L, FULL>(x, n_agents, start0, start1, goal0, goal1)) ? 1u : 0u;
 
     // per-env totals and the scalar trajectory arrays: their addresses are parked in VGPRs so that seven base
     // pointers do not occupy SGPRs across the step loop (it already keeps ~100 scalars live).  They stay typed as
@@ -180,20 +182,20 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
         STAMP(0);   // loop top: action fetch / policy / delayed stores
         // one slip-stream call serves four steps: refresh when t is a multiple of 4 (and at the first step)
         if (p.c.need_rng && ((t & 3u) == 0u || s == 0u)) rng = slip_words(p.c, env_id, t >> 2, x.g, 0u, 0u);
-        lg_transition<L, FULL, false, true, MV_LDS>(p.c, mv, slip, x, n_agents, cur0, cur1, goal0, goal1, act0, act1, 0.0, 0.0,
-                                            env_id, t, rng, terminal, next0, next1, o STAMP_ARG);
+        lg_transition<L, FULL, false, true, MV_LDS, true>(p.c, mv, slip, outcome, x, n_agents, cur0, cur1, goal0, goal1, act0, act1, 0.0, 0.0,
+                                            env_id, t, rng, terminal != 0u, next0, next1, o STAMP_ARG);
         STAMP(6);   // reward / selects
         ret = __dadd_rn(ret, o.reward);
-        episodes += o.done ? 1u : 0u;
-        collisions += o.collision ? 1u : 0u;
+        episodes += o.status & 1u;
+        collisions += (o.status >> 1) & 1u;
         if (RECORD) {
             d_next0 = next0; d_next1 = next1; d_reward = o.reward; d_prob = o.prob;
-            d_flags = (o.done ? 1u : 0u) | (o.collision ? 2u : 0u);
+            d_flags = o.status & 3u;                       // done | collision << 1
         }
-        const bool back = p.auto_reset && o.done;          // MapfEnv.reset(): start cells, no reseed
+        const bool back = p.auto_reset && (o.status & 1u) != 0u;   // MapfEnv.reset(): start cells, no reseed
         cur0 = back ? start0 : next0;
         cur1 = back ? start1 : next1;
-        terminal = back ? start_terminal : o.next_terminal;
+        terminal = back ? start_terminal : (o.status >> 2);
         STAMP(7);   // reset handling
     }
     if (RECORD && p.n_steps > 0) store_record();             // flush the last step's outputs
@@ -212,8 +214,9 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     }
 }
 
-// LDS budget for the move table: the CU has 160 KiB; keep room for the slip rows
+// LDS budget for the move table: the CU has 160 KiB; keep room for the slip rows and the outcome table
 static constexpr size_t kLdsBytes = 160 * 1024, kLdsReserve = 1024;
+static_assert(sizeof(SlipRow) * 8 + sizeof(OutcomeRow) * 16 <= kLdsReserve, "static LDS of the rollout kernel");
 
 // Largest move table that is staged into LDS (tuning knob: MAPF_MV_LDS_MAX_BYTES, default = what leaves room
 // for two resident blocks per CU; a table that allows only one block per CU starves the SIMDs of waves).
