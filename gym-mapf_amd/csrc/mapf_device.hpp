@@ -76,7 +76,8 @@ __device__ __forceinline__ void stage_slip_table(const SlipRow *__restrict__ src
 // the LDS row holding that list's probabilities and cumulative thresholds.  `mant` is the 53-bit integer
 // of the uniform (u = mant * 2^-53), used when !EXT_UNIFORMS.
 __device__ __forceinline__ uint32_t entry_cell(const MoveEntry &entry, uint32_t idx) {   // list slot idx = 0, 1, 2
-    return ((idx == 2u ? entry.y : entry.x) >> ((idx & 1u) * 16u)) & 0xFFFFu;
+    // half-word idx of {y, x}, zero-extended: one v_perm_b32 with selector bytes (0x0c = constant 0, 2*idx+1, 2*idx)
+    return __builtin_amdgcn_perm(entry.y, entry.x, 0x0C0C0100u + idx * 0x0202u);
 }
 __device__ __forceinline__ uint32_t entry_code(const MoveEntry &entry) { return (entry.y >> 16) & 7u; }
 
@@ -144,7 +145,9 @@ __device__ __forceinline__ MoveEntry move_entry(const MoveEntry *__restrict__ mv
                                                 uint32_t action) {
     // CLAMP = false only for an LDS-resident table: an out-of-range LDS read returns zeros instead of faulting
     const uint32_t c = (!CLAMP || cell < n_cells) ? cell : n_cells - 1u;
-    return mv[__umul24(c, 5u) + action];   // cells are 16-bit: one v_mad_u32_u24
+    uint32_t row = __umul24(c, 5u) + action;   // cells are 16-bit: one v_mad_u32_u24
+    asm volatile("" : "+v"(row));             // keep row * 16 + base as one shift-add (not c * 80 + action * 16 + base)
+    return mv[row];
 }
 
 template <int A, bool EXT_UNIFORMS>

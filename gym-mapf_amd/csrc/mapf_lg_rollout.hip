@@ -109,6 +109,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     const uint64_t step_rows = n_envs, step_cells = uint64_t(n_envs) * n_agents;
     const uint32_t last_step = p.n_steps ? p.n_steps - 1u : 0u;
     const bool odd = (x.g & 1u) != 0u;
+    const uint32_t flag_bit = x.g & 1u;
     const uint32_t lane_cell = e * n_agents + 2u * x.g;
     gf64 reward_lane = reward_base + e, prob_lane = prob_base + e;      // the delayed step's row
     gu8 done_lane = done_base + e, coll_lane = coll_base + e;
@@ -124,7 +125,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
         if (DENSE) {
             *(gu32)rec_lane = cells;
             *reward_lane = (L > 1 && odd) ? d_prob : d_reward;
-            *done_lane = uint8_t((L > 1 && odd) ? (d_flags >> 1) : (d_flags & 1u));
+            *done_lane = uint8_t(L > 1 ? (d_flags >> flag_bit) & 1u : d_flags & 1u);   // flag_bit: 1 in odd lanes
             if (L == 1) {
                 *prob_lane = d_prob;
                 *coll_lane = uint8_t(d_flags >> 1);
