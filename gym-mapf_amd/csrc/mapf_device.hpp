@@ -5,6 +5,7 @@
 // Float64 arithmetic follows the reference operation by operation (mapf_env.py:163-184, :225-266, :436-446); every
 // add/mul that decides a bit is an explicit round-to-nearest intrinsic so no FMA contraction can change it.
 #pragma once
+#include <cstddef>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mapf_kernels.hpp"
@@ -80,6 +81,9 @@ __device__ __forceinline__ uint32_t entry_cell(const MoveEntry &entry, uint32_t 
     return __builtin_amdgcn_perm(entry.y, entry.x, 0x0C0C0100u + idx * 0x0202u);
 }
 __device__ __forceinline__ uint32_t entry_code(const MoveEntry &entry) { return (entry.y >> 16) & 7u; }
+// byte offset of that code's SlipRow (code * sizeof(SlipRow), packed beside the code by the host)
+__device__ __forceinline__ uint32_t entry_row_offset(const MoveEntry &entry) { return entry.y >> 19; }
+static_assert(offsetof(SlipRow, q) == 0, "entry_row_offset() addresses q[] directly");
 
 template <bool EXT_UNIFORMS>
 __device__ __forceinline__ void slip_move(const SlipRow *lds_slip, const MoveEntry &entry, uint64_t mant, double u,
@@ -106,11 +110,13 @@ __device__ __forceinline__ void slip_move_hi(const SlipRow *lds_slip, const Move
                                              double &q, uint32_t &tie_dist) {
     // the thresholds travel with the move-table row: no LDS access until the sampled probability is fetched
     const uint32_t t0 = entry.z & 0xFFFFu, t1 = entry.z >> 16, t2 = entry.w & 0xFFFFu;
-    const bool b0 = hi < t0, b1 = hi < t1, b2 = hi < t2;
-    tie_dist = min(hi ^ t0, min(hi ^ t1, hi ^ t2));   // 0 <=> hi ties with a threshold (integer, no wave-mask booleans)
+    // one subtraction per threshold serves both questions: negative <=> hi < t, zero <=> a tie
+    const uint32_t d0 = hi - t0, d1 = hi - t1, d2 = hi - t2;
+    const bool b0 = int32_t(d0) < 0, b1 = int32_t(d1) < 0, b2 = int32_t(d2) < 0;
+    tie_dist = min(d0, min(d1, d2));   // 0 <=> hi ties with a threshold (integer, no wave-mask booleans)
     const uint32_t idx = b0 ? 0u : (b1 ? 1u : (b2 ? 2u : 0u));
     next = entry_cell(entry, idx);
-    q = lds_slip[entry_code(entry)].q[idx];
+    q = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lds_slip) + entry_row_offset(entry) + idx * 8u);
 }
 
 // Slip stream (oracle/philox.py): one call with rslot = refine = 0 yields the four words that serve agents

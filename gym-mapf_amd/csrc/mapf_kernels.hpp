@@ -10,8 +10,9 @@ namespace mapf {
 // Built on the host by replaying single_agent_movements (mapf_env.py:163-184): drop p <= 0, merge equal
 // cells in first-seen order with old + new, then cumsum left to right.
 // Move table row of one (cell, action): everything the fast sampling path needs in ONE 16-byte read.
-//   x = c0 | c1 << 16, y = c2 | code << 16 : the merged movement list's cells in list order + the equality code of
-//       the three candidates (selects the SlipRow with the list's probabilities / full-width thresholds);
+//   x = c0 | c1 << 16, y = c2 | code << 16 | (code * sizeof(SlipRow)) << 19 : the merged movement list's cells in
+//       list order + the equality code of the three candidates (selects the SlipRow with the list's probabilities /
+//       full-width thresholds; also pre-scaled to that row's byte offset);
 //   z = t0 | t1 << 16, w = t2              : top 16 bits of the cumulative thresholds, saturated to 65535 (0 past the
 //       end of the list).  hi16 < t_k decides `cum[k] > u` unless hi16 == t_k; that tie (which the saturation makes
 //       slightly more frequent: hi16 = 65535 against a threshold of 1.0) is resolved by the exact 53-bit path.

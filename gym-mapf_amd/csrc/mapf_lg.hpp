@@ -368,7 +368,9 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const MoveEntr
     // --- pair tests, then per-env facts: one flag word per lane, OR-reduced over the group
     const PairAcc<FULL> acc = pair_tests<L, FULL, !KNOWN_TERM, true>(x, n_agents, cur0, cur1, next0, next1);
     STAMP(3);   // pair tests
-    const bool off_goal_next = (v0 && next0 != goal0) || (v1 && next1 != goal1);
+    // (full groups: both cells in one compare of the packed pairs)
+    const bool off_goal_next = FULL ? (next0 | (next1 << 16)) != (goal0 | (goal1 << 16))
+                                    : (v0 && next0 != goal0) || (v1 && next1 != goal1);
     uint32_t flags = (PairAcc<FULL>::hit(acc.vertex) ? 1u : 0u) | (PairAcc<FULL>::hit(acc.swap) ? 2u : 0u) | (off_goal_next ? 4u : 0u);
     if (!KNOWN_TERM) {
         const bool off_goal = (v0 && cur0 != goal0) || (v1 && cur1 != goal1);
