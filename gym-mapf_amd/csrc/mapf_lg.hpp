@@ -287,27 +287,21 @@ __device__ __forceinline__ double prob_product(const LaneCtx<L> &x, double q0, d
 
 struct EnvOut {
     double reward, prob;
-    uint32_t status;             // kDone | kCollision | kNextTerminal
+    uint32_t status;             // one 0/1 fact per BYTE (sub-dword operand selects read them for free):
+                                 // byte 0 done, byte 1 collision, byte 2 is_terminal of the returned state
     bool was_terminal;
-    __device__ __forceinline__ bool done() const { return (status & 1u) != 0u; }
-    __device__ __forceinline__ bool collision() const { return (status & 2u) != 0u; }
-    // is_terminal of the state step() returned (the rollout loop carries it to the next step)
-    __device__ __forceinline__ bool next_terminal() const { return (status & 4u) != 0u; }
+    __device__ __forceinline__ bool done() const { return (status & 0xFFu) != 0u; }
+    __device__ __forceinline__ bool collision() const { return (status & 0xFF00u) != 0u; }
 };
 
 // Outcome of a transition as a function of the group's reduced facts f = vertex | swap << 1 | off_goal_next << 2
 // (calc_transition_reward_from_local_states, mapf_env.py:225-235: collision before goal; is_terminal,
-// :210-223: a swap alone leaves a non-terminal state): status bits done | collision << 1 | next_terminal << 2.
+// :210-223: a swap alone leaves a non-terminal state): done | collision << 8 | next_terminal << 16 (EnvOut::status).
 __host__ __device__ constexpr uint32_t outcome_status(uint32_t f) {
     const bool vertex = (f & 1u) != 0u, coll = (f & 3u) != 0u, goal_next = (f & 4u) == 0u;
-    return ((coll || goal_next) ? 1u : 0u) | (coll ? 2u : 0u) | ((vertex || goal_next) ? 4u : 0u);
+    return ((coll || goal_next) ? 1u : 0u) | (coll ? 0x100u : 0u) | ((vertex || goal_next) ? 0x10000u : 0u);
 }
-__host__ __device__ constexpr uint32_t outcome_status_table() {   // 3 bits per f
-    uint32_t t = 0u;
-    for (uint32_t f = 0; f < 8u; ++f) t |= outcome_status(f) << (3u * f);
-    return t;
-}
-constexpr uint32_t kTerminalStatus = 5u;   // a step from a terminal state: done, no collision, still terminal
+constexpr uint32_t kTerminalStatus = 0x10001u;   // a step from a terminal state: done, no collision, still terminal
 
 // LDS outcome table of the rollout kernel (Makespan: the living reward is a constant, so the whole reward is a
 // function of f): rows 0..7 = f, rows 8..15 = "the state was terminal" (mapf_env.py:239-240: reward 0, done).
@@ -319,7 +313,7 @@ __device__ __forceinline__ void stage_outcome_table(const EnvConsts &c, OutcomeR
     const uint32_t i = threadIdx.x;
     if (i < 16u) {
         const uint32_t st = outcome_status(i & 7u);
-        const double r = (st & 2u) ? __dadd_rn(c.r_clash, c.r_living) : ((st & 1u) ? __dadd_rn(c.r_goal, c.r_living) : c.r_living);
+        const double r = (st & 0x100u) ? __dadd_rn(c.r_clash, c.r_living) : ((st & 1u) ? __dadd_rn(c.r_goal, c.r_living) : c.r_living);
         lds[i].reward = i < 8u ? r : 0.0;
         lds[i].status = i < 8u ? st : kTerminalStatus;
         lds[i].pad = 0u;
@@ -400,8 +394,9 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const MoveEntr
             living = __dmul_rn(double(int(n_agents) - stayed), c.r_living);
         }
         // calc_transition_reward_from_local_states: mapf_env.py:225-235 (collision before goal)
-        const uint32_t st = (outcome_status_table() >> (3u * f)) & 7u;
-        const double r = (st & 2u) ? __dadd_rn(c.r_clash, living) : ((st & 1u) ? __dadd_rn(c.r_goal, living) : living);
+        const bool vertex = (f & 1u) != 0u, coll = (f & 3u) != 0u, goal_next = (f & 4u) == 0u;
+        const uint32_t st = ((coll || goal_next) ? 1u : 0u) | (coll ? 0x100u : 0u) | ((vertex || goal_next) ? 0x10000u : 0u);
+        const double r = coll ? __dadd_rn(c.r_clash, living) : (goal_next ? __dadd_rn(c.r_goal, living) : living);
         out.reward = was_terminal ? 0.0 : r;           // mapf_env.py:239-240 -- (s, 0, True, {"prob": 0}), nothing drawn
         out.status = was_terminal ? kTerminalStatus : st;
     }

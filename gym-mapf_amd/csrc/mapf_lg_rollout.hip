@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     const uint64_t step_rows = n_envs, step_cells = uint64_t(n_envs) * n_agents;
     const uint32_t last_step = p.n_steps ? p.n_steps - 1u : 0u;
     const bool odd = (x.g & 1u) != 0u;
-    const uint32_t flag_bit = x.g & 1u;
+    const uint32_t flag_shift = (x.g & 1u) * 8u;
     const uint32_t lane_cell = e * n_agents + 2u * x.g;
     gf64 reward_lane = reward_base + e, prob_lane = prob_base + e;      // the delayed step's row
     gu8 done_lane = done_base + e, coll_lane = coll_base + e;
@@ -125,10 +125,10 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
         if (DENSE) {
             *(gu32)rec_lane = cells;
             *reward_lane = (L > 1 && odd) ? d_prob : d_reward;
-            *done_lane = uint8_t(L > 1 ? (d_flags >> flag_bit) & 1u : d_flags & 1u);   // flag_bit: 1 in odd lanes
+            *done_lane = uint8_t(L > 1 ? d_flags >> flag_shift : d_flags);   // flag_shift: 8 in odd lanes
             if (L == 1) {
                 *prob_lane = d_prob;
-                *coll_lane = uint8_t(d_flags >> 1);
+                *coll_lane = uint8_t(d_flags >> 8);
             }
         } else {
             if (FULL || (n_agents & 1u) == 0u) {
@@ -141,7 +141,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
                 *reward_lane = d_reward;
                 *prob_lane = d_prob;
                 *done_lane = uint8_t(d_flags & 1u);
-                *coll_lane = uint8_t(d_flags >> 1);
+                *coll_lane = uint8_t(d_flags >> 8);
             }
         }
     };
@@ -157,7 +157,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
         const uint64_t t = p.t + s;
         uint32_t act0, act1;
         if (STREAM) {
-            act0 = raw & 0xFFu; act1 = raw >> 8;
+            act0 = raw & 0xFFu; act1 = (raw >> 8) & 0xFFu;   // only the low half-word of `raw` is defined
             asm volatile("" : "+v"(act0), "+v"(act1));       // (1) pins the wait for `raw` here, ahead of (2)
             if (DENSE) {                                     // clamped, not guarded: the last step re-reads its own row
                 act_lane += (s + 1u < p.n_steps) ? step_cells : 0u;
@@ -187,16 +187,16 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
                                             env_id, t, rng, terminal != 0u, next0, next1, o STAMP_ARG);
         STAMP(6);   // reward / selects
         ret = __dadd_rn(ret, o.reward);
-        episodes += o.status & 1u;
-        collisions += (o.status >> 1) & 1u;
+        episodes += o.status & 0xFFu;
+        collisions += (o.status >> 8) & 0xFFu;
         if (RECORD) {
             d_next0 = next0; d_next1 = next1; d_reward = o.reward; d_prob = o.prob;
-            d_flags = o.status & 3u;                       // done | collision << 1
+            d_flags = o.status;                            // byte 0 done, byte 1 collision
         }
-        const bool back = p.auto_reset && (o.status & 1u) != 0u;   // MapfEnv.reset(): start cells, no reseed
+        const bool back = p.auto_reset && (o.status & 0xFFu) != 0u;   // MapfEnv.reset(): start cells, no reseed
         cur0 = back ? start0 : next0;
         cur1 = back ? start1 : next1;
-        terminal = back ? start_terminal : (o.status >> 2);
+        terminal = back ? start_terminal : (o.status >> 16);
         STAMP(7);   // reset handling
     }
     if (RECORD && p.n_steps > 0) store_record();             // flush the last step's outputs
