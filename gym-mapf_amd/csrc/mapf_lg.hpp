@@ -173,7 +173,7 @@ __device__ __forceinline__ void pair_apply(const LaneCtx<L> &x, uint32_t n_agent
 
 // rotations 1..L/2: unrolled with DPP moves for groups up to 16 lanes, a rolled ds_bpermute loop beyond
 // (32 unrolled rounds would cost hundreds of registers for no gain)
-template <int L, int S, bool FULL, bool DUP, bool MOVES>
+template <int L, int S, bool FULL, bool DUP, bool MOVES, int LAST = L / 2>
 struct PairRounds {
     static __device__ __forceinline__ void run(const LaneCtx<L> &x, uint32_t n_agents, uint32_t cur0, uint32_t cur1,
                                                uint32_t next0, uint32_t next1, uint32_t pk_prev, uint32_t pk_next,
@@ -187,12 +187,12 @@ struct PairRounds {
                 const uint32_t o_next = MOVES ? uint32_t(__shfl(int(pk_next), src, 64)) : 0u;
                 pair_apply<L, FULL, DUP, MOVES>(x, n_agents, cur0, cur1, next0, next1, o_prev, o_next, og, acc);
             }
-        } else if constexpr (S <= L / 2 && L > 1) {
+        } else if constexpr (S <= LAST && L > 1) {
             const uint32_t o_prev = group_rot<L, S>(pk_prev, x);
             const uint32_t o_next = MOVES ? group_rot<L, S>(pk_next, x) : 0u;
             pair_apply<L, FULL, DUP, MOVES>(x, n_agents, cur0, cur1, next0, next1, o_prev, o_next,
                                             (x.g + uint32_t(S)) & uint32_t(L - 1), acc);
-            PairRounds<L, S + 1, FULL, DUP, MOVES>::run(x, n_agents, cur0, cur1, next0, next1, pk_prev, pk_next, acc);
+            PairRounds<L, S + 1, FULL, DUP, MOVES, LAST>::run(x, n_agents, cur0, cur1, next0, next1, pk_prev, pk_next, acc);
         }
     }
 };
@@ -218,7 +218,23 @@ __device__ __forceinline__ PairAcc<FULL> pair_tests(const LaneCtx<L> &x, uint32_
             acc.swap = ((cur0 | (next0 << 16)) ^ (next1 | (cur1 << 16))) | ghost;
         }
     }
-    PairRounds<L, 1, FULL, DUP, MOVES>::run(x, n_agents, cur0, cur1, next0, next1, pk_prev, pk_next, acc);
+    if constexpr (FULL && L >= 2 && L <= 16) {
+        // rotations 1 .. L/2-1 as usual; the half rotation pairs lane g with lane g + L/2 in BOTH directions, so the
+        // two lanes split its four agent pairs: every lane offers its pair swapped if it sits in the lower half, the
+        // receiver therefore sees a straight pair (lower half: tests 0-0', 1-1') or a swapped one (upper half: 0-1',
+        // 1-0') and runs only the "same half-word" tests.
+        PairRounds<L, 1, FULL, DUP, MOVES, L / 2 - 1>::run(x, n_agents, cur0, cur1, next0, next1, pk_prev, pk_next, acc);
+        const bool lower = x.g < uint32_t(L / 2);
+        const uint32_t o_prev = group_rot<L, L / 2>(lower ? swap_halves(pk_prev) : pk_prev, x);
+        if (DUP) acc.dup = pk_min_u16(acc.dup, pk_prev ^ o_prev);
+        if (MOVES) {
+            const uint32_t o_next = group_rot<L, L / 2>(lower ? swap_halves(pk_next) : pk_next, x);
+            acc.vertex = pk_min_u16(acc.vertex, pk_next ^ o_next);
+            acc.swap = pk_min_u16(acc.swap, (pk_next ^ o_prev) | (pk_prev ^ o_next));
+        }
+    } else {
+        PairRounds<L, 1, FULL, DUP, MOVES>::run(x, n_agents, cur0, cur1, next0, next1, pk_prev, pk_next, acc);
+    }
     return acc;
 }
 
@@ -278,15 +294,15 @@ __device__ __forceinline__ double prob_product(const LaneCtx<L> &x, double q0, d
             const uint32_t hi = from_prev_lane<L>(uint32_t(__double2hiint(run)));
             run = __dmul_rn(__dmul_rn(__hiloint2double(int(hi), int(lo)), q0), q1);
         }
-        // total sits in lane L-1: hand it to everyone
-        return group_bcast_f64<L, L - 1>(run, x);
+        return run;   // the total sits in lane L-1 only (the lane that stores it)
     } else {
         return ProbChain<L, 0>::run(x, q0, q1, 1.0);
     }
 }
 
 struct EnvOut {
-    double reward, prob;
+    double reward;
+    double prob;                 // valid in the group's LAST lane (g == L-1), the one the product chain ends in
     uint32_t status;             // one 0/1 fact per BYTE (sub-dword operand selects read them for free):
                                  // byte 0 done, byte 1 collision, byte 2 is_terminal of the returned state
     bool was_terminal;

@@ -35,9 +35,9 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
     if (!live) return;
 
     if (p.out_local) store_cells(p.out_local, e, n_agents, x.g, x.v0, x.v1, next0, next1);
+    if (x.g == uint32_t(L - 1) && p.out_prob) *at(p.out_prob, e) = o.prob;   // the product chain ends in the last lane
     if (x.g == 0u) {
         if (p.out_reward) *at(p.out_reward, e) = o.reward;
-        if (p.out_prob) *at(p.out_prob, e) = o.prob;
         if (p.out_done) *at(p.out_done, e) = o.done() ? 1 : 0;
         if (p.out_collision) *at(p.out_collision, e) = o.collision() ? 1 : 0;
         if (p.out_was_terminal) *at(p.out_was_terminal, e) = o.was_terminal ? 1 : 0;

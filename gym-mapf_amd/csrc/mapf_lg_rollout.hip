@@ -34,7 +34,8 @@ __device__ __forceinline__ uint32_t load_actions_raw(const uint8_t *base, uint32
 // loop body has no uniform branches around its memory operations.  DENSE (A == 2L and the env count fills every
 // block) additionally removes the per-lane predicates: every lane owns two real agents, the action prefetch is
 // clamped instead of guarded, and the four per-env scalars are stored by ALL lanes with per-lane addresses (even
-// lanes of a group write reward and done, odd lanes prob and collision -- duplicates carry identical data), so the
+// lanes of a group write done, odd lanes collision, the last lane prob, the others reward -- duplicates carry
+// identical data), so the
 // loop contains no exec-masked memory operation and the compiler can wait for the prefetched action word with a
 // counted vmcnt(N) instead of draining every store.  Start cells stay in two registers per lane, so an
 // auto-reset touches no memory.
@@ -49,6 +50,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     if (DENSE) { x.v0 = true; x.v1 = true; }
     const uint32_t e = x.e;
     const bool leader = live && x.g == 0u;
+    const bool tail = live && x.g == uint32_t(L - 1);   // holds the step's probability product
 
     uint32_t cur0, cur1, goal0, goal1, start0 = 0u, start1 = 0u;
     load_pair<uint16_t>(p.state, e, n_agents, x.g, x.v0, x.v1, cur0, cur1);
@@ -114,8 +116,9 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     gf64 reward_lane = reward_base + e, prob_lane = prob_base + e;      // the delayed step's row
     gu8 done_lane = done_base + e, coll_lane = coll_base + e;
     gu16 rec_lane = (gu16)(RECORD ? p.rec_local : nullptr) + lane_cell;
-    if (DENSE && L > 1) {   // even lanes of a group write reward and done, odd lanes prob and collision
-        reward_lane = odd ? prob_lane : reward_lane;
+    const bool wide_is_prob = x.g == uint32_t(L - 1);   // the probability product ends in the group's last lane
+    if (DENSE && L > 1) {   // last lane writes prob, the others reward; even lanes write done, odd lanes collision
+        reward_lane = wide_is_prob ? prob_lane : reward_lane;
         done_lane = odd ? coll_lane : done_lane;
     }
     asm volatile("" : "+v"(reward_lane), "+v"(prob_lane), "+v"(done_lane), "+v"(coll_lane), "+v"(rec_lane));
@@ -124,7 +127,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
         const uint32_t cells = d_next0 | (d_next1 << 16);
         if (DENSE) {
             *(gu32)rec_lane = cells;
-            *reward_lane = (L > 1 && odd) ? d_prob : d_reward;
+            *reward_lane = (L > 1 && wide_is_prob) ? d_prob : d_reward;
             *done_lane = uint8_t(L > 1 ? d_flags >> flag_shift : d_flags);   // flag_shift: 8 in odd lanes
             if (L == 1) {
                 *prob_lane = d_prob;
@@ -137,9 +140,9 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
                 if (x.v0) rec_lane[0] = uint16_t(d_next0);
                 if (x.v1) rec_lane[1] = uint16_t(d_next1);
             }
+            if (tail) *prob_lane = d_prob;
             if (leader) {
                 *reward_lane = d_reward;
-                *prob_lane = d_prob;
                 *done_lane = uint8_t(d_flags & 1u);
                 *coll_lane = uint8_t(d_flags >> 8);
             }
