@@ -10,7 +10,7 @@ ids so results do not depend on the rank count), synthetic uniform-random action
 HBM before the timed region, every done env auto-reset as the reference's caller loop does.
 
 A "step" is one MapfEnv.step() of every env of the rank: every output (next cells, reward, done,
-collision, prob) is written to HBM.  The headline leg fuses T = 64 steps per mapf_rollout launch
+collision, prob) is written to HBM.  The headline leg fuses T = 256 steps per mapf_rollout launch
 (state stays in registers between steps); K steps = ceil(K/T) launches enqueued back to back on the
 env's HIP stream between barrier + synchronize on both sides; rank 0 prints ONE JSON line.  Keys:
   roofline      dominant kernel (lg_rollout_kernel<4,...>) -- algorithmic bytes / HIP-event time per launch
@@ -43,13 +43,16 @@ def bytes_per_agent_step(A):
     return 5.0 + 18.0 / A
 
 
-def measured_traffic(kernel):
+def measured_traffic(kernel, steps_per_launch=None):
     """HBM bytes per launch of `kernel`, from the committed rocprofv3 PMC passes of this same command
     (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950).  None when no profile is present."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-            return json.load(f)['kernels'][kernel]['hbm_bytes_per_launch']
+            entry = json.load(f)['kernels'][kernel]
+        if steps_per_launch is not None and entry.get('steps_per_launch') != steps_per_launch:
+            return None
+        return entry['hbm_bytes_per_launch']
     except (OSError, KeyError, ValueError):
         return None
 
@@ -120,7 +123,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=128)
     ap.add_argument('--envs', type=int, default=65536, help='envs per GPU')
     ap.add_argument('--ring', type=int, default=512, help='distinct pre-generated action steps kept in HBM')
-    ap.add_argument('--rollout-steps', type=int, default=64, help='T of the fused rollout leg')
+    ap.add_argument('--rollout-steps', type=int, default=256, help='T of the fused rollout leg')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--kernel', default='auto', choices=['auto', 'thread_per_env', 'lane_group'])
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
@@ -287,7 +290,7 @@ def main():
                        "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ro_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ro_achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("lg_rollout_kernel") if T == 64 and E == 65536 else None,
+                         "traffic": measured_traffic("lg_rollout_kernel", T) if E == 65536 else None,
                          "kernel": "mapf::lg_rollout_kernel<4,true,true,true,true,true>", "bytes_per_launch": ro_bytes,
                          "ms_per_launch_hip_events": ro_launch_ms},
             "single_step_launches": single,

@@ -56,9 +56,21 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     load_pair<uint16_t>(p.state, e, n_agents, x.g, x.v0, x.v1, cur0, cur1);
     load_pair<uint16_t>(p.goal, p.goal_broadcast ? 0 : e, n_agents, x.g, x.v0, x.v1, goal0, goal1);
     if (p.auto_reset) load_pair<uint16_t>(p.start, p.start_broadcast ? 0 : e, n_agents, x.g, x.v0, x.v1, start0, start1);
-    if (MV_LDS) {
+    if (MV_LDS) {   // batches of four independent loads per thread, then the four LDS writes (not load-wait-write)
         const uint32_t n_words = p.c.n_cells * 5u;
-        for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) lds_mv[w] = p.mv[w];
+        for (uint32_t w0 = threadIdx.x; w0 < n_words; w0 += 4u * blockDim.x) {
+            MoveEntry part[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t w = w0 + k * blockDim.x;
+                part[k] = p.mv[w < n_words ? w : n_words - 1u];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t w = w0 + k * blockDim.x;
+                if (w < n_words) lds_mv[w] = part[k];
+            }
+        }
     }
     stage_outcome_table(p.c, outcome);
     stage_slip_table(p.slip, slip);   // ends with __syncthreads()

@@ -12,7 +12,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-E, A, T = 65536, 8, 64
+E, A, T = 65536, 8, 256   # bench.py defaults
 BYTES_PER_AGENT_STEP = 5.0 + 18.0 / A   # SURVEY.md 8(d), same figure as bench.py bytes_per_agent_step
 ALGORITHMIC = {"lg_rollout_kernel": int(T * E * A * BYTES_PER_AGENT_STEP), "lg_step_kernel": int(E * A * BYTES_PER_AGENT_STEP)}
 
@@ -46,6 +46,8 @@ def main():
                  "hbm_bytes_per_launch": int(round((2 * f_kb + w_kb) * 1024))}
         if k in ALGORITHMIC:
             entry["algorithmic_bytes_per_launch"] = ALGORITHMIC[k]
+        if k == "lg_rollout_kernel":
+            entry["steps_per_launch"] = T
         out["kernels"][k] = entry
     dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "traffic.json")
     with open(dst, "w") as f:
