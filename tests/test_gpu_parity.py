@@ -256,6 +256,43 @@ def test_results_do_not_depend_on_how_envs_are_sharded():
     [p.close() for p in parts]
 
 
+@pytest.mark.parametrize('n_agents,n_envs', [(2, 16384), (2, 2048), (4, 16384), (4, 1024), (8, 4096), (8, 1024),
+                                             (16, 2048), (16, 512), (32, 1024), (64, 512), (128, 256)])
+def test_recorded_rollout_of_full_groups_against_c_oracle(n_agents, n_envs):
+    """Full groups (A = 2L) whose env count fills every block run the predicate-free rollout kernel (LDS move
+    table for the larger batches, global table for the smaller): every recorded step -- cells, reward, prob,
+    done, collision -- against the C oracle stepped with the same actions, streamed and policy-generated,
+    both criteria, with envs that stay terminal (no auto-reset) in the second pass."""
+    rs = np.random.RandomState(500 + n_agents)
+    H = W = 20
+    lines = [''.join('@' if rs.rand() < 0.15 else '.' for _ in range(W)) for _ in range(H)]
+    grid = MapfGrid(lines)
+    valid, _, nbr = grid.tables()
+    V, E, A, T = len(valid), n_envs, n_agents, 14
+    start = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    goal = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    goal[::7] = start[::7]                                   # some envs start in a terminal state
+    ids = 77 + np.arange(E)
+    for crit, ocrit, auto, streamed in ((OptimizationCriteria.Makespan, mo.MAKESPAN, True, True),
+                                        (OptimizationCriteria.SoC, mo.SOC, False, False)):
+        env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, crit, seed=11, env_id_offset=77,
+                         start_local=start, goal_local=goal)
+        co = c_oracle.COracle(nbr, A, start, goal, 0.2, -1000.0, 100.0, -1.0, ocrit, seed=11, env_id_offset=77)
+        acts = np.stack([philox.random_actions_np(11, ids, t, A) for t in range(T)])
+        res = env.rollout(T, actions=acts if streamed else None, auto_reset=auto, record=True)
+        ret = np.zeros(E)
+        for t in range(T):
+            ref = co.step(acts[t], auto_reset=auto)
+            assert np.array_equal(res['local'][t], ref['local']), (A, t)
+            assert np.array_equal(_bits(res['reward'][t]), _bits(ref['reward'])), (A, t)
+            assert np.array_equal(_bits(res['prob'][t]), _bits(ref['prob'])), (A, t)
+            assert np.array_equal(res['done'][t], ref['done']) and np.array_equal(res['collision'][t], ref['collision'])
+            ret = ret + ref['reward']
+        assert np.array_equal(_bits(res['returns']), _bits(ret))
+        assert np.array_equal(env.get_state()[0], co.state)
+        env.close()
+
+
 # ----------------------------------------------------------------------- BASELINE.json full sizes
 def _full_size_check(grid, nbr, A, start, goal, fail_prob, crit, ocrit, n_step, n_roll, kernel='auto'):
     E = start.shape[0]
