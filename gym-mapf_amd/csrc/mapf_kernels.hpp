@@ -104,6 +104,8 @@ constexpr int kTpeMaxAgents = 16;         // thread-per-env step kernels are spe
 constexpr int kTpeRolloutMaxAgents = 6;   // ... their rollout form is dispatched only where it is spill-free
 hipError_t launch_step_lg(int n_agents, const StepArgs &args, hipStream_t stream);
 hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, hipStream_t stream);
+// quad-lane layout of the fused rollout (mapf_lq_rollout.hip): true when it took the launch (*err = its status)
+bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, size_t mv_lds_limit, hipStream_t stream, hipError_t *err);
 int lg_group_size(int n_agents);
 
 // per-group entry points: group g holds the kernels specialised for A in 4g+1 .. 4g+4

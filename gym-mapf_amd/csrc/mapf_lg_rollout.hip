@@ -121,7 +121,6 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     // Addresses advance by one step's worth of elements per iteration (wave-uniform strides added to per-lane
     // pointers) -- no per-step row * width multiplications.
     const uint64_t step_rows = n_envs, step_cells = uint64_t(n_envs) * n_agents;
-    const uint32_t last_step = p.n_steps ? p.n_steps - 1u : 0u;
     const bool odd = (x.g & 1u) != 0u;
     const uint32_t flag_shift = (x.g & 1u) * 8u;
     const uint32_t lane_cell = e * n_agents + 2u * x.g;
@@ -282,6 +281,10 @@ hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, hipStream_t 
     // the record variant writes all five trajectory arrays: the C ABI passes either all of them or none
     const bool record = args.rec_local != nullptr, stream_actions = args.actions != nullptr;
     if (record && !(args.rec_reward && args.rec_prob && args.rec_done && args.rec_collision)) return hipErrorInvalidValue;
+#ifndef MAPF_STAMPS   // (the diagnostic build stamps the pair layout's loop)
+    hipError_t quad_status;
+    if (try_launch_rollout_lq(n_agents, args, mv_lds_limit(), stream, &quad_status)) return quad_status;
+#endif
     switch (L) {
 #define X(N)                                                                                                         \
     case N:                                                                                                          \

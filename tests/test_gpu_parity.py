@@ -256,10 +256,17 @@ def test_results_do_not_depend_on_how_envs_are_sharded():
     [p.close() for p in parts]
 
 
-@pytest.mark.parametrize('n_agents,n_envs', [(2, 16384), (2, 2048), (4, 16384), (4, 1024), (8, 4096), (8, 1024),
-                                             (16, 2048), (16, 512), (32, 1024), (64, 512), (128, 256)])
+@pytest.mark.parametrize('n_agents,n_envs', [
+    (2, 16384), (2, 2048),                       # pair layout L = 1: LDS table / global table
+    (4, 16384), (4, 16512), (4, 1024),           # quad layout Q = 1; pair layout L = 2 (LDS: 16512 = 129 pair blocks); global
+    (8, 8192), (8, 16448), (8, 1024),            # quad Q = 2; pair L = 4 (LDS: 257 pair blocks); global
+    (16, 4096), (16, 4128), (16, 512),           # quad Q = 4; pair L = 8 (LDS); global
+    (32, 2048), (32, 1024),                      # quad Q = 8; pair L = 16 (LDS)
+    (64, 1024), (64, 512),                       # quad Q = 16; pair L = 32 (LDS)
+    (128, 256)])                                 # pair L = 64
 def test_recorded_rollout_of_full_groups_against_c_oracle(n_agents, n_envs):
-    """Full groups (A = 2L) whose env count fills every block run the predicate-free rollout kernel (LDS move
+    """Full groups whose env count fills every block run the predicate-free rollout kernels -- the quad-lane
+    layout (four agents per lane) where A = 4Q and the batch fills its blocks, else the pair layout (LDS move
     table for the larger batches, global table for the smaller): every recorded step -- cells, reward, prob,
     done, collision -- against the C oracle stepped with the same actions, streamed and policy-generated,
     both criteria, with envs that stay terminal (no auto-reset) in the second pass."""
