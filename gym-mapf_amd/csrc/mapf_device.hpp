@@ -33,6 +33,32 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
+// Two calls that share the key and differ only in the last counter word, advanced in lockstep: the round's four
+// multiplies are independent of each other (one call alone is a chain of dependent multiply -> xor pairs, and the
+// scalar launder below is a scheduling fence, so two separate calls would run back to back).
+__device__ __forceinline__ void philox4x32_10_x2(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3a, uint32_t c3b,
+                                                 uint32_t k0, uint32_t k1, uint32_t (&outa)[4], uint32_t (&outb)[4]) {
+    uint32_t a0 = c0, a1 = c1, a2 = c2, a3 = c3a, b0 = c0, b1 = c1, b2 = c2, b3 = c3b;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t pa0 = uint64_t(0xD2511F53u) * a0, pa1 = uint64_t(0xCD9E8D57u) * a2;
+        const uint64_t pb0 = uint64_t(0xD2511F53u) * b0, pb1 = uint64_t(0xCD9E8D57u) * b2;
+        a0 = __builtin_amdgcn_bitop3_b32(uint32_t(pa1 >> 32), a1, k0, 0x96);
+        b0 = __builtin_amdgcn_bitop3_b32(uint32_t(pb1 >> 32), b1, k0, 0x96);
+        a1 = uint32_t(pa1);
+        b1 = uint32_t(pb1);
+        a2 = __builtin_amdgcn_bitop3_b32(uint32_t(pa0 >> 32), a3, k1, 0x96);
+        b2 = __builtin_amdgcn_bitop3_b32(uint32_t(pb0 >> 32), b3, k1, 0x96);
+        a3 = uint32_t(pa0);
+        b3 = uint32_t(pb0);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+        asm volatile("" : "+s"(k0), "+s"(k1));
+    }
+    outa[0] = a0; outa[1] = a1; outa[2] = a2; outa[3] = a3;
+    outb[0] = b0; outb[1] = b1; outb[2] = b2; outb[3] = b3;
+}
+
 // 53-bit integer of a uniform in [0,1): u = mant * 2^-53 -- same construction as RandomState.rand().
 __device__ __forceinline__ uint64_t mantissa53(uint32_t a, uint32_t b) {
     return (uint64_t(a >> 5) << 26) | uint64_t(b >> 6);
@@ -131,6 +157,17 @@ __device__ __forceinline__ Words4 slip_words(const EnvConsts &c, uint64_t env_id
     uint32_t w[4];
     philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(h), c3, c.seed_lo, c.seed_hi, w);
     return Words4{w[0], w[1], w[2], w[3]};
+}
+
+// the calls of two pairs of the same (env, h) in lockstep
+__device__ __forceinline__ void slip_words_x2(const EnvConsts &c, uint64_t env_id, uint64_t h, uint32_t pair_a, uint32_t pair_b,
+                                              Words4 &wa, Words4 &wb) {
+    const uint32_t hi = uint32_t(h >> 32) & 0xFFFFu;
+    uint32_t a[4], b[4];
+    philox4x32_10_x2(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(h), hi | (pair_a << 16), hi | (pair_b << 16),
+                     c.seed_lo, c.seed_hi, a, b);
+    wa = Words4{a[0], a[1], a[2], a[3]};
+    wb = Words4{b[0], b[1], b[2], b[3]};
 }
 
 // word (t & 3) of a call

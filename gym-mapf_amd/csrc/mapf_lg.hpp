@@ -325,6 +325,7 @@ struct OutcomeRow {
     double reward;
     uint32_t status, pad;
 };
+static_assert(sizeof(OutcomeRow) == 16, "read as one 16-byte LDS word");
 __device__ __forceinline__ void stage_outcome_table(const EnvConsts &c, OutcomeRow *lds) {   // before a __syncthreads()
     const uint32_t i = threadIdx.x;
     if (i < 16u) {

@@ -257,8 +257,7 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         for (int k = 0; k < 4; ++k) entry[k] = move_entry<false>(lds_mv, p.c.n_cells, cur[k], act[k]);
         // one slip-stream call per pair serves four steps: refresh when t is a multiple of 4 (and at the first step)
         if (p.c.need_rng && ((t & 3u) == 0u || s == 0u)) {
-            rng_a = slip_words(p.c, env_id, t >> 2, 2u * x.g, 0u, 0u);
-            rng_b = slip_words(p.c, env_id, t >> 2, 2u * x.g + 1u, 0u, 0u);
+            slip_words_x2(p.c, env_id, t >> 2, 2u * x.g, 2u * x.g + 1u, rng_a, rng_b);
         }
         const uint32_t word_a = step_word(rng_a, t), word_b = step_word(rng_b, t);
         const uint32_t hi[4] = {word_a & 0xFFFFu, word_a >> 16, word_b & 0xFFFFu, word_b >> 16};
@@ -284,15 +283,16 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         uint32_t flags = (PairAcc<true>::hit(acc.vertex) ? 1u : 0u) | (PairAcc<true>::hit(acc.swap) ? 2u : 0u) | (off_goal_next ? 4u : 0u);
         flags = group_reduce<Q, false>(flags, x);
         const uint32_t f = flags & 7u;
-        const double prob = quad_prob_product<Q>(q[0], q[1], q[2], q[3]);
         const bool was_terminal = terminal != 0u;
-        double reward;
-        uint32_t status;
-        if (p.c.criteria == 0u) {
-            const OutcomeRow row = outcome[f | (was_terminal ? 8u : 0u)];
-            reward = row.reward;
-            status = row.status;
-        } else {
+        // the outcome row is requested BEFORE the probability chain and consumed after it (one 16-byte LDS read whose
+        // latency the chain covers); its status word holds for both criteria, its reward for Makespan
+        const uint4 row = *reinterpret_cast<const uint4 *>(&outcome[f | (was_terminal ? 8u : 0u)]);
+        double prob = quad_prob_product<Q>(q[0], q[1], q[2], q[3]);
+        uint32_t row_lo = row.x, row_hi = row.y, status = row.z;
+        // the row is consumed here, after the chain (which only exists when the trajectory is recorded)
+        if (RECORD) asm volatile("" : "+v"(row_lo), "+v"(row_hi), "+v"(status), "+v"(prob));
+        double reward = __hiloint2double(int(row_hi), int(row_lo));
+        if (p.c.criteria != 0u) {
             // _living_reward: mapf_env.py:436-446
             const uint32_t goal[4] = {ga & 0xFFFFu, ga >> 16, gb & 0xFFFFu, gb >> 16};
             uint32_t mine = 0u;
@@ -300,11 +300,9 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
             for (int k = 0; k < 4; ++k) mine += (cur[k] == goal[k] && act[k] == 0u) ? 1u : 0u;
             const int stayed = int(group_reduce<Q, true>(mine, x));
             const double living = __dmul_rn(double(int(n_agents) - stayed), p.c.r_living);
-            const bool vertex = (f & 1u) != 0u, coll = (f & 3u) != 0u, goal_next = (f & 4u) == 0u;
-            const uint32_t live_status = ((coll || goal_next) ? 1u : 0u) | (coll ? 0x100u : 0u) | ((vertex || goal_next) ? 0x10000u : 0u);
+            const bool coll = (f & 3u) != 0u, goal_next = (f & 4u) == 0u;
             const double r = coll ? __dadd_rn(p.c.r_clash, living) : (goal_next ? __dadd_rn(p.c.r_goal, living) : living);
             reward = was_terminal ? 0.0 : r;
-            status = was_terminal ? kTerminalStatus : live_status;
         }
         if (was_terminal) { na = ca; nb = cb; }                // mapf_env.py:239-240 -- (s, 0, True, {"prob": 0})
 
@@ -315,7 +313,9 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
             d_a = na; d_b = nb; d_reward = reward; d_prob = was_terminal ? 0.0 : prob;
             d_flags = status;                                  // byte 0 done, byte 1 collision
         }
-        const bool back = p.auto_reset && (status & 0xFFu) != 0u;   // MapfEnv.reset(): start cells, no reseed
+        // MapfEnv.reset(): start cells, no reseed.  `done` is re-derived from the facts (every f except "off goal,
+        // no collision" ends the episode) so that the next step's table address does not wait for the outcome row
+        const bool back = p.auto_reset && (f != 4u || was_terminal);
         ca = back ? sa : na;
         cb = back ? sb : nb;
         terminal = back ? start_terminal : (status >> 16);
