@@ -13,7 +13,7 @@ A "step" is one MapfEnv.step() of every env of the rank: every output (next cell
 collision, prob) is written to HBM.  The headline leg fuses T = 256 steps per mapf_rollout launch
 (state stays in registers between steps); K steps = ceil(K/T) launches enqueued back to back on the
 env's HIP stream between barrier + synchronize on both sides; rank 0 prints ONE JSON line.  Keys:
-  roofline      dominant kernel (lg_rollout_kernel<4,...>) -- algorithmic bytes / HIP-event time per launch
+  roofline      dominant kernel (lq_rollout_kernel<2,...>) -- algorithmic bytes / HIP-event time per launch
   single_step_launches   the same steps as one mapf_step launch each (launch-latency bound at this size)
   cpu_baseline  the pure-Python restatement of the reference (oracle/, kind "port") timed on
                 this box's host cores on a bounded sample (rank 0, N=1 only)
@@ -290,8 +290,8 @@ def main():
                        "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ro_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ro_achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("lg_rollout_kernel", T) if E == 65536 else None,
-                         "kernel": "mapf::lg_rollout_kernel<4,true,true,true,true,true>", "bytes_per_launch": ro_bytes,
+                         "traffic": measured_traffic("rollout_kernel", T) if E == 65536 else None,
+                         "kernel": "mapf::lq_rollout_kernel<2,true,true> (quad-lane layout: 4 agents per lane)", "bytes_per_launch": ro_bytes,
                          "ms_per_launch_hip_events": ro_launch_ms},
             "single_step_launches": single,
             "parity": parity,

@@ -14,7 +14,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 E, A, T = 65536, 8, 256   # bench.py defaults
 BYTES_PER_AGENT_STEP = 5.0 + 18.0 / A   # SURVEY.md 8(d), same figure as bench.py bytes_per_agent_step
-ALGORITHMIC = {"lg_rollout_kernel": int(T * E * A * BYTES_PER_AGENT_STEP), "lg_step_kernel": int(E * A * BYTES_PER_AGENT_STEP)}
+ALGORITHMIC = {"rollout_kernel": int(T * E * A * BYTES_PER_AGENT_STEP), "lg_step_kernel": int(E * A * BYTES_PER_AGENT_STEP)}
 
 
 def per_kernel(path, counter):
@@ -24,8 +24,8 @@ def per_kernel(path, counter):
             if r["Counter_Name"] != counter:
                 continue
             name = r["Kernel_Name"]
-            for key in ("lg_rollout_kernel", "lg_step_kernel", "reset_kernel", "fill_actions_kernel"):
-                if key in name:
+            for key in ("rollout_kernel", "lg_step_kernel", "reset_kernel", "fill_actions_kernel"):
+                if key in name:   # "rollout_kernel" matches the quad-lane (lq_) and the pair (lg_) layout
                     total[key] += float(r["Counter_Value"])
                     count[key] += 1
                     names[key] = name
@@ -36,17 +36,17 @@ def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     out = {"_how": __doc__.strip().split("\n\n", 1)[1].replace("\n", " "), "kernels": {}}
-    for k in ("lg_rollout_kernel", "lg_step_kernel", "reset_kernel", "fill_actions_kernel"):
+    for k in ("rollout_kernel", "lg_step_kernel", "reset_kernel", "fill_actions_kernel"):
         if k not in fetch or k not in write:
             continue
         f_kb, n, name = fetch[k]
         w_kb = write[k][0]
-        entry = {"instance": name.split("(")[0].replace("void ", ""), "dispatches": n,
+        entry = {"instance": name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", ""), "dispatches": n,
                  "FETCH_SIZE_KB": round(f_kb, 2), "WRITE_SIZE_KB": round(w_kb, 2),
                  "hbm_bytes_per_launch": int(round((2 * f_kb + w_kb) * 1024))}
         if k in ALGORITHMIC:
             entry["algorithmic_bytes_per_launch"] = ALGORITHMIC[k]
-        if k == "lg_rollout_kernel":
+        if k == "rollout_kernel":
             entry["steps_per_launch"] = T
         out["kernels"][k] = entry
     dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "traffic.json")
