@@ -95,7 +95,7 @@ def test_dispatched_lane_group_kernels_have_no_register_spills(tmp_path):
     SGPRs/VGPRs both cost time and were the one place a miscompile was ever observed)."""
     text = ''
     procs = []
-    for unit in ('mapf_lg_kernels', 'mapf_lg_rollout', 'mapf_transitions'):
+    for unit in ('mapf_lg_kernels', 'mapf_lg_rollout', 'mapf_lq_rollout', 'mapf_transitions'):
         out = tmp_path / (unit + '.s')
         procs.append((out, subprocess.Popen(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
                                              '-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only',
