@@ -187,9 +187,26 @@ def main():
             ok &= bool(np.array_equal(info['prob'].cpu().numpy().view(np.uint64), ref['prob'].view(np.uint64)))
             ok &= bool(np.array_equal(done.cpu().numpy(), ref['done']))
             ok &= bool(np.array_equal(info['collision'].cpu().numpy(), ref['collision']))
-        parity = {"checked_env_steps": n_chk * E, "bit_exact": ok, "against": "oracle/mapf_oracle.c"}
+        # ... and the same for the fused rollout kernel the headline leg times: recorded trajectory of its first steps
+        env.reset()
+        env.set_state(None, t=0)
+        co.reset()
+        co.t = 0
+        n_ro = min(8, ring)
+        res = env.rollout(n_ro, actions=actions[:n_ro], auto_reset=True, record=True)
+        env.sync()
+        for t in range(n_ro):
+            ref = co.step(actions[t].cpu().numpy(), auto_reset=True)
+            ok &= bool(np.array_equal(res['local'][t].cpu().numpy(), ref['local']))
+            ok &= bool(np.array_equal(res['reward'][t].cpu().numpy().view(np.uint64), ref['reward'].view(np.uint64)))
+            ok &= bool(np.array_equal(res['prob'][t].cpu().numpy().view(np.uint64), ref['prob'].view(np.uint64)))
+            ok &= bool(np.array_equal(res['done'][t].cpu().numpy(), ref['done']))
+            ok &= bool(np.array_equal(res['collision'][t].cpu().numpy(), ref['collision']))
+        parity = {"checked_env_steps": (n_chk + n_ro) * E, "bit_exact": ok, "against": "oracle/mapf_oracle.c",
+                  "covers": "%d single-step launches + a %d-step fused rollout (recorded trajectory), every env of rank 0"
+                            % (n_chk, n_ro)}
         if not ok:
-            raise SystemExit('PARITY FAILURE: HIP step differs from the oracle')
+            raise SystemExit('PARITY FAILURE: HIP path differs from the oracle')
         env.reset()
         env.set_state(None, t=0)
 
