@@ -281,10 +281,8 @@ hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, hipStream_t 
     // the record variant writes all five trajectory arrays: the C ABI passes either all of them or none
     const bool record = args.rec_local != nullptr, stream_actions = args.actions != nullptr;
     if (record && !(args.rec_reward && args.rec_prob && args.rec_done && args.rec_collision)) return hipErrorInvalidValue;
-#ifndef MAPF_STAMPS   // (the diagnostic build stamps the pair layout's loop)
     hipError_t quad_status;
     if (try_launch_rollout_lq(n_agents, args, mv_lds_limit(), stream, &quad_status)) return quad_status;
-#endif
     switch (L) {
 #define X(N)                                                                                                         \
     case N:                                                                                                          \

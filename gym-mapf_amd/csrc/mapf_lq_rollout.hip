@@ -147,11 +147,11 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
     const uint32_t lane_cell = e * n_agents + 4u * x.g;             // my first agent's element index
     const uint32_t fixed_cell = 4u * x.g;                           // ... in a broadcast row
 
-    const u32x2 st = *reinterpret_cast<const u32x2 *>(at(p.state, lane_cell));
+    const u32x2 cells = *reinterpret_cast<const u32x2 *>(at(p.state, lane_cell));
     const u32x2 gl = *reinterpret_cast<const u32x2 *>(at(p.goal, p.goal_broadcast ? fixed_cell : lane_cell));
     u32x2 sc = {0u, 0u};
     if (p.auto_reset) sc = *reinterpret_cast<const u32x2 *>(at(p.start, p.start_broadcast ? fixed_cell : lane_cell));
-    uint32_t ca = st.x, cb = st.y;                                   // packed current cells
+    uint32_t ca = cells.x, cb = cells.y;                                   // packed current cells
     const uint32_t ga = gl.x, gb = gl.y, sa = sc.x, sb = sc.y;
     {   // move table -> LDS, batches of four independent loads per thread
         const uint32_t n_words = p.c.n_cells * 5u;
@@ -213,6 +213,10 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
     uint32_t d_a = 0u, d_b = 0u, d_flags = 0u;      // step s-1's results, stored during step s
     double d_reward = 0.0, d_prob = 0.0;
 
+#ifdef MAPF_STAMPS
+    StampCtx st{};
+    { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); st.last = _t; }
+#endif
     auto store_record = [&]() __attribute__((always_inline)) {
         *rec_lane = u32x2{d_a, d_b};
         *wide_lane = (Q > 1 && tail) ? d_prob : d_reward;
@@ -249,6 +253,7 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) act[k] = act[k] > 4u ? 0u : act[k];
+        STAMP(0);   // loop top: action fetch / policy / delayed stores
 
         // --- my four agents' table rows
         const uint32_t cur[4] = {ca & 0xFFFFu, ca >> 16, cb & 0xFFFFu, cb >> 16};
@@ -259,6 +264,7 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         if (p.c.need_rng && ((t & 3u) == 0u || s == 0u)) {
             slip_words_x2(p.c, env_id, t >> 2, 2u * x.g, 2u * x.g + 1u, rng_a, rng_b);
         }
+        STAMP(1);   // table read issue + slip Philox (1 step in 4)
         const uint32_t word_a = step_word(rng_a, t), word_b = step_word(rng_b, t);
         const uint32_t hi[4] = {word_a & 0xFFFFu, word_a >> 16, word_b & 0xFFFFu, word_b >> 16};
         double q[4];
@@ -277,12 +283,15 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
             nb = nx[2] | (nx[3] << 16);
         }
 
+        STAMP(2);   // sampling (table wait, thresholds, probability read issue)
         // --- pair tests, per-env facts, outcome
         const PairAcc<true> acc = quad_pair_tests<Q, false, true>(x, ca, cb, na, nb);
+        STAMP(3);   // pair tests
         const bool off_goal_next = na != ga || nb != gb;
         uint32_t flags = (PairAcc<true>::hit(acc.vertex) ? 1u : 0u) | (PairAcc<true>::hit(acc.swap) ? 2u : 0u) | (off_goal_next ? 4u : 0u);
         flags = group_reduce<Q, false>(flags, x);
         const uint32_t f = flags & 7u;
+        STAMP(4);   // flags + group reduce
         const bool was_terminal = terminal != 0u;
         // the outcome row is requested BEFORE the probability chain and consumed after it (one 16-byte LDS read whose
         // latency the chain covers); its status word holds for both criteria, its reward for Makespan
@@ -305,6 +314,7 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
             reward = was_terminal ? 0.0 : r;
         }
         if (was_terminal) { na = ca; nb = cb; }                // mapf_env.py:239-240 -- (s, 0, True, {"prob": 0})
+        STAMP(5);   // outcome row + probability product
 
         ret = __dadd_rn(ret, reward);
         episodes += status & 0xFFu;
@@ -313,14 +323,22 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
             d_a = na; d_b = nb; d_reward = reward; d_prob = was_terminal ? 0.0 : prob;
             d_flags = status;                                  // byte 0 done, byte 1 collision
         }
+        STAMP(6);   // totals
         // MapfEnv.reset(): start cells, no reseed.  `done` is re-derived from the facts (every f except "off goal,
         // no collision" ends the episode) so that the next step's table address does not wait for the outcome row
         const bool back = p.auto_reset && (f != 4u || was_terminal);
         ca = back ? sa : na;
         cb = back ? sb : nb;
         terminal = back ? start_terminal : (status >> 16);
+        STAMP(7);   // reset handling
     }
     if (RECORD && p.n_steps > 0) store_record();               // flush the last step's outputs
+#ifdef MAPF_STAMPS
+    if (x.lane == 0u && epi_p) {   // diagnostic build: segment sums replace the episode counts
+        for (int k = 0; k < 8; ++k) epi_p[k] = uint32_t(st.seg[k]);
+        return;
+    }
+#endif
     *reinterpret_cast<u32x2 *>(at(p.state, lane_cell)) = u32x2{ca, cb};
     if (leader) {
         if (ret_p) *ret_p = ret;

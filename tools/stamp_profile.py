@@ -5,6 +5,7 @@ episode counters, so this build's outputs are not valid results) and prints medi
 
     make -C gym-mapf_amd/csrc stamps
     MAPF_HIP_LIB=gym-mapf_amd/csrc/build/libmapf_hip_stamps.so python tools/stamp_profile.py
+    (MAPF_QUAD_LANES=0 in the environment profiles the pair layout instead of the quad-lane one)
 
 Stamps serialise the segments (a fence on each side), so read the SHARES, not the total (cdna_hip_programming.md
 section 7, in-kernel stamps).
@@ -22,6 +23,9 @@ from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv  # noqa: 
 if 'stamps' not in os.environ.get('MAPF_HIP_LIB', ''):
     raise SystemExit('set MAPF_HIP_LIB to the stamps build (see the docstring)')
 E, A, T = 65536, 8, 64
+# envs per wave: 32 in the quad-lane layout (default), 16 in the pair layout (MAPF_QUAD_LANES=0)
+PER_WAVE = 16 if os.environ.get('MAPF_QUAD_LANES') == '0' else 32
+print('layout: %s' % ('pair (2 agents per lane)' if PER_WAVE == 16 else 'quad (4 agents per lane)'))
 grid, nbr, start, goal = bench.workload_tables(E, 0)
 env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=42,
                  device_arrays=True, start_local=start, goal_local=goal)
@@ -35,7 +39,7 @@ for acts, label in ((actions, 'streamed actions'), (None, 'in-kernel policy')):
         env.rollout(T, actions=acts, auto_reset=True, record=record)
         res = env.rollout(T, actions=acts, auto_reset=True, record=record)
         env.sync()
-        seg = res['episodes'].cpu().numpy().view(np.uint32).reshape(-1, 16)[:, :8].astype(np.float64) / T
+        seg = res['episodes'].cpu().numpy().view(np.uint32).reshape(-1, PER_WAVE)[:, :8].astype(np.float64) / T
         med = np.median(seg, axis=0)
         print('%s, record=%s: %d cycles per wave-step' % (label, record, med.sum()))
         for n, m in zip(names, med):
