@@ -210,20 +210,35 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
     if (STREAM && p.n_steps > 0) raw = *reinterpret_cast<const uint32_t *>(act_lane);
     asm volatile("" : "+v"(raw));     // consume the first word here: the loop's wait is the back edge's counted one
     Words4 rng_a{0u, 0u, 0u, 0u}, rng_b{0u, 0u, 0u, 0u};
-    uint32_t d_a = 0u, d_b = 0u, d_flags = 0u;      // step s-1's results, stored during step s
-    double d_reward = 0.0, d_prob = 0.0;
+    // "Pending" = what is left of step s-1 when step s begins: its probability chain, its totals and its trajectory
+    // stores.  They are finished at the top of step s, right after step s's table reads have been issued, so the
+    // chain of dependent float64 multiplies runs while those reads are in flight, and the outcome row / probability
+    // reads of step s-1 (requested in step s-1, consumed only here) never stall anything.  Step 0 finishes a dummy:
+    // reward -0.0 leaves the running return unchanged bit for bit, the stores hit row 0 and are overwritten by step 1.
+    double pq0 = 0.0, pq1 = 0.0, pq2 = 0.0, pq3 = 0.0, p_reward = -0.0;
+    uint32_t p_a = 0u, p_b = 0u, p_status = 0u;
 
 #ifdef MAPF_STAMPS
     StampCtx st{};
     { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); st.last = _t; }
 #endif
-    auto store_record = [&]() __attribute__((always_inline)) {
-        *rec_lane = u32x2{d_a, d_b};
-        *wide_lane = (Q > 1 && tail) ? d_prob : d_reward;
-        *narrow_lane = uint8_t(Q > 1 ? d_flags >> flag_shift : d_flags);
-        if (Q == 1) {
-            *prob_lane = d_prob;
-            *coll_lane = uint8_t(d_flags >> 8);
+    auto finish_pending = [&]() __attribute__((always_inline)) {
+        // opaque from here on: otherwise the optimiser moves these consumers back to where the values are produced
+        // (the end of the previous step), which is exactly the stall this pipeline removes
+        asm volatile("" : "+v"(p_reward), "+v"(p_status));
+        if (RECORD) asm volatile("" : "+v"(pq0), "+v"(pq1), "+v"(pq2), "+v"(pq3));
+        ret = __dadd_rn(ret, p_reward);
+        episodes += p_status & 0xFFu;                          // byte 0 done, byte 1 collision
+        collisions += (p_status >> 8) & 0xFFu;
+        if (RECORD) {
+            const double prob = quad_prob_product<Q>(pq0, pq1, pq2, pq3);   // total in the last lane
+            *rec_lane = u32x2{p_a, p_b};
+            *wide_lane = (Q > 1 && tail) ? prob : p_reward;
+            *narrow_lane = uint8_t(Q > 1 ? p_status >> flag_shift : p_status);
+            if (Q == 1) {
+                *prob_lane = prob;
+                *coll_lane = uint8_t(p_status >> 8);
+            }
         }
     };
 
@@ -242,29 +257,29 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
 #pragma unroll
             for (int k = 0; k < 4; ++k) act[k] = __umulhi(w[k], 5u);
         }
-        if (RECORD) {                                         // the previous step's outputs (step 0: a dummy row 0)
-            store_record();
-            if (s > 0) {
-                rec_lane = (gu32x2)((__attribute__((address_space(1))) uint16_t *)rec_lane + step_cells);
-                wide_lane += step_rows;
-                narrow_lane += step_rows;
-                if (Q == 1) { prob_lane += step_rows; coll_lane += step_rows; }
-            }
-        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) act[k] = act[k] > 4u ? 0u : act[k];
-        STAMP(0);   // loop top: action fetch / policy / delayed stores
 
-        // --- my four agents' table rows
+        // --- my four agents' table rows: requested first ...
         const uint32_t cur[4] = {ca & 0xFFFFu, ca >> 16, cb & 0xFFFFu, cb >> 16};
         MoveEntry entry[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) entry[k] = move_entry<false>(lds_mv, p.c.n_cells, cur[k], act[k]);
+        STAMP(0);   // loop top: action fetch / policy, table read issue
+        // --- ... then the previous step is finished while they are in flight
+        finish_pending();
+        if (RECORD && s > 0) {
+            rec_lane = (gu32x2)((__attribute__((address_space(1))) uint16_t *)rec_lane + step_cells);
+            wide_lane += step_rows;
+            narrow_lane += step_rows;
+            if (Q == 1) { prob_lane += step_rows; coll_lane += step_rows; }
+        }
+        STAMP(1);   // previous step: probability chain, totals, trajectory stores
         // one slip-stream call per pair serves four steps: refresh when t is a multiple of 4 (and at the first step)
         if (p.c.need_rng && ((t & 3u) == 0u || s == 0u)) {
             slip_words_x2(p.c, env_id, t >> 2, 2u * x.g, 2u * x.g + 1u, rng_a, rng_b);
         }
-        STAMP(1);   // table read issue + slip Philox (1 step in 4)
+        STAMP(2);   // slip Philox (1 step in 4)
         const uint32_t word_a = step_word(rng_a, t), word_b = step_word(rng_b, t);
         const uint32_t hi[4] = {word_a & 0xFFFFu, word_a >> 16, word_b & 0xFFFFu, word_b >> 16};
         double q[4];
@@ -282,25 +297,24 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
             na = nx[0] | (nx[1] << 16);
             nb = nx[2] | (nx[3] << 16);
         }
+        STAMP(3);   // sampling (table wait, thresholds, probability read issue)
 
-        STAMP(2);   // sampling (table wait, thresholds, probability read issue)
-        // --- pair tests, per-env facts, outcome
+        // --- pair tests, per-env facts
         const PairAcc<true> acc = quad_pair_tests<Q, false, true>(x, ca, cb, na, nb);
-        STAMP(3);   // pair tests
+        STAMP(4);   // pair tests
         const bool off_goal_next = na != ga || nb != gb;
         uint32_t flags = (PairAcc<true>::hit(acc.vertex) ? 1u : 0u) | (PairAcc<true>::hit(acc.swap) ? 2u : 0u) | (off_goal_next ? 4u : 0u);
         flags = group_reduce<Q, false>(flags, x);
         const uint32_t f = flags & 7u;
-        STAMP(4);   // flags + group reduce
+        STAMP(5);   // flags + group reduce
+
+        // --- outcome: the row (status for both criteria, reward for Makespan) is only REQUESTED here; everything the
+        // next step's table address depends on is re-derived from f without waiting for it
         const bool was_terminal = terminal != 0u;
-        // the outcome row is requested BEFORE the probability chain and consumed after it (one 16-byte LDS read whose
-        // latency the chain covers); its status word holds for both criteria, its reward for Makespan
-        const uint4 row = *reinterpret_cast<const uint4 *>(&outcome[f | (was_terminal ? 8u : 0u)]);
-        double prob = quad_prob_product<Q>(q[0], q[1], q[2], q[3]);
-        uint32_t row_lo = row.x, row_hi = row.y, status = row.z;
-        // the row is consumed here, after the chain (which only exists when the trajectory is recorded)
-        if (RECORD) asm volatile("" : "+v"(row_lo), "+v"(row_hi), "+v"(status), "+v"(prob));
-        double reward = __hiloint2double(int(row_hi), int(row_lo));
+        const OutcomeRow *row = &outcome[f | (was_terminal ? 8u : 0u)];
+        const uint32_t row_status = row->status;
+        const double row_reward = row->reward;                 // two plain reads, both unconditional
+        double soc_reward = 0.0;
         if (p.c.criteria != 0u) {
             // _living_reward: mapf_env.py:436-446
             const uint32_t goal[4] = {ga & 0xFFFFu, ga >> 16, gb & 0xFFFFu, gb >> 16};
@@ -311,28 +325,29 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
             const double living = __dmul_rn(double(int(n_agents) - stayed), p.c.r_living);
             const bool coll = (f & 3u) != 0u, goal_next = (f & 4u) == 0u;
             const double r = coll ? __dadd_rn(p.c.r_clash, living) : (goal_next ? __dadd_rn(p.c.r_goal, living) : living);
-            reward = was_terminal ? 0.0 : r;
+            soc_reward = was_terminal ? 0.0 : r;
         }
+        const double reward = p.c.criteria != 0u ? soc_reward : row_reward;
         if (was_terminal) { na = ca; nb = cb; }                // mapf_env.py:239-240 -- (s, 0, True, {"prob": 0})
-        STAMP(5);   // outcome row + probability product
-
-        ret = __dadd_rn(ret, reward);
-        episodes += status & 0xFFu;
-        collisions += (status >> 8) & 0xFFu;
-        if (RECORD) {
-            d_a = na; d_b = nb; d_reward = reward; d_prob = was_terminal ? 0.0 : prob;
-            d_flags = status;                                  // byte 0 done, byte 1 collision
+        p_reward = reward;
+        p_status = row_status;
+        p_a = na; p_b = nb;
+        if (RECORD) {                                          // a zero factor makes the whole product +0.0
+            pq0 = was_terminal ? 0.0 : q[0];
+            pq1 = q[1]; pq2 = q[2]; pq3 = q[3];
         }
-        STAMP(6);   // totals
-        // MapfEnv.reset(): start cells, no reseed.  `done` is re-derived from the facts (every f except "off goal,
-        // no collision" ends the episode) so that the next step's table address does not wait for the outcome row
-        const bool back = p.auto_reset && (f != 4u || was_terminal);
+        STAMP(6);   // outcome request, SoC living reward
+        // MapfEnv.reset(): start cells, no reseed.  Every f except "off goal, no collision" ends the episode; the
+        // returned state is terminal after a vertex collision or on goal (mapf_env.py:210-223), a swap alone is not
+        const bool done = f != 4u || was_terminal;
+        const bool next_terminal = ((f ^ 4u) & 5u) != 0u || was_terminal;
+        const bool back = p.auto_reset && done;
         ca = back ? sa : na;
         cb = back ? sb : nb;
-        terminal = back ? start_terminal : (status >> 16);
+        terminal = back ? start_terminal : (next_terminal ? 1u : 0u);
         STAMP(7);   // reset handling
     }
-    if (RECORD && p.n_steps > 0) store_record();               // flush the last step's outputs
+    if (p.n_steps > 0) finish_pending();                       // the last step's chain, totals and stores
 #ifdef MAPF_STAMPS
     if (x.lane == 0u && epi_p) {   // diagnostic build: segment sums replace the episode counts
         for (int k = 0; k < 8; ++k) epi_p[k] = uint32_t(st.seg[k]);
