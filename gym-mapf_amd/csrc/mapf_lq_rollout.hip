@@ -381,6 +381,16 @@ hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size
 bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, size_t mv_lds_limit, hipStream_t stream, hipError_t *err) {
     static const bool enabled = [] { const char *e = getenv("MAPF_QUAD_LANES"); return !e || atoi(e) != 0; }();
     if (!enabled || n_agents < 4 || n_agents % 4 != 0) return false;
+    // Half as many lanes per env means half as many waves: the quad layout only pays while it still keeps two waves on
+    // every SIMD (measured: 65536 envs x 8 agents = 2 waves/SIMD -> 460 G vs 413 G agent-steps/s for the pair layout;
+    // 32768 envs = 1 wave/SIMD -> 233 G vs 300 G).  MAPF_QUAD_MIN_LANES overrides the threshold (tests use 0).
+    static const uint64_t min_lanes = [] {
+        if (const char *e = getenv("MAPF_QUAD_MIN_LANES")) return uint64_t(strtoull(e, nullptr, 10));
+        int dev = 0, n_cu = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+            n_cu = 256;
+        return uint64_t(n_cu) * 4u * 64u * 2u;   // CUs x SIMDs x lanes x two waves
+    }();
     const int Q = n_agents / 4;
     if (Q > 16 || (Q & (Q - 1)) != 0) return false;
     const size_t mv_bytes = size_t(args.c.n_cells) * 5 * sizeof(MoveEntry);
@@ -388,7 +398,8 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, size_t mv_lds_
     const size_t copies = (kLdsBytes - kLdsReserve) / (mv_bytes + kLdsReserve);   // blocks per CU by LDS
     const unsigned block = copies >= 4 ? 256u : 512u;
     const uint64_t per_block = block / unsigned(Q);
-    if (args.n_envs % per_block != 0 || args.n_envs * uint64_t(Q) < 64 * 256) return false;
+    const uint64_t lanes = args.n_envs * uint64_t(Q);
+    if (args.n_envs % per_block != 0 || lanes < 64 * 256 || lanes < min_lanes) return false;
     const bool record = args.rec_local != nullptr, stream_actions = args.actions != nullptr;
     if (record && !(args.rec_reward && args.rec_prob && args.rec_done && args.rec_collision)) {
         *err = hipErrorInvalidValue;

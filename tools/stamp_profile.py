@@ -31,8 +31,13 @@ env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCri
                  device_arrays=True, start_local=start, goal_local=goal)
 actions = env.fill_random_actions(0, T)
 env.sync()
-names = ['loop top (actions, delayed stores)', 'slip Philox (1 step in 4) + table read', 'sampling + probability read', 'pair tests',
-         'flags + group reduce', 'probability product', 'reward / selects', 'reset handling']
+if PER_WAVE == 16:
+    names = ['loop top (actions, delayed stores)', 'slip Philox (1 step in 4) + table read', 'sampling + probability read',
+             'pair tests', 'flags + group reduce', 'probability product', 'reward / selects', 'reset handling']
+else:
+    names = ['loop top (actions, table read issue)', 'previous step: prob chain, totals, stores', 'slip Philox (1 step in 4)',
+             'sampling (table wait) + probability read', 'pair tests', 'flags + group reduce', 'outcome request',
+             'reset handling']
 for acts, label in ((actions, 'streamed actions'), (None, 'in-kernel policy')):
     for record in (True, False):
         env.reset()
