@@ -300,6 +300,37 @@ def test_recorded_rollout_of_full_groups_against_c_oracle(n_agents, n_envs):
         env.close()
 
 
+@pytest.mark.parametrize('n_agents,n_envs', [(4, 16384), (8, 8192), (8, 16448), (16, 4096)])
+def test_dense_rollout_split_launches_accumulate_and_single_steps(n_agents, n_envs):
+    """Quad-lane and pair layouts: a rollout split into launches of 1, 4 and 7 steps that accumulate into the same
+    totals equals one 12-step launch (returns bit for bit, episode and collision counts, final state), starting at a
+    step index that is not a multiple of 4 (the slip stream's call granularity)."""
+    rs = np.random.RandomState(900 + n_agents)
+    grid = MapfGrid([''.join('@' if rs.rand() < 0.15 else '.' for _ in range(18)) for _ in range(18)])
+    valid, _, nbr = grid.tables()
+    V, E, A = len(valid), n_envs, n_agents
+    start = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    goal = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    mk = lambda: VecMapfEnv(grid, A, None, None, 0.25, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=3,  # noqa: E731
+                            start_local=start, goal_local=goal)
+    one, parts = mk(), mk()
+    for env in (one, parts):
+        env.set_state(None, t=3)
+    full = one.rollout(12, auto_reset=True)
+    acc = parts.rollout(1, auto_reset=True)
+    acc = parts.rollout(4, auto_reset=True, accumulate_into=acc)
+    acc = parts.rollout(7, auto_reset=True, accumulate_into=acc)
+    assert np.array_equal(_bits(full['returns']), _bits(acc['returns']))
+    assert np.array_equal(full['episodes'], acc['episodes']) and np.array_equal(full['collisions'], acc['collisions'])
+    (s1, t1), (s2, t2) = one.get_state(), parts.get_state()
+    assert t1 == t2 == 15 and np.array_equal(s1, s2)
+    co = c_oracle.COracle(nbr, A, start, goal, 0.25, -1000.0, 100.0, -1.0, mo.MAKESPAN, seed=3)
+    co.t = 3
+    ref = co.rollout(12, auto_reset=True)
+    assert np.array_equal(_bits(full['returns']), _bits(ref['returns'])) and np.array_equal(s1, co.state)
+    one.close(), parts.close()
+
+
 # ----------------------------------------------------------------------- BASELINE.json full sizes
 def _full_size_check(grid, nbr, A, start, goal, fail_prob, crit, ocrit, n_step, n_roll, kernel='auto'):
     E = start.shape[0]
