@@ -127,22 +127,22 @@ int fetch_out(mapf_handle_t h, const T *dev, T *dst, size_t count) {
 // same operations CPython performs: rf = lf = fail_prob / 2 (:131-132), p0 = 1 - rf - lf (:167), drop
 // p <= 0 (:172), merge equal cells with old + new in first-seen order (:177-182); cum = np.cumsum.
 // Returns true when some list has more than one entry, i.e. a uniform is actually consumed.
-bool build_slip_table(double fail_prob, mapf::SlipRow (&rows)[8]) {
+bool build_slip_table(double fail_prob, mapf::SlipRow (&rows)[8], double (&cand_p)[3]) {
     const double rf = fail_prob / 2, lf = fail_prob / 2;
-    const double cand_p[3] = {(1 - rf) - lf, rf, lf};
+    cand_p[0] = (1 - rf) - lf; cand_p[1] = rf; cand_p[2] = lf;
     bool any_multi = false;
     for (unsigned code = 0; code < 8; ++code) {
         // representative cells realising the pattern (inconsistent codes cannot occur at run time)
         const int m = 0, r = (code & 1u) ? 0 : 1, l = (code & 2u) ? 0 : ((code & 4u) ? r : 2);
         const int cand_cell[3] = {m, r, l};
-        int cells[3] = {-1, -1, -1}, src[3] = {0, 0, 0}, n = 0;
+        int cells[3] = {-1, -1, -1}, src[3] = {0, 0, 0}, members[3] = {0, 0, 0}, n = 0;
         double q[3] = {0, 0, 0};
         for (int k = 0; k < 3; ++k) {
             if (!(cand_p[k] > 0)) continue;
             int hit = -1;
             for (int j = 0; j < n; ++j) if (cells[j] == cand_cell[k]) { hit = j; break; }
-            if (hit >= 0) q[hit] = q[hit] + cand_p[k];
-            else { cells[n] = cand_cell[k]; src[n] = k; q[n] = cand_p[k]; ++n; }
+            if (hit >= 0) { q[hit] = q[hit] + cand_p[k]; members[hit] |= 1 << k; }
+            else { cells[n] = cand_cell[k]; src[n] = k; q[n] = cand_p[k]; members[n] = 1 << k; ++n; }
         }
         mapf::SlipRow &row = rows[code];
         std::memset(&row, 0, sizeof(row));
@@ -157,6 +157,7 @@ bool build_slip_table(double fail_prob, mapf::SlipRow (&rows)[8]) {
                 row.thr[k] = scaled >= 9007199254740992.0 ? (uint64_t(1) << 53) : (scaled <= 0 ? 0 : uint64_t(scaled));
                 row.th[k] = uint32_t(row.thr[k] >> 37);
                 row.src |= uint32_t(src[k]) << (8 * k);
+                row.members |= uint32_t(members[k]) << (3 * k);
             } else {
                 row.cum[k] = -HUGE_VAL;
                 row.q[k] = 0.0;
@@ -259,7 +260,18 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
     h->lane_group_rollout = h->lane_group || A > uint32_t(mapf::kTpeRolloutMaxAgents);
 
     mapf::SlipRow slip_host[8];
-    h->c.need_rng = build_slip_table(d->fail_prob, slip_host) ? 1u : 0u;
+    h->c.need_rng = build_slip_table(d->fail_prob, slip_host, h->c.p_cand) ? 1u : 0u;
+    // the single-step kernels rebuild a merged probability from its members instead of reading the row: the ordered
+    // sum ((m ? p_m : 0) + (r ? p_r : 0)) + (l ? p_l : 0) must reproduce the table bit for bit
+    for (unsigned code = 0; code < 8; ++code)
+        for (unsigned k = 0; k < slip_host[code].n; ++k) {
+            const unsigned mem = (slip_host[code].members >> (3 * k)) & 7u;
+            const double q = (((mem & 1u) ? h->c.p_cand[0] : 0.0) + ((mem & 2u) ? h->c.p_cand[1] : 0.0)) + ((mem & 4u) ? h->c.p_cand[2] : 0.0);
+            if (std::memcmp(&q, &slip_host[code].q[k], sizeof(q)) != 0) {
+                destroy_impl(h);
+                return fail(MAPF_EINVAL, "create: merged slip probabilities are not reproducible from their members");
+            }
+        }
     h->c.r_clash = d->r_clash; h->c.r_goal = d->r_goal; h->c.r_living = d->r_living;
     h->c.criteria = d->criteria; h->c.n_cells = V;
     h->c.seed_lo = uint32_t(d->seed); h->c.seed_hi = uint32_t(d->seed >> 32);
@@ -301,7 +313,7 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
             for (int k = 0; k < 3; ++k) t16[k] = slip_host[code].th[k] > 65535u ? 65535u : slip_host[code].th[k];
             packed[size_t(v) * 5 + a] = make_uint4(uint32_t(cells[0]) | (uint32_t(cells[1]) << 16),
                                                     uint32_t(cells[2]) | (uint32_t(code) << 16) | (uint32_t(code * sizeof(mapf::SlipRow)) << 19),
-                                                    t16[0] | (t16[1] << 16), t16[2]);
+                                                    t16[0] | (t16[1] << 16), t16[2] | (slip_host[code].members << 16));
         }
     }
     const size_t row = size_t(A) * sizeof(uint16_t);

@@ -145,6 +145,21 @@ __device__ __forceinline__ void slip_move_hi(const SlipRow *lds_slip, const Move
     q = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lds_slip) + entry_row_offset(entry) + idx * 8u);
 }
 
+// The same, with the probability rebuilt from the slot's members (bits 16.. of entry.w) instead of read from the
+// row: ((m ? p_m : 0) + (r ? p_r : 0)) + (l ? p_l : 0) in the order the host merged them (old + new, first-seen
+// order; adding 0.0 is exact).  Used where the row would be one more dependent memory round trip (single steps).
+__device__ __forceinline__ void slip_move_hi_members(const EnvConsts &c, const MoveEntry &entry, uint32_t hi, uint32_t &next,
+                                                     double &q, uint32_t &tie_dist) {
+    const uint32_t t0 = entry.z & 0xFFFFu, t1 = entry.z >> 16, t2 = entry.w & 0xFFFFu;
+    const uint32_t d0 = hi - t0, d1 = hi - t1, d2 = hi - t2;
+    const bool b0 = int32_t(d0) < 0, b1 = int32_t(d1) < 0, b2 = int32_t(d2) < 0;
+    tie_dist = min(d0, min(d1, d2));
+    const uint32_t idx = b0 ? 0u : (b1 ? 1u : (b2 ? 2u : 0u));
+    next = entry_cell(entry, idx);
+    const uint32_t mem = (entry.w >> (16u + 3u * idx)) & 7u;
+    q = __dadd_rn(__dadd_rn((mem & 1u) ? c.p_cand[0] : 0.0, (mem & 2u) ? c.p_cand[1] : 0.0), (mem & 4u) ? c.p_cand[2] : 0.0);
+}
+
 // Slip stream (oracle/philox.py): one call with rslot = refine = 0 yields the four words that serve agents
 // (2*pair, 2*pair+1) at steps 4h .. 4h+3 -- word (t & 3): low half = top 16 bits of agent 2*pair's uniform, high
 // half = agent 2*pair+1's.  The low 37 bits of a slot's uniform come from a separate call (refine = 1, rslot =

@@ -13,7 +13,7 @@ namespace mapf {
 //   x = c0 | c1 << 16, y = c2 | code << 16 | (code * sizeof(SlipRow)) << 19 : the merged movement list's cells in
 //       list order + the equality code of the three candidates (selects the SlipRow with the list's probabilities /
 //       full-width thresholds; also pre-scaled to that row's byte offset);
-//   z = t0 | t1 << 16, w = t2              : top 16 bits of the cumulative thresholds, saturated to 65535 (0 past the
+//   z = t0 | t1 << 16, w = t2 | members << 16 : (members: SlipRow::members of the entry's code) top 16 bits of the cumulative thresholds, saturated to 65535 (0 past the
 //       end of the list).  hi16 < t_k decides `cum[k] > u` unless hi16 == t_k; that tie (which the saturation makes
 //       slightly more frequent: hi16 = 65535 against a threshold of 1.0) is resolved by the exact 53-bit path.
 using MoveEntry = uint4;
@@ -25,11 +25,12 @@ struct SlipRow {
     uint64_t thr[3];               // ceil(cum[k] * 2^53): cum[k] > u  <=>  mant(u) < thr[k]; 0 past the list end
     double cum[3];                 // running float64 sums (for caller-supplied uniforms); -inf past the list end
     uint32_t src;                  // byte k: candidate (0 m, 1 r, 2 l) in list slot k (host bookkeeping)
-    uint32_t pad;
+    uint32_t members;              // bits 3k..3k+2: which candidates (m, r, l) merged into list slot k
 };
 
 struct EnvConsts {
     double r_clash, r_goal, r_living;
+    double p_cand[3];              // probabilities of the three candidates: intended move, right slip, left slip
     uint32_t need_rng;             // 0 when every slip list has one entry (e.g. fail_prob == 0)
     uint32_t criteria;             // 0 Makespan, 1 SoC
     uint32_t n_cells;              // V

@@ -340,7 +340,8 @@ __device__ __forceinline__ void stage_outcome_table(const EnvConsts &c, OutcomeR
 // One transition for the group's env.  cur0/cur1: my agents' cells (ghost slots hold 0).  Every lane of the
 // group returns the same per-env results; next0/next1 are this lane's.  KNOWN_TERM: the caller already knows
 // is_terminal(prev) (rollout carries it from step to step); otherwise it is derived here.
-template <int L, bool FULL, bool EXT_UNIFORMS, bool KNOWN_TERM, bool MV_IN_LDS = false, bool OUTCOME_LDS = false>
+template <int L, bool FULL, bool EXT_UNIFORMS, bool KNOWN_TERM, bool MV_IN_LDS = false, bool OUTCOME_LDS = false,
+          bool Q_FROM_MEMBERS = false>
 __device__ __forceinline__ void lg_transition(const EnvConsts &c, const MoveEntry *__restrict__ mv,
                                               const SlipRow *lds_slip, const OutcomeRow *lds_outcome,
                                               const LaneCtx<L> &x, uint32_t n_agents,
@@ -364,8 +365,13 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const MoveEntr
         const uint32_t hi0 = word & 0xFFFFu, hi1 = word >> 16;
         STAMP(1);   // philox + gather issue
         uint32_t tie0, tie1;
-        slip_move_hi(lds_slip, entry0, hi0, next0, q0, tie0);
-        slip_move_hi(lds_slip, entry1, hi1, next1, q1, tie1);
+        if (Q_FROM_MEMBERS) {
+            slip_move_hi_members(c, entry0, hi0, next0, q0, tie0);
+            slip_move_hi_members(c, entry1, hi1, next1, q1, tie1);
+        } else {
+            slip_move_hi(lds_slip, entry0, hi0, next0, q0, tie0);
+            slip_move_hi(lds_slip, entry1, hi1, next1, q1, tie1);
+        }
         if (__builtin_expect(__any(min(tie0, tie1) == 0u && c.need_rng), 0)) {
             // a top-16-bit tie somewhere in the wave (~2^-8 of wave-steps): redo with all 53 bits
             slip_move<false>(lds_slip, entry0, refine_mantissa(c, env_id, t, 2u * x.g, hi0), 0.0, next0, q0);
@@ -481,7 +487,9 @@ __device__ __forceinline__ LaneCtx<L> lane_ctx(uint32_t n_agents, uint64_t n_env
 
 static inline void lg_geometry(int L, uint64_t n_envs, unsigned &grid, unsigned &block) {
     const uint64_t threads = n_envs * uint64_t(L);
-    block = threads <= (uint64_t(1) << 19) ? 64u : 256u;       // keep >= ~2 blocks per CU at small sizes
+    // one-wave blocks keep >= ~2 blocks per CU at small sizes; from two waves per SIMD upward four-wave blocks launch
+    // faster (measured at 65536 envs x 8 agents: 5.29 us per step instead of 5.67)
+    block = threads < (uint64_t(1) << 17) ? 64u : 256u;
     const uint64_t per_block = block / unsigned(L);
     grid = unsigned((n_envs + per_block - 1) / per_block);
 }

@@ -19,8 +19,9 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
         if (x.v0) u0 = up[0];
         if (x.v1) u1 = up[1];
     }
-    // A single step is launch-latency bound: the 8 slip rows are read straight from global memory (they stay in
-    // L1/L2) rather than staged into LDS behind a barrier -- measured 2-3 % faster per launch.
+    // A single step is launch-latency bound: the sampled probability is rebuilt from its members (no third dependent
+    // memory round trip); the 8 slip rows are only read on the exact-tie path and for caller-supplied uniforms,
+    // straight from global memory (they stay in L1/L2) rather than staged into LDS behind a barrier.
     const SlipRow *rows = p.slip;
 
     uint32_t next0, next1;
@@ -30,7 +31,7 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
 #endif
     Words4 rng{0u, 0u, 0u, 0u};
     if (!EXT_UNIFORMS && p.c.need_rng) rng = slip_words(p.c, p.env_id_offset + e, p.t >> 2, x.g, 0u, 0u);
-    lg_transition<L, FULL, EXT_UNIFORMS, false>(p.c, p.mv, rows, nullptr, x, n_agents, cur0, cur1, goal0, goal1, act0, act1,
+    lg_transition<L, FULL, EXT_UNIFORMS, false, false, false, !EXT_UNIFORMS>(p.c, p.mv, rows, nullptr, x, n_agents, cur0, cur1, goal0, goal1, act0, act1,
                                                 u0, u1, p.env_id_offset + e, p.t, rng, false, next0, next1, o STAMP_ARG);
     if (!live) return;
 
