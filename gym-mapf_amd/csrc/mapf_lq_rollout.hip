@@ -41,12 +41,9 @@ __device__ __forceinline__ uint32_t sample_slot(const SlipRow *lds_slip, const M
     q = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lds_slip) + entry_row_offset(entry) + idx * 8u);
     return idx;
 }
-// list slot idx of an entry as the LOW / HIGH half-word of a dword (other half zero): one v_perm_b32 each
+// list slot idx of an entry, zero-extended: one v_perm_b32
 __device__ __forceinline__ uint32_t cell_lo(const MoveEntry &entry, uint32_t idx) {
     return __builtin_amdgcn_perm(entry.y, entry.x, 0x0C0C0100u + idx * 0x0202u);
-}
-__device__ __forceinline__ uint32_t cell_hi(const MoveEntry &entry, uint32_t idx) {
-    return __builtin_amdgcn_perm(entry.y, entry.x, 0x01000C0Cu + idx * 0x02020000u);
 }
 
 // "same half-word" tests only: my pair against a pair that arrives straight or half-swapped (half rotation)
@@ -286,8 +283,8 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         uint32_t idx[4], tie[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) idx[k] = sample_slot(slip, entry[k], hi[k], q[k], tie[k]);
-        uint32_t na = cell_lo(entry[0], idx[0]) | cell_hi(entry[1], idx[1]);
-        uint32_t nb = cell_lo(entry[2], idx[2]) | cell_hi(entry[3], idx[3]);
+        uint32_t na = cell_lo(entry[0], idx[0]) | (cell_lo(entry[1], idx[1]) << 16);   // one v_lshl_or_b32 per pair
+        uint32_t nb = cell_lo(entry[2], idx[2]) | (cell_lo(entry[3], idx[3]) << 16);
         if (__builtin_expect(__any(min(min(tie[0], tie[1]), min(tie[2], tie[3])) == 0u && p.c.need_rng), 0)) {
             // a top-16-bit tie somewhere in the wave: redo with all 53 bits
             uint32_t nx[4];
