@@ -18,7 +18,9 @@ ALGORITHMIC = {"rollout_kernel": int(T * E * A * BYTES_PER_AGENT_STEP), "lg_step
 
 
 def per_kernel(path, counter):
-    total, count, names = collections.Counter(), collections.Counter(), {}
+    """{kernel key: (mean counter value, dispatches, full name)}.  The bench also launches one short rollout (the
+    8-step parity leg): dispatches whose value is below half of the kernel's largest are left out of the mean."""
+    values, names = collections.defaultdict(list), {}
     with open(path) as f:
         for r in csv.DictReader(f):
             if r["Counter_Name"] != counter:
@@ -26,10 +28,13 @@ def per_kernel(path, counter):
             name = r["Kernel_Name"]
             for key in ("rollout_kernel", "lg_step_kernel", "reset_kernel", "fill_actions_kernel"):
                 if key in name:   # "rollout_kernel" matches the quad-lane (lq_) and the pair (lg_) layout
-                    total[key] += float(r["Counter_Value"])
-                    count[key] += 1
+                    values[key].append(float(r["Counter_Value"]))
                     names[key] = name
-    return {k: (total[k] / count[k], count[k], names[k]) for k in total}
+    out = {}
+    for k, v in values.items():
+        full = [x for x in v if x >= 0.5 * max(v)] if k == "rollout_kernel" else v
+        out[k] = (sum(full) / len(full), len(full), names[k])
+    return out
 
 
 def main():

@@ -10,6 +10,7 @@ export TMPDIR=/tmp
 rm -rf /tmp/prof && mkdir -p /tmp/prof
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof/stats -- python3 bench.py --no-cpu-baseline > "$out/${tag}_bench_under_rocprof.json"
 cp /tmp/prof/stats/*/*kernel_stats.csv "$out/${tag}_bench_kernel_stats.csv"
+python3 tools/kernel_durations.py /tmp/prof/stats/*/*kernel_trace.csv > "$out/${tag}_bench_kernel_durations.txt"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof/fetch -- python3 bench.py --no-cpu-baseline > /dev/null
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/prof/write -- python3 bench.py --no-cpu-baseline > /dev/null
 python3 tools/pmc_compact.py /tmp/prof/fetch/*/*counter_collection.csv > "$out/${tag}_pmc_fetch_size.csv"
