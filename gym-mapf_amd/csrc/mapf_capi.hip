@@ -62,8 +62,8 @@ struct mapf_handle_s {
     uint16_t *state = nullptr, *start = nullptr, *goal = nullptr;
     // host-pointer mode staging
     DeviceBuf s_actions, s_uniforms, s_local, s_reward, s_prob, s_done, s_coll, s_term, s_mask, s_ret, s_epi, s_ncoll;
-    DeviceBuf x_local, x_reward, x_prob, x_done, x_coll;
-    DeviceBuf q_local, q_actions, q_env, q_count, q_next, q_prob, q_reward, q_done, q_coll;   // mapf_transitions staging   // stand-ins for trajectory arrays the caller left out
+    DeviceBuf x_local, x_reward, x_prob, x_done, x_coll;   // stand-ins for trajectory arrays the caller left out
+    DeviceBuf q_local, q_actions, q_env, q_count, q_next, q_prob, q_reward, q_done, q_coll;   // mapf_transitions staging
 };
 
 namespace {
