@@ -280,11 +280,18 @@ def test_recorded_rollout_of_full_groups_against_c_oracle(n_agents, n_envs):
     goal = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
     goal[::7] = start[::7]                                   # some envs start in a terminal state
     ids = 77 + np.arange(E)
-    for crit, ocrit, auto, streamed in ((OptimizationCriteria.Makespan, mo.MAKESPAN, True, True),
-                                        (OptimizationCriteria.SoC, mo.SOC, False, False)):
-        env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, crit, seed=11, env_id_offset=77,
-                         start_local=start, goal_local=goal)
-        co = c_oracle.COracle(nbr, A, start, goal, 0.2, -1000.0, 100.0, -1.0, ocrit, seed=11, env_id_offset=77)
+    # third and fourth pass: no slip at all (no uniform is consumed) and fail_prob = 1 (the intended move has
+    # probability 0 and is dropped from the list), with one start / goal row broadcast to every env
+    for crit, ocrit, auto, streamed, fail_prob, bcast in (
+            (OptimizationCriteria.Makespan, mo.MAKESPAN, True, True, 0.2, False),
+            (OptimizationCriteria.SoC, mo.SOC, False, False, 0.2, False),
+            (OptimizationCriteria.Makespan, mo.MAKESPAN, True, False, 0.0, True),
+            (OptimizationCriteria.SoC, mo.SOC, True, True, 1.0, True)):
+        st, gl = (start[0], goal[1]) if bcast else (start, goal)
+        env = VecMapfEnv(grid, A, None, None, fail_prob, -1000.0, 100.0, -1.0, crit, seed=11, env_id_offset=77,
+                         start_local=st, goal_local=gl, n_envs=E)
+        co = c_oracle.COracle(nbr, A, np.broadcast_to(st, (E, A)).copy(), np.broadcast_to(gl, (E, A)).copy(), fail_prob,
+                              -1000.0, 100.0, -1.0, ocrit, seed=11, env_id_offset=77)
         acts = np.stack([philox.random_actions_np(11, ids, t, A) for t in range(T)])
         res = env.rollout(T, actions=acts if streamed else None, auto_reset=auto, record=True)
         ret = np.zeros(E)
