@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -59,6 +60,8 @@ struct mapf_handle_s {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     mapf::MoveEntry *mv = nullptr;
     mapf::SlipRow *slip = nullptr;
+    std::vector<uint16_t> nbr;        // host copy of the neighbour table (policy tables are derived from it)
+    uint2 *policy_cells = nullptr;    // greedy policy table (mapf_set_policy); null = random policy stream
     uint16_t *state = nullptr, *start = nullptr, *goal = nullptr;
     // host-pointer mode staging
     DeviceBuf s_actions, s_uniforms, s_local, s_reward, s_prob, s_done, s_coll, s_term, s_mask, s_ret, s_epi, s_ncoll;
@@ -180,6 +183,7 @@ void destroy_impl(mapf_handle_t h) {
                          &h->q_prob, &h->q_reward, &h->q_done, &h->q_coll})
         b->release();
     if (h->mv) (void)hipFree(h->mv);
+    if (h->policy_cells) (void)hipFree(h->policy_cells);
     if (h->slip) (void)hipFree(h->slip);
     if (h->state) (void)hipFree(h->state);
     if (h->start) (void)hipFree(h->start);
@@ -317,6 +321,7 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
         }
     }
     const size_t row = size_t(A) * sizeof(uint16_t);
+    h->nbr.assign(d->nbr, d->nbr + size_t(V) * 5);
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->mv), packed.size() * sizeof(mapf::MoveEntry)));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->state), (E ? E : 1) * row));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->start), (sb ? 1 : (E ? E : 1)) * row));
@@ -435,6 +440,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     mapf::RolloutArgs a{};
     a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
     a.n_envs = h->E; a.env_id_offset = h->env_id_offset; a.t = h->t; a.n_steps = io->n_steps;
+    a.policy_cells = h->policy_cells;
     a.start_broadcast = h->start_broadcast; a.goal_broadcast = h->goal_broadcast;
     a.auto_reset = io->step_flags & MAPF_STEP_AUTO_RESET;
     a.accumulate = io->accumulate != 0;
@@ -485,6 +491,42 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     if (int rc = fetch_out(h, a.rec_done, io->rec_done, TE)) return rc;
     if (int rc = fetch_out(h, a.rec_collision, io->rec_collision, TE)) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    return MAPF_OK;
+}
+
+int mapf_set_policy(mapf_handle_t h, int policy, const uint32_t *cell_rc) {
+    if (int rc = check_handle(h)) return rc;
+    if (policy != MAPF_POLICY_RANDOM && policy != MAPF_POLICY_GREEDY) return fail(MAPF_EINVAL, "set_policy: unknown policy");
+    HIP_TRY(hipStreamSynchronize(h->stream));   // no launch may still be reading the old table
+    if (policy == MAPF_POLICY_RANDOM) {
+        if (h->policy_cells) { (void)hipFree(h->policy_cells); h->policy_cells = nullptr; }
+        return MAPF_OK;
+    }
+    if (!cell_rc) return fail(MAPF_EINVAL, "set_policy: the greedy policy needs cell_rc");
+    // For every cell and every direction (sign of goal row - row, sign of goal col - col) the first action in
+    // ACTIONS order that is not blocked and lands one step closer; whether a move helps is read off the
+    // coordinates of its target, so no axis convention is assumed.
+    std::vector<uint2> cells(h->V);
+    for (uint32_t v = 0; v < h->V; ++v) {
+        const int r = int(cell_rc[v] & 0xFFFFu), c = int(cell_rc[v] >> 16);
+        uint32_t best = 0;
+        for (int sr = -1; sr <= 1; ++sr)
+            for (int sc = -1; sc <= 1; ++sc) {
+                uint32_t pick = 0;   // STAY
+                for (uint32_t a = 1; a < 5 && pick == 0; ++a) {
+                    const uint32_t tgt = h->nbr[size_t(v) * 5 + a];
+                    if (tgt == v) continue;   // blocked
+                    const int dr = int(cell_rc[tgt] & 0xFFFFu) - r, dc = int(cell_rc[tgt] >> 16) - c;
+                    if ((std::abs(dr) + std::abs(dc)) != 1)
+                        return fail(MAPF_EINVAL, "set_policy: cell_rc does not match the neighbour table (a move must change one coordinate by one)");
+                    if ((dr != 0 && dr == sr) || (dc != 0 && dc == sc)) pick = a;
+                }
+                best |= pick << (3 * (3 * (sr + 1) + (sc + 1)));
+            }
+        cells[v] = make_uint2(cell_rc[v], best);
+    }
+    if (!h->policy_cells) HIP_TRY(hipMalloc(reinterpret_cast<void **>(&h->policy_cells), cells.size() * sizeof(uint2)));
+    HIP_TRY(hipMemcpy(h->policy_cells, cells.data(), cells.size() * sizeof(uint2), hipMemcpyHostToDevice));
     return MAPF_OK;
 }
 

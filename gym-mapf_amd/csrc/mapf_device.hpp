@@ -306,6 +306,16 @@ __device__ __forceinline__ void env_transition(const EnvConsts &c, const MoveEnt
     out.reward = coll ? __dadd_rn(c.r_clash, living) : (goal_next ? __dadd_rn(c.r_goal, living) : living);
 }
 
+// Greedy policy (include/mapf_hip.h MAPF_POLICY_GREEDY; no reference counterpart): cells[c] = {row | col << 16,
+// nine 3-bit actions indexed by 3 * (sgn(goal_row - row) + 1) + (sgn(goal_col - col) + 1)} -- the first action in
+// ACTIONS order that is not blocked and moves one step closer to a goal lying in that direction, else STAY.
+__device__ __forceinline__ uint32_t greedy_action(const uint2 *cells, uint32_t cell, uint32_t goal_rc) {
+    const uint2 pc = cells[cell];
+    const int r = int(pc.x & 0xFFFFu), c = int(pc.x >> 16), gr = int(goal_rc & 0xFFFFu), gc = int(goal_rc >> 16);
+    const int k = 3 * ((gr > r) - (gr < r) + 1) + ((gc > c) - (gc < c) + 1);
+    return (pc.y >> (3 * k)) & 7u;
+}
+
 // Policy stream (oracle/philox.py random_actions_np): one Philox call per 4 agents.
 template <int A>
 __device__ __forceinline__ void policy_actions(const EnvConsts &c, uint64_t env_id, uint64_t t,

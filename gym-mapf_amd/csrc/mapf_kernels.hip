@@ -94,6 +94,9 @@ __global__ void __launch_bounds__(256) rollout_kernel(const RolloutArgs p) {
             const Row<uint8_t, A> ar = load_row<uint8_t, A>(p.actions, row);
 #pragma unroll
             for (int i = 0; i < A; ++i) act[i] = ar.v[i];
+        } else if (p.policy_cells) {
+#pragma unroll
+            for (int i = 0; i < A; ++i) act[i] = greedy_action(p.policy_cells, cur[i], p.policy_cells[goal[i]].x);
         } else {
             policy_actions<A>(p.c, env_id, t, act);
         }

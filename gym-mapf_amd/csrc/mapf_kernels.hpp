@@ -59,7 +59,8 @@ struct RolloutArgs {
     const SlipRow *slip;
     uint16_t *state;
     const uint16_t *start, *goal;
-    const uint8_t *actions;        // [T*E*A] or null (policy stream)
+    const uint8_t *actions;        // [T*E*A] or null (on-device policy)
+    const uint2 *policy_cells;     // greedy policy: [V] {row | col << 16, nine 3-bit actions}; null = random policy stream
     double *out_returns;
     uint32_t *out_episodes, *out_collisions;
     uint16_t *rec_local;

@@ -167,6 +167,9 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     };
     const uint8_t *act_lane = STREAM ? p.actions + lane_cell : nullptr;   // the row being prefetched
 
+    uint32_t goal_rc0 = 0u, goal_rc1 = 0u;   // greedy policy: my agents' goal coordinates
+    if (!STREAM && p.policy_cells) { goal_rc0 = p.policy_cells[goal0].x; goal_rc1 = p.policy_cells[goal1].x; }
+
     for (uint32_t s = 0; s < p.n_steps; ++s) {
         const uint64_t t = p.t + s;
         uint32_t act0, act1;
@@ -180,6 +183,9 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
                 act_lane += step_cells;
                 raw = load_actions_raw<FULL>(act_lane, 0u, 0u, 0u, x.v0, x.v1);
             }
+        } else if (p.policy_cells) {   // greedy policy (ghost slots read cell 0: their actions are never used)
+            act0 = greedy_action(p.policy_cells, cur0, goal_rc0);
+            act1 = greedy_action(p.policy_cells, cur1, goal_rc1);
         } else {   // policy stream: one Philox call covers agents 4q..4q+3; this lane needs words 2(g&1), 2(g&1)+1
             uint32_t w[4];
             const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | ((x.g >> 1) << 24);

@@ -239,6 +239,13 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         }
     };
 
+    uint32_t goal_rc[4] = {0u, 0u, 0u, 0u};   // greedy policy: my agents' goal coordinates
+    if (!STREAM && p.policy_cells) {
+        const uint32_t goal_cell[4] = {ga & 0xFFFFu, ga >> 16, gb & 0xFFFFu, gb >> 16};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) goal_rc[k] = p.policy_cells[goal_cell[k]].x;
+    }
+
     for (uint32_t s = 0; s < p.n_steps; ++s) {
         const uint64_t t = p.t + s;
         uint32_t act[4];
@@ -247,6 +254,10 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
             asm volatile("" : "+v"(act[0]), "+v"(act[1]), "+v"(act[2]), "+v"(act[3]));   // the wait for `raw` sits here
             act_lane += (s + 1u < p.n_steps) ? step_cells : 0u;   // clamped, not guarded: the last step re-reads its row
             raw = *reinterpret_cast<const uint32_t *>(act_lane);
+        } else if (p.policy_cells) {   // greedy policy
+            const uint32_t at_cell[4] = {ca & 0xFFFFu, ca >> 16, cb & 0xFFFFu, cb >> 16};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) act[k] = greedy_action(p.policy_cells, at_cell[k], goal_rc[k]);
         } else {   // policy stream: one Philox call covers exactly my agents 4g .. 4g+3
             uint32_t w[4];
             const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | (x.g << 24);

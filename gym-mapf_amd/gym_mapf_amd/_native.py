@@ -15,6 +15,7 @@ MAPF_MAKESPAN, MAPF_SOC = 0, 1
 MAPF_FLAG_DEVICE_PTRS, MAPF_FLAG_START_BROADCAST, MAPF_FLAG_GOAL_BROADCAST = 0x1, 0x2, 0x4
 MAPF_FLAG_THREAD_PER_ENV, MAPF_FLAG_LANE_GROUP = 0x10, 0x20
 MAPF_TPE_MAX_AGENTS = 16
+MAPF_POLICY_RANDOM, MAPF_POLICY_GREEDY = 0, 1
 MAPF_STEP_AUTO_RESET = 0x1
 
 
@@ -47,6 +48,7 @@ SIGNATURES = {
     'mapf_step': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_uint32]),
     'mapf_rollout': (c_int, [c_void_p, POINTER(MapfRolloutIO)]),
     'mapf_fill_random_actions': (c_int, [c_void_p, c_void_p, c_uint64, c_uint32]),
+    'mapf_set_policy': (c_int, [c_void_p, c_int, c_void_p]),
     'mapf_transitions': (c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
     'mapf_query_terminal': (c_int, [c_void_p, c_void_p]),

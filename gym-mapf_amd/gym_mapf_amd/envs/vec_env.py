@@ -283,6 +283,21 @@ class VecMapfEnv:
                                                      int(t0), int(n_steps)))
         return out
 
+    def set_policy(self, policy='random'):
+        """On-device policy of ``rollout(actions=None)``: ``'random'`` (default; the uniform-random action stream)
+        or ``'greedy'`` -- every agent takes the first action in ACTIONS order whose intended target is closest
+        (Manhattan distance) to its goal, i.e. the first unblocked move one step closer, else STAY.  The reference
+        has no policy; this stands in for the caller-side ``a = policy(s)`` of the loop around ``step``."""
+        if policy == 'random':
+            nat.check(self._lib.mapf_set_policy(self._h, nat.MAPF_POLICY_RANDOM, None))
+        elif policy == 'greedy':
+            valid, _, _ = self.grid.tables()
+            rc = np.ascontiguousarray([r | (c << 16) for r, c in valid], dtype=np.uint32)
+            nat.check(self._lib.mapf_set_policy(self._h, nat.MAPF_POLICY_GREEDY, rc.ctypes.data))
+        else:
+            raise ValueError("policy must be 'random' or 'greedy'")
+        self.policy = policy
+
     def query_terminal(self, out=None):
         """``MapfEnv.is_terminal`` of every env's current state: uint8 [E]."""
         if out is None:

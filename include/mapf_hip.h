@@ -153,6 +153,19 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io);
 int mapf_fill_random_actions(mapf_handle_t h, uint8_t *actions, uint64_t t0, uint32_t n_steps);
 
 /*
+ * On-device policy of mapf_rollout calls that pass actions == NULL (the reference has no policy; this stands in
+ * for the caller-side `a = policy(s)` of the loop around MapfEnv.step).
+ *   MAPF_POLICY_RANDOM (default): the uniform-random policy stream, as mapf_fill_random_actions.
+ *   MAPF_POLICY_GREEDY: every agent takes the first action in ACTIONS order (STAY, UP, RIGHT, DOWN, LEFT) whose
+ *     intended target cell is closest (Manhattan distance over grid rows / columns) to its goal -- i.e. the first
+ *     unblocked move that brings it one step closer, else STAY.  Slip still applies.  cell_rc u32[V] (HOST
+ *     pointer, copied): row | col << 16 of every free cell (rows and columns below 65536).
+ */
+#define MAPF_POLICY_RANDOM 0
+#define MAPF_POLICY_GREEDY 1
+int mapf_set_policy(mapf_handle_t h, int policy, const uint32_t *cell_rc);
+
+/*
  * MapfEnv.P[s][a] (mapf_env.py:448-478 _get_transitions): for each of n_queries (state, joint action) pairs,
  * every branch of the joint slip distribution, in the reference's order (itertools.product over the agents'
  * merged movement lists, agent 0 slowest).  Does not touch the handle's env state or step index.

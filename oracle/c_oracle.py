@@ -22,6 +22,8 @@ def load():
                                     ctypes.c_int, _P, _P, _P, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint64,
                                     ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                                     ctypes.c_uint32, ctypes.c_int, _P, _P, _P, _P, _P, _P]
+        lib.oracle_greedy_actions.restype = None
+        lib.oracle_greedy_actions.argtypes = [_P, ctypes.c_uint32, ctypes.c_uint64, _P, _P, _P, ctypes.c_int, _P]
         lib.oracle_rollout.restype = ctypes.c_uint64
         lib.oracle_rollout.argtypes = [_P, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint64, _P, ctypes.c_int, _P,
                                        ctypes.c_int, _P, _P, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_uint64,
@@ -71,6 +73,13 @@ class COracle:
                                 _p(out['collision']), _p(out['prob']), _p(out['was_terminal']))
         assert rc == 0
         self.t += 1
+        return out
+
+    def greedy_actions(self, cell_rc):
+        """MAPF_POLICY_GREEDY actions u8[E, A] for the current states; cell_rc u32[V] = row | col << 16."""
+        cell_rc = np.ascontiguousarray(cell_rc, dtype=np.uint32)
+        out = np.empty((self.E, self.A), np.uint8)
+        load().oracle_greedy_actions(_p(self.nbr), self.A, self.E, _p(cell_rc), _p(self.state), _p(self.goal), self.gb, _p(out))
         return out
 
     def rollout(self, n_steps, actions=None, auto_reset=True):

@@ -197,3 +197,23 @@ uint64_t oracle_rollout(const uint16_t *nbr, uint32_t V, uint32_t A, uint64_t E,
     }
     return (uint64_t)T * E * A;
 }
+
+/* MAPF_POLICY_GREEDY of include/mapf_hip.h, straight from its definition (no reference counterpart): for every agent
+ * the action a = 0..4 (STAY, UP, RIGHT, DOWN, LEFT) whose intended target nbr[cell][a] minimises the Manhattan distance
+ * to the agent's goal over cell_rc (row | col << 16), first minimum wins.  out_actions u8[E*A]. */
+void oracle_greedy_actions(const uint16_t *nbr, uint32_t A, uint64_t E, const uint32_t *cell_rc,
+                           const uint16_t *state, const uint16_t *goal, int goal_bcast, uint8_t *out_actions) {
+    for (uint64_t e = 0; e < E; ++e)
+        for (uint32_t i = 0; i < A; ++i) {
+            const uint32_t cur = state[e * A + i], g = goal[(goal_bcast ? 0 : e * A) + i];
+            const int gr = (int)(cell_rc[g] & 0xFFFFu), gc = (int)(cell_rc[g] >> 16);
+            int best = 0, best_d = 0;
+            for (int a = 0; a < 5; ++a) {
+                const uint32_t t = nbr[(size_t)cur * 5 + a];
+                const int dr = (int)(cell_rc[t] & 0xFFFFu) - gr, dc = (int)(cell_rc[t] >> 16) - gc;
+                const int d = (dr < 0 ? -dr : dr) + (dc < 0 ? -dc : dc);
+                if (a == 0 || d < best_d) { best = a; best_d = d; }
+            }
+            out_actions[e * A + i] = (uint8_t)best;
+        }
+}

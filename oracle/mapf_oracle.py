@@ -163,6 +163,17 @@ class OracleEnv:
         self._dist = {}
         self.local = self.start
 
+    # -- MAPF_POLICY_GREEDY of include/mapf_hip.h (no reference counterpart): per agent the action whose intended
+    #    target is closest (Manhattan, over (row, col) locations) to its goal, first minimum in ACTIONS order wins
+    def greedy_actions(self):
+        acts = []
+        for cell, goal in zip(self.local, self.goal):
+            gr, gc = self.cells[goal]
+            dist = [abs(self.cells[self.nbr[cell][a]][0] - gr) + abs(self.cells[self.nbr[cell][a]][1] - gc)
+                    for a in range(N_ACTIONS)]
+            acts.append(dist.index(min(dist)))
+        return acts
+
     # -- reference reset(): mapf_env.py:290-293 (no reseed)
     def reset(self):
         self.local = self.start

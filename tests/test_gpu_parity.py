@@ -338,6 +338,41 @@ def test_dense_rollout_split_launches_accumulate_and_single_steps(n_agents, n_en
     one.close(), parts.close()
 
 
+@pytest.mark.parametrize('n_agents,n_envs,kernel', [(2, 300, 'thread_per_env'), (5, 300, 'thread_per_env'), (3, 257, 'lane_group'),
+                                                    (8, 8192, 'auto'), (8, 16448, 'auto'), (16, 4096, 'auto'), (7, 1000, 'auto')])
+def test_greedy_policy_rollout_against_c_oracle(n_agents, n_envs, kernel):
+    """mapf_set_policy(MAPF_POLICY_GREEDY): the fused rollout with the on-device greedy policy (thread-per-env,
+    pair and quad-lane kernels) records exactly the trajectory the C oracle produces when it is stepped with the
+    greedy actions of its own restatement; switching back to the random policy restores the policy stream."""
+    rs = np.random.RandomState(700 + n_agents)
+    lines = [''.join('@' if rs.rand() < 0.15 else '.' for _ in range(20)) for _ in range(20)]
+    grid = MapfGrid(lines)
+    valid, _, nbr = grid.tables()
+    rc = np.asarray([r | (c << 16) for r, c in valid], np.uint32)
+    V, E, A, T = len(valid), n_envs, n_agents, 20
+    start = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    goal = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=21,
+                     start_local=start, goal_local=goal, kernel=kernel)
+    co = c_oracle.COracle(nbr, A, start, goal, 0.2, -1000.0, 100.0, -1.0, mo.MAKESPAN, seed=21)
+    env.set_policy('greedy')
+    res = env.rollout(T, auto_reset=True, record=True)
+    goals_reached = 0
+    for t in range(T):
+        ref = co.step(co.greedy_actions(rc), auto_reset=True)
+        assert np.array_equal(res['local'][t], ref['local']), (A, t)
+        assert np.array_equal(_bits(res['reward'][t]), _bits(ref['reward'])) and np.array_equal(_bits(res['prob'][t]), _bits(ref['prob']))
+        assert np.array_equal(res['done'][t], ref['done']) and np.array_equal(res['collision'][t], ref['collision'])
+        goals_reached += int((ref['done'] & ~ref['collision']).sum())
+    assert np.array_equal(env.get_state()[0], co.state)
+    assert A > 3 or goals_reached > 0                        # small teams do arrive within 20 greedy steps
+    env.set_policy('random')
+    ref = co.rollout(6, auto_reset=True)
+    out = env.rollout(6, auto_reset=True)
+    assert np.array_equal(_bits(out['returns']), _bits(ref['returns'])) and np.array_equal(env.get_state()[0], co.state)
+    env.close()
+
+
 # ----------------------------------------------------------------------- BASELINE.json full sizes
 def _full_size_check(grid, nbr, A, start, goal, fail_prob, crit, ocrit, n_step, n_roll, kernel='auto'):
     E = start.shape[0]

@@ -145,3 +145,32 @@ def test_c_oracle_rollout_returns(trajectory_set):
             ret = ret + g['reward'][t, j]
         assert _bits(out['returns'][0]) == _bits(ret)
         assert out['episodes'][0] == g['done'][:, j].sum() and out['collisions'][0] == g['collision'][:, j].sum()
+
+
+def test_greedy_policy_definitions_agree_and_walk_to_the_goal():
+    """MAPF_POLICY_GREEDY (include/mapf_hip.h; no reference counterpart): the Python and the C restatement pick the
+    same actions on random obstacle maps, and on an open grid without slip a lone agent reaches its goal in exactly
+    Manhattan-distance steps."""
+    import c_oracle
+    from gym_mapf_amd.envs.grid import MapfGrid
+    rs = np.random.RandomState(5)
+    lines = [''.join('@' if rs.rand() < 0.2 else '.' for _ in range(12)) for _ in range(9)]
+    grid = MapfGrid(lines)
+    valid, _, nbr = grid.tables()
+    rc = np.asarray([r | (c << 16) for r, c in valid], np.uint32)
+    A, E = 3, 40
+    state = np.stack([rs.choice(len(valid), A, replace=False) for _ in range(E)]).astype(np.uint16)
+    goal = np.stack([rs.choice(len(valid), A, replace=False) for _ in range(E)]).astype(np.uint16)
+    co = c_oracle.COracle(nbr, A, state, goal, 0.0, -1000.0, 100.0, -1.0, mo.MAKESPAN, seed=1)
+    acts = co.greedy_actions(rc)
+    for e in range(E):
+        env = mo.OracleEnv(lines, A, [valid[i] for i in state[e]], [valid[i] for i in goal[e]], 0.0, -1000.0, 100.0, -1.0)
+        assert env.greedy_actions() == acts[e].tolist()
+    # open grid, one agent, no slip: the walk takes exactly the Manhattan distance
+    open_lines = ['.' * 7] * 6
+    env = mo.OracleEnv(open_lines, 1, [(5, 0)], [(1, 4)], 0.0, -1000.0, 100.0, -1.0)
+    for n in range(1, 20):
+        _, _, done, _, _, _ = env.step(env.greedy_actions(), [0.5])
+        if done:
+            break
+    assert n == 4 + 4 and env.local == env.goal
