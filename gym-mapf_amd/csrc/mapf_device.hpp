@@ -309,8 +309,8 @@ __device__ __forceinline__ void env_transition(const EnvConsts &c, const MoveEnt
 // Greedy policy (include/mapf_hip.h MAPF_POLICY_GREEDY; no reference counterpart): cells[c] = {row | col << 16,
 // nine 3-bit actions indexed by 3 * (sgn(goal_row - row) + 1) + (sgn(goal_col - col) + 1)} -- the first action in
 // ACTIONS order that is not blocked and moves one step closer to a goal lying in that direction, else STAY.
-__device__ __forceinline__ uint32_t greedy_action(const uint2 *cells, uint32_t cell, uint32_t goal_rc) {
-    const uint2 pc = cells[cell];
+__device__ __forceinline__ uint32_t greedy_action(const uint2 *cells, uint32_t n_cells, uint32_t cell, uint32_t goal_rc) {
+    const uint2 pc = cells[min(cell, n_cells - 1u)];   // (a corrupted state must not turn into a wild read)
     const int r = int(pc.x & 0xFFFFu), c = int(pc.x >> 16), gr = int(goal_rc & 0xFFFFu), gc = int(goal_rc >> 16);
     const int k = 3 * ((gr > r) - (gr < r) + 1) + ((gc > c) - (gc < c) + 1);
     return (pc.y >> (3 * k)) & 7u;

@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(256) rollout_kernel(const RolloutArgs p) {
             for (int i = 0; i < A; ++i) act[i] = ar.v[i];
         } else if (p.policy_cells) {
 #pragma unroll
-            for (int i = 0; i < A; ++i) act[i] = greedy_action(p.policy_cells, cur[i], p.policy_cells[goal[i]].x);
+            for (int i = 0; i < A; ++i) act[i] = greedy_action(p.policy_cells, p.c.n_cells, cur[i], p.policy_cells[goal[i]].x);
         } else {
             policy_actions<A>(p.c, env_id, t, act);
         }

@@ -184,8 +184,8 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
                 raw = load_actions_raw<FULL>(act_lane, 0u, 0u, 0u, x.v0, x.v1);
             }
         } else if (p.policy_cells) {   // greedy policy (ghost slots read cell 0: their actions are never used)
-            act0 = greedy_action(p.policy_cells, cur0, goal_rc0);
-            act1 = greedy_action(p.policy_cells, cur1, goal_rc1);
+            act0 = greedy_action(p.policy_cells, p.c.n_cells, cur0, goal_rc0);
+            act1 = greedy_action(p.policy_cells, p.c.n_cells, cur1, goal_rc1);
         } else {   // policy stream: one Philox call covers agents 4q..4q+3; this lane needs words 2(g&1), 2(g&1)+1
             uint32_t w[4];
             const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | ((x.g >> 1) << 24);

@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         } else if (p.policy_cells) {   // greedy policy
             const uint32_t at_cell[4] = {ca & 0xFFFFu, ca >> 16, cb & 0xFFFFu, cb >> 16};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) act[k] = greedy_action(p.policy_cells, at_cell[k], goal_rc[k]);
+            for (int k = 0; k < 4; ++k) act[k] = greedy_action(p.policy_cells, p.c.n_cells, at_cell[k], goal_rc[k]);
         } else {   // policy stream: one Philox call covers exactly my agents 4g .. 4g+3
             uint32_t w[4];
             const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | (x.g << 24);
