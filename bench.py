@@ -13,7 +13,8 @@ A "step" is one MapfEnv.step() of every env of the rank: every output (next cell
 collision, prob) is written to HBM.  The headline leg fuses T = 256 steps per mapf_rollout launch
 (state stays in registers between steps); K steps = ceil(K/T) launches enqueued back to back on the
 env's HIP stream between barrier + synchronize on both sides; rank 0 prints ONE JSON line.  Keys:
-  roofline      dominant kernel (lq_rollout_kernel<2,...>) -- algorithmic bytes / HIP-event time per launch
+  roofline      dominant kernel (lq_rollout_kernel<2,...>) -- algorithmic bytes / HIP-event time per launch; `traffic` =
+                HBM bytes per launch from the committed PMC passes, `traffic_gbs` = that figure / the same time
   single_step_launches   the same steps as one mapf_step launch each (launch-latency bound at this size)
   cpu_baseline  the pure-Python restatement of the reference (oracle/, kind "port") timed on
                 this box's host cores on a bounded sample (rank 0, N=1 only)
@@ -294,6 +295,7 @@ def main():
                            "traffic": measured_traffic("lg_step_kernel") if E == 65536 else None,
                            "bytes_per_launch": launch_bytes, "ms_per_launch_hip_events": step_ms}}
 
+    ro_traffic = measured_traffic("rollout_kernel", T) if E == 65536 else None   # PMC bytes per launch (profiles/)
     if rank == 0:
         line = {
             "metric": "agent-steps/sec (batched MapfEnv.step)", "value": value, "unit": "agent-steps/s",
@@ -307,7 +309,8 @@ def main():
                        "parallelism": "env-sharded x%d" % world},
             "roofline": {"bound": "hbm", "achieved": ro_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ro_achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic("rollout_kernel", T) if E == 65536 else None,
+                         "traffic": ro_traffic,
+                         "traffic_gbs": (ro_traffic / (ro_launch_ms * 1e-3) / 1e9) if ro_traffic else None,
                          "kernel": "mapf::lq_rollout_kernel<2,true,true> (quad-lane layout: 4 agents per lane)", "bytes_per_launch": ro_bytes,
                          "ms_per_launch_hip_events": ro_launch_ms},
             "single_step_launches": single,
