@@ -135,12 +135,14 @@ __device__ __forceinline__ void slip_move(const SlipRow *lds_slip, const MoveEnt
 __device__ __forceinline__ void slip_move_hi(const SlipRow *lds_slip, const MoveEntry &entry, uint32_t hi, uint32_t &next,
                                              double &q, uint32_t &tie_dist) {
     // the thresholds travel with the move-table row: no LDS access until the sampled probability is fetched
-    const uint32_t t0 = entry.z & 0xFFFFu, t1 = entry.z >> 16, t2 = entry.w & 0xFFFFu;
-    // one subtraction per threshold serves both questions: negative <=> hi < t, zero <=> a tie
-    const uint32_t d0 = hi - t0, d1 = hi - t1, d2 = hi - t2;
-    const bool b0 = int32_t(d0) < 0, b1 = int32_t(d1) < 0, b2 = int32_t(d2) < 0;
+    // One subtraction per threshold serves both questions: negative <=> hi < t, zero <=> a tie.  A list's last
+    // cumulative sum is 1 up to rounding (or more for an out-of-range fail_prob), so the top 16 bits of its threshold
+    // are always 65535 -- as are the entries past the list end -- and `hi < 65535` only fails in a tie: away from
+    // ties the slot is how many of the first two thresholds hi has passed.
+    const uint32_t t0 = entry.z & 0xFFFFu, t1 = entry.z >> 16;
+    const uint32_t d0 = hi - t0, d1 = hi - t1, d2 = hi - 0xFFFFu;
     tie_dist = min(d0, min(d1, d2));   // 0 <=> hi ties with a threshold (integer, no wave-mask booleans)
-    const uint32_t idx = b0 ? 0u : (b1 ? 1u : (b2 ? 2u : 0u));
+    const uint32_t idx = 2u - (d0 >> 31) - (d1 >> 31);
     next = entry_cell(entry, idx);
     q = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lds_slip) + entry_row_offset(entry) + idx * 8u);
 }
@@ -150,11 +152,10 @@ __device__ __forceinline__ void slip_move_hi(const SlipRow *lds_slip, const Move
 // order; adding 0.0 is exact).  Used where the row would be one more dependent memory round trip (single steps).
 __device__ __forceinline__ void slip_move_hi_members(const EnvConsts &c, const MoveEntry &entry, uint32_t hi, uint32_t &next,
                                                      double &q, uint32_t &tie_dist) {
-    const uint32_t t0 = entry.z & 0xFFFFu, t1 = entry.z >> 16, t2 = entry.w & 0xFFFFu;
-    const uint32_t d0 = hi - t0, d1 = hi - t1, d2 = hi - t2;
-    const bool b0 = int32_t(d0) < 0, b1 = int32_t(d1) < 0, b2 = int32_t(d2) < 0;
+    const uint32_t t0 = entry.z & 0xFFFFu, t1 = entry.z >> 16;
+    const uint32_t d0 = hi - t0, d1 = hi - t1, d2 = hi - 0xFFFFu;   // see slip_move_hi
     tie_dist = min(d0, min(d1, d2));
-    const uint32_t idx = b0 ? 0u : (b1 ? 1u : (b2 ? 2u : 0u));
+    const uint32_t idx = 2u - (d0 >> 31) - (d1 >> 31);
     next = entry_cell(entry, idx);
     const uint32_t mem = (entry.w >> (16u + 3u * idx)) & 7u;
     q = __dadd_rn(__dadd_rn((mem & 1u) ? c.p_cand[0] : 0.0, (mem & 2u) ? c.p_cand[1] : 0.0), (mem & 4u) ? c.p_cand[2] : 0.0);

@@ -13,8 +13,8 @@ namespace mapf {
 //   x = c0 | c1 << 16, y = c2 | code << 16 | (code * sizeof(SlipRow)) << 19 : the merged movement list's cells in
 //       list order + the equality code of the three candidates (selects the SlipRow with the list's probabilities /
 //       full-width thresholds; also pre-scaled to that row's byte offset);
-//   z = t0 | t1 << 16, w = t2 | members << 16 : (members: SlipRow::members of the entry's code) top 16 bits of the cumulative thresholds, saturated to 65535 (0 past the
-//       end of the list).  hi16 < t_k decides `cum[k] > u` unless hi16 == t_k; that tie (which the saturation makes
+//   z = t0 | t1 << 16, w = t2 | members << 16 : (t2 is always 65535 and no longer read on the fast path) (members: SlipRow::members of the entry's code) top 16 bits of the cumulative thresholds, saturated to 65535 (65535 past the
+//       end of the list too).  hi16 < t_k decides `cum[k] > u` unless hi16 == t_k; that tie (which the saturation makes
 //       slightly more frequent: hi16 = 65535 against a threshold of 1.0) is resolved by the exact 53-bit path.
 using MoveEntry = uint4;
 

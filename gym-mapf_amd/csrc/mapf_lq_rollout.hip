@@ -33,11 +33,11 @@ using gu32x2 = __attribute__((address_space(1))) u32x2 *;
 // the tie distance (0 <=> hi equals a threshold -> exact path)
 __device__ __forceinline__ uint32_t sample_slot(const SlipRow *lds_slip, const MoveEntry &entry, uint32_t hi, double &q,
                                                 uint32_t &tie_dist) {
-    const uint32_t t0 = entry.z & 0xFFFFu, t1 = entry.z >> 16, t2 = entry.w & 0xFFFFu;
-    const uint32_t d0 = hi - t0, d1 = hi - t1, d2 = hi - t2;
-    const bool b0 = int32_t(d0) < 0, b1 = int32_t(d1) < 0, b2 = int32_t(d2) < 0;
+    // (slot = how many of the first two thresholds hi has passed: see slip_move_hi in mapf_device.hpp)
+    const uint32_t t0 = entry.z & 0xFFFFu, t1 = entry.z >> 16;
+    const uint32_t d0 = hi - t0, d1 = hi - t1, d2 = hi - 0xFFFFu;
     tie_dist = min(d0, min(d1, d2));
-    const uint32_t idx = b0 ? 0u : (b1 ? 1u : (b2 ? 2u : 0u));
+    const uint32_t idx = 2u - (d0 >> 31) - (d1 >> 31);
     q = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lds_slip) + entry_row_offset(entry) + idx * 8u);
     return idx;
 }
