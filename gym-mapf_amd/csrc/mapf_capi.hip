@@ -318,8 +318,8 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
             for (int k = 0; k < 3; ++k)
                 t16[k] = (k >= int(slip_host[code].n) || slip_host[code].th[k] > 65535u) ? 65535u : slip_host[code].th[k];
             packed[size_t(v) * 5 + a] = make_uint4(uint32_t(cells[0]) | (uint32_t(cells[1]) << 16),
-                                                    uint32_t(cells[2]) | (uint32_t(code) << 16) | (uint32_t(code * sizeof(mapf::SlipRow)) << 19),
-                                                    t16[0] | (t16[1] << 16), t16[2] | (slip_host[code].members << 16));
+                                                    uint32_t(cells[2]) | (uint32_t(code) << 16) | (slip_host[code].members << 19),
+                                                    t16[0] | (t16[1] << 16), uint32_t(code * sizeof(mapf::SlipRow)));
         }
     }
     const size_t row = size_t(A) * sizeof(uint16_t);

@@ -108,7 +108,7 @@ __device__ __forceinline__ uint32_t entry_cell(const MoveEntry &entry, uint32_t 
 }
 __device__ __forceinline__ uint32_t entry_code(const MoveEntry &entry) { return (entry.y >> 16) & 7u; }
 // byte offset of that code's SlipRow (code * sizeof(SlipRow), packed beside the code by the host)
-__device__ __forceinline__ uint32_t entry_row_offset(const MoveEntry &entry) { return entry.y >> 19; }
+__device__ __forceinline__ uint32_t entry_row_offset(const MoveEntry &entry) { return entry.w; }
 static_assert(offsetof(SlipRow, q) == 0, "entry_row_offset() addresses q[] directly");
 
 template <bool EXT_UNIFORMS>
@@ -147,7 +147,7 @@ __device__ __forceinline__ void slip_move_hi(const SlipRow *lds_slip, const Move
     q = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lds_slip) + entry_row_offset(entry) + idx * 8u);
 }
 
-// The same, with the probability rebuilt from the slot's members (bits 16.. of entry.w) instead of read from the
+// The same, with the probability rebuilt from the slot's members (bits 19.. of entry.y) instead of read from the
 // row: ((m ? p_m : 0) + (r ? p_r : 0)) + (l ? p_l : 0) in the order the host merged them (old + new, first-seen
 // order; adding 0.0 is exact).  Used where the row would be one more dependent memory round trip (single steps).
 __device__ __forceinline__ void slip_move_hi_members(const EnvConsts &c, const MoveEntry &entry, uint32_t hi, uint32_t &next,
@@ -157,7 +157,7 @@ __device__ __forceinline__ void slip_move_hi_members(const EnvConsts &c, const M
     tie_dist = min(d0, min(d1, d2));
     const uint32_t idx = 2u - (d0 >> 31) - (d1 >> 31);
     next = entry_cell(entry, idx);
-    const uint32_t mem = (entry.w >> (16u + 3u * idx)) & 7u;
+    const uint32_t mem = (entry.y >> (19u + 3u * idx)) & 7u;
     q = __dadd_rn(__dadd_rn((mem & 1u) ? c.p_cand[0] : 0.0, (mem & 2u) ? c.p_cand[1] : 0.0), (mem & 4u) ? c.p_cand[2] : 0.0);
 }
 

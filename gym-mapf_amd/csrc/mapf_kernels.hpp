@@ -10,12 +10,14 @@ namespace mapf {
 // Built on the host by replaying single_agent_movements (mapf_env.py:163-184): drop p <= 0, merge equal
 // cells in first-seen order with old + new, then cumsum left to right.
 // Move table row of one (cell, action): everything the fast sampling path needs in ONE 16-byte read.
-//   x = c0 | c1 << 16, y = c2 | code << 16 | (code * sizeof(SlipRow)) << 19 : the merged movement list's cells in
-//       list order + the equality code of the three candidates (selects the SlipRow with the list's probabilities /
-//       full-width thresholds; also pre-scaled to that row's byte offset);
-//   z = t0 | t1 << 16, w = t2 | members << 16 : (t2 is always 65535 and no longer read on the fast path) (members: SlipRow::members of the entry's code) top 16 bits of the cumulative thresholds, saturated to 65535 (65535 past the
-//       end of the list too).  hi16 < t_k decides `cum[k] > u` unless hi16 == t_k; that tie (which the saturation makes
-//       slightly more frequent: hi16 = 65535 against a threshold of 1.0) is resolved by the exact 53-bit path.
+//   x = c0 | c1 << 16, y = c2 | code << 16 | members << 19 : the merged movement list's cells in list order, the
+//       equality code of the three candidates (selects the SlipRow with the list's probabilities / full-width
+//       thresholds) and SlipRow::members of that code (which candidates merged into each slot);
+//   z = t0 | t1 << 16 : top 16 bits of the first two cumulative thresholds, saturated to 65535 (65535 past the end of
+//       the list too).  The last threshold of a list is always 65535 (its cumulative sum is 1 up to rounding), so
+//       away from ties the sampled slot is the number of passed thresholds among these two; hi16 equal to t0, t1 or
+//       65535 is a tie and is resolved by the exact 53-bit path;
+//   w = code * sizeof(SlipRow) : byte offset of the code's row (the sampled probability is q[slot] at its start).
 using MoveEntry = uint4;
 
 struct SlipRow {
