@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         // --- outcome: the row (status for both criteria, reward for Makespan) is only REQUESTED here; everything the
         // next step's table address depends on is re-derived from f without waiting for it
         const bool was_terminal = terminal != 0u;
-        const OutcomeRow *row = &outcome[f | (was_terminal ? 8u : 0u)];
+        const OutcomeRow *row = &outcome[f | (terminal << 3)];   // terminal is 0 / 1
         const uint32_t row_status = row->status;
         const double row_reward = row->reward;                 // two plain reads, both unconditional
         double soc_reward = 0.0;
