@@ -203,9 +203,17 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
     asm volatile("" : "+v"(wide_lane), "+v"(prob_lane), "+v"(narrow_lane), "+v"(coll_lane), "+v"(rec_lane));
     const uint8_t *act_lane = STREAM ? p.actions + lane_cell : nullptr;
 
-    uint32_t raw = 0u;
-    if (STREAM && p.n_steps > 0) raw = *reinterpret_cast<const uint32_t *>(act_lane);
-    asm volatile("" : "+v"(raw));     // consume the first word here: the loop's wait is the back edge's counted one
+    // Action words are fetched TWO steps ahead (one step is shorter than a loaded HBM round trip): two registers take
+    // turns -- even steps use raw_even, odd steps raw_odd, each reloading its own register for two steps later --
+    // so the loop is unrolled by two (rotating one register through a move would be a use, i.e. a wait).
+    const uint32_t last_row = p.n_steps ? p.n_steps - 1u : 0u;
+    uint32_t raw_even = 0u, raw_odd = 0u;
+    if (STREAM && p.n_steps > 0) {
+        raw_even = *reinterpret_cast<const uint32_t *>(act_lane);
+        act_lane += last_row >= 1u ? step_cells : 0u;             // clamped, not guarded: late rows are re-read
+        raw_odd = *reinterpret_cast<const uint32_t *>(act_lane);
+    }
+    asm volatile("" : "+v"(raw_even), "+v"(raw_odd));   // consumed here: the loop's waits are the back edge's counted ones
     Words4 rng_a{0u, 0u, 0u, 0u}, rng_b{0u, 0u, 0u, 0u};
     // "Pending" = what is left of step s-1 when step s begins: its probability chain, its totals and its trajectory
     // stores.  They are finished at the top of step s, right after step s's table reads have been issued, so the
@@ -246,13 +254,13 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         for (int k = 0; k < 4; ++k) goal_rc[k] = p.policy_cells[goal_cell[k]].x;
     }
 
-    for (uint32_t s = 0; s < p.n_steps; ++s) {
+    auto one_step = [&](const uint32_t s, uint32_t &raw) __attribute__((always_inline)) {
         const uint64_t t = p.t + s;
         uint32_t act[4];
         if (STREAM) {
             act[0] = raw & 0xFFu; act[1] = (raw >> 8) & 0xFFu; act[2] = (raw >> 16) & 0xFFu; act[3] = raw >> 24;
             asm volatile("" : "+v"(act[0]), "+v"(act[1]), "+v"(act[2]), "+v"(act[3]));   // the wait for `raw` sits here
-            act_lane += (s + 1u < p.n_steps) ? step_cells : 0u;   // clamped, not guarded: the last step re-reads its row
+            act_lane += (s + 2u <= last_row) ? step_cells : 0u;   // row min(s + 2, last)
             raw = *reinterpret_cast<const uint32_t *>(act_lane);
         } else if (p.policy_cells) {   // greedy policy
             const uint32_t at_cell[4] = {ca & 0xFFFFu, ca >> 16, cb & 0xFFFFu, cb >> 16};
@@ -354,7 +362,13 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         cb = back ? sb : nb;
         terminal = back ? start_terminal : (next_terminal ? 1u : 0u);
         STAMP(7);   // reset handling
+    };
+    uint32_t s = 0;
+    for (; s + 1u < p.n_steps; s += 2u) {
+        one_step(s, raw_even);
+        one_step(s + 1u, raw_odd);
     }
+    if (s < p.n_steps) one_step(s, raw_even);
     if (p.n_steps > 0) finish_pending();                       // the last step's chain, totals and stores
 #ifdef MAPF_STAMPS
     if (x.lane == 0u && epi_p) {   // diagnostic build: segment sums replace the episode counts
