@@ -1,28 +1,43 @@
 #!/usr/bin/env python3
 """bench.py -- agent-steps/s of the batched MapfEnv.step() hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3|c4|c5|c2]
 
-Workload (BASELINE.json configs[2], SURVEY.md 8(d) "C3"): room-32-32-4, 8 agents, slip 0.2,
-65536 envs PER GPU (weak scaling; env e uses scen id {6,12,13,23,24,25}[e mod 6], global env
-ids so results do not depend on the rank count), synthetic uniform-random actions resident in
-HBM before the timed region, every done env auto-reset as the reference's caller loop does.
+N > 1 without a launcher: this process starts N children itself (one rank per GPU, RCCL), before it touches
+any GPU; under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is one of the ranks.
 
-A "step" is one MapfEnv.step() of every env of the rank: every output (next cells, reward, done,
-collision, prob) is written to HBM.  The headline leg fuses T = 256 steps per mapf_rollout launch
-(state stays in registers between steps); K steps = ceil(K/T) launches enqueued back to back on the
-env's HIP stream between barrier + synchronize on both sides; rank 0 prints ONE JSON line.  Keys:
-  roofline      dominant kernel (lq_rollout_kernel<2,...>) -- algorithmic bytes / HIP-event time per launch; `traffic` =
-                HBM bytes per launch from the committed PMC passes, `traffic_gbs` = that figure / the same time
-  single_step_launches   the same steps as one mapf_step launch each (launch-latency bound at this size)
-  cpu_baseline  the pure-Python restatement of the reference (oracle/, kind "port") timed on
-                this box's host cores on a bounded sample (rank 0, N=1 only)
+Workloads (BASELINE.json configs):
+  c3 (default)  configs[2]: room-32-32-4, 8 agents, slip 0.2, 65536 envs PER GPU (weak scaling; env e uses scen id
+                {6,12,13,23,24,25}[e mod 6])
+  c4            configs[3]: the same map, 262144 envs IN TOTAL split evenly over the N GPUs (strong scaling)
+  c5            configs[4]: synthetic random-64-64-20 map (the MovingAI file is not shipped: 64x64, cells blocked
+                with p = 0.2 from RandomState(20)), 32 agents, slip 0.2, 131072 envs in total over the N GPUs,
+                per-env seeded random distinct start / goal cells
+  c2            configs[1]: empty-16-16, 4 agents, slip 0.1, 4096 envs per GPU (env e uses scen id 1 + e mod 25)
+Global env ids feed the RNG counters, so results do not depend on the rank count.  Actions are synthetic
+(uniform-random policy stream), resident in HBM before the timed region; every done env is auto-reset as the
+reference's caller loop does.
+
+A CLI "step" is ONE PASS of the hot path over the rank's batch as the library runs it at speed: one mapf_rollout
+launch = T = 256 fused MapfEnv.step() calls of every env (`config.env_steps_per_step`), each of which writes all
+its outputs (next cells, reward, done, collision, prob) to HBM.  K steps = K launches back to back on the env's
+HIP stream between barrier + synchronize on both sides; `value` = all ranks' agent-steps / max-over-ranks wall
+time of that region.  Rank 0 prints ONE JSON line.  Keys beyond the contract:
+  roofline      dominant kernel (the fused rollout; `kernel` = what the library reports it dispatched): algorithmic
+                bytes / HIP-event time per launch; `traffic` = HBM bytes per launch from the committed PMC passes
+                (profiles/traffic.json: per-step + fixed part), `traffic_frac` = that / the same time / peak
+  single_step_launches   the same env-steps as one mapf_step launch each (launch-latency bound at this size)
+  scalar_env    the reference's own regime (configs[0]: empty-8-8, 2 agents, slip 0, ONE env): MapfEnv.step()
+                calls per second through the drop-in class, beside the reference's build-container figure
+  cpu_baseline  the pure-Python restatement of the reference (oracle/, kind "port") timed on this box's host
+                cores on a bounded sample (rank 0, N=1 only), the real reference's build-container rate beside it
   parity        bit-exact check of the first steps of this very run against the C oracle
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,11 +46,20 @@ sys.path.insert(0, os.path.join(ROOT, 'gym-mapf_amd'))
 
 import numpy as np  # noqa: E402
 
-MAP, N_AGENTS, FAIL_PROB = 'room-32-32-4', 8, 0.2
-SCEN_IDS = (6, 12, 13, 23, 24, 25)
 R_CLASH, R_GOAL, R_LIVING = -1000.0, 100.0, -1.0
 SEED = 42
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
+
+CONFIGS = {
+    'c2': dict(baseline='configs[1]', map='empty-16-16', scen_ids=tuple(range(1, 26)), agents=4, fail_prob=0.1,
+               envs=4096, scaling='weak'),
+    'c3': dict(baseline='configs[2]', map='room-32-32-4', scen_ids=(6, 12, 13, 23, 24, 25), agents=8, fail_prob=0.2,
+               envs=65536, scaling='weak'),
+    'c4': dict(baseline='configs[3]', map='room-32-32-4', scen_ids=(6, 12, 13, 23, 24, 25), agents=8, fail_prob=0.2,
+               envs=262144, scaling='strong'),
+    'c5': dict(baseline='configs[4]', map='random-64-64-20 (synthetic stand-in)', scen_ids=None, agents=32,
+               fail_prob=0.2, envs=131072, scaling='strong'),
+}
 
 
 def bytes_per_agent_step(A):
@@ -44,37 +68,86 @@ def bytes_per_agent_step(A):
     return 5.0 + 18.0 / A
 
 
-def measured_traffic(kernel, steps_per_launch=None):
-    """HBM bytes per launch of `kernel`, from the committed rocprofv3 PMC passes of this same command
+def measured_traffic(kernel, n_envs, n_agents, steps_per_launch):
+    """HBM bytes per launch of `kernel` at this batch, from the committed rocprofv3 PMC passes of this same command
     (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950).  None when no profile is present."""
+    MI355X_MICROARCH.md prescribes for gfx950; two launch lengths give a per-step and a fixed part).  None when no
+    profile of this kernel instance at this batch is committed."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-            entry = json.load(f)['kernels'][kernel]
-        if steps_per_launch is not None and entry.get('steps_per_launch') != steps_per_launch:
-            return None
-        return entry['hbm_bytes_per_launch']
+            entries = json.load(f)['kernels']
     except (OSError, KeyError, ValueError):
         return None
+    for entry in entries:
+        if entry.get('kernel') == kernel and entry.get('n_envs') == n_envs and entry.get('n_agents') == n_agents:
+            return entry['fixed_bytes'] + entry['bytes_per_env_step_launch'] * steps_per_launch
+    return None
 
 
-def workload_tables(n_envs, env_id_offset):
+def synthetic_random_map(size=64, p_obst=0.2, seed=20):
+    """the stand-in for the unshipped random-64-64-20 file."""
+    obst = np.random.RandomState(seed).rand(size, size) < p_obst
+    return [''.join('@' if obst[r, c] else '.' for c in range(size)) for r in range(size)]
+
+
+def random_distinct_cells(n_cells, n_agents, env_ids, salt):
+    """[len(env_ids), A] distinct free cells per env, a function of the GLOBAL env id only (chunks of 4096 ids share
+    one RandomState seeded by (SEED, salt, chunk); rows with a repeated cell are redrawn until none is left)."""
+    env_ids = np.asarray(env_ids, dtype=np.int64)
+    out = np.empty((len(env_ids), n_agents), np.uint16)
+    chunk = 4096
+    for c in np.unique(env_ids // chunk):
+        rs = np.random.RandomState([SEED, salt, int(c)])
+        cells = rs.randint(0, n_cells, size=(chunk, n_agents))
+        while True:
+            srt = np.sort(cells, axis=1)
+            bad = np.nonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1))[0]
+            if bad.size == 0:
+                break
+            cells[bad] = rs.randint(0, n_cells, size=(bad.size, n_agents))
+        sel = np.nonzero(env_ids // chunk == c)[0]
+        out[sel] = cells[env_ids[sel] % chunk]
+    return out
+
+
+def workload_tables(cfg, n_envs, env_id_offset):
+    """(grid, map lines, nbr, start u16[E, A], goal u16[E, A]) of this rank's slice of the configuration."""
     from gym_mapf_amd.envs import map_name_to_files
     from gym_mapf_amd.envs.grid import MapfGrid
     from gym_mapf_amd.envs.utils import parse_map_file, parse_scen_file
-    grid = MapfGrid(parse_map_file(map_name_to_files(MAP, SCEN_IDS[0])[0]))
+    A = cfg['agents']
+    ids = env_id_offset + np.arange(n_envs)
+    if cfg['scen_ids'] is None:
+        lines = synthetic_random_map()
+        grid = MapfGrid(lines)
+        V = len(grid.tables()[0])
+        start = random_distinct_cells(V, A, ids, 1)
+        goal = random_distinct_cells(V, A, ids, 2)
+        return grid, lines, grid.tables()[2], start, goal
+    lines = parse_map_file(map_name_to_files(cfg['map'], cfg['scen_ids'][0])[0])
+    grid = MapfGrid(lines)
     _, loc_to_int, nbr = grid.tables()
     per_scen = []
-    for sid in SCEN_IDS:
-        s, g = parse_scen_file(map_name_to_files(MAP, sid)[1], N_AGENTS)
+    for sid in cfg['scen_ids']:
+        s, g = parse_scen_file(map_name_to_files(cfg['map'], sid)[1], A)
         per_scen.append(([loc_to_int[l] for l in s], [loc_to_int[l] for l in g]))
-    which = (env_id_offset + np.arange(n_envs)) % len(SCEN_IDS)
+    which = ids % len(cfg['scen_ids'])
     start = np.asarray([p[0] for p in per_scen], np.uint16)[which]
     goal = np.asarray([p[1] for p in per_scen], np.uint16)[which]
-    return grid, nbr, np.ascontiguousarray(start), np.ascontiguousarray(goal)
+    return grid, lines, nbr, np.ascontiguousarray(start), np.ascontiguousarray(goal)
 
 
-def cpu_baseline(budget_s=12.0):
+def reference_cpu_figures():
+    """The REAL reference timed in the build container (tools/time_reference.py -> profiles/reference_cpu.json; the
+    reference may not travel to the GPU box, so this is a committed measurement, not re-run here)."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'reference_cpu.json')) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(cfg, budget_s=12.0):
     """Time the CPU restatements of the reference on this box (bounded sample of the same workload).
 
     value = the pure-Python scalar port (oracle/mapf_oracle.py OracleEnv: one env object, Python
@@ -83,14 +156,14 @@ def cpu_baseline(budget_s=12.0):
     import c_oracle
     import mapf_oracle as mo
     import philox
-    from gym_mapf_amd.envs import map_name_to_files
-    from gym_mapf_amd.envs.utils import parse_map_file, parse_scen_file
-    lines = parse_map_file(map_name_to_files(MAP, SCEN_IDS[0])[0])
-    starts, goals = parse_scen_file(map_name_to_files(MAP, SCEN_IDS[0])[1], N_AGENTS)
-    env = mo.OracleEnv(lines, N_AGENTS, starts, goals, FAIL_PROB, R_CLASH, R_GOAL, R_LIVING, mo.MAKESPAN)
+    A = cfg['agents']
+    grid, lines, nbr, start, goal = workload_tables(cfg, 16384, 0)
+    valid = grid.tables()[0]
+    env = mo.OracleEnv(lines, A, [valid[c] for c in start[0]], [valid[c] for c in goal[0]], cfg['fail_prob'],
+                       R_CLASH, R_GOAL, R_LIVING, mo.MAKESPAN)
     chunk = 2000
-    acts = [philox.random_actions_np(SEED, [0], t, N_AGENTS)[0].tolist() for t in range(chunk)]
-    us = [philox.slip_uniforms_np(SEED, [0], t, N_AGENTS)[0].tolist() for t in range(chunk)]
+    acts = [philox.random_actions_np(SEED, [0], t, A)[0].tolist() for t in range(chunk)]
+    us = [philox.slip_uniforms_np(SEED, [0], t, A)[0].tolist() for t in range(chunk)]
     n, t0 = 0, time.perf_counter()
     while time.perf_counter() - t0 < budget_s:
         for a, u in zip(acts, us):
@@ -98,47 +171,110 @@ def cpu_baseline(budget_s=12.0):
             if done:
                 env.reset()
         n += chunk
-    py_rate = n * N_AGENTS / (time.perf_counter() - t0)
+    py_rate = n * A / (time.perf_counter() - t0)
 
     E = 16384
-    _, nbr, start, goal = workload_tables(E, 0)
-    co = c_oracle.COracle(nbr, N_AGENTS, start, goal, FAIL_PROB, R_CLASH, R_GOAL, R_LIVING, mo.MAKESPAN, seed=SEED)
+    co = c_oracle.COracle(nbr, A, start, goal, cfg['fail_prob'], R_CLASH, R_GOAL, R_LIVING, mo.MAKESPAN, seed=SEED)
     co.rollout(4)
     t0 = time.perf_counter()
     steps = 0
     while time.perf_counter() - t0 < 3.0:
         co.rollout(16)
         steps += 16
-    c_rate = steps * E * N_AGENTS / (time.perf_counter() - t0)
-    return {"value": py_rate, "unit": "agent-steps/s", "cores": 1, "kind": "port",
-            "sample": "oracle/mapf_oracle.py OracleEnv (pure-Python restatement of MapfEnv.step), room-32-32-4 scen 6, "
-                      "8 agents, slip 0.2, one env, %d env-steps with reset on done, 1 core of %d" % (n, os.cpu_count()),
-            "c_port_value": c_rate,
-            "c_port_sample": "oracle/mapf_oracle.c scalar C, %d envs x %d steps, 1 core" % (E, steps)}
+    c_rate = steps * E * A / (time.perf_counter() - t0)
+    out = {"value": py_rate, "unit": "agent-steps/s", "cores": 1, "kind": "port",
+           "sample": "oracle/mapf_oracle.py OracleEnv (pure-Python restatement of MapfEnv.step), %s, env 0's scenario, "
+                     "%d agents, slip %g, one env, %d env-steps with reset on done, 1 core of %d"
+                     % (cfg['map'], A, cfg['fail_prob'], n, os.cpu_count()),
+           "c_port_value": c_rate,
+           "c_port_sample": "oracle/mapf_oracle.c scalar C, %d envs x %d steps, 1 core" % (E, steps)}
+    ref = reference_cpu_figures()
+    if ref:
+        out["reference_build_container"] = ref
+    return out
+
+
+def scalar_env_rate(budget_s=2.0):
+    """BASELINE configs[0]: empty-8-8, 2 agents, slip 0, ONE env, stepped through the drop-in MapfEnv class the way
+    the reference's users do (joint-integer action in, (s, r, done, info) out, reset on done)."""
+    import random
+    from gym_mapf_amd.envs.utils import create_mapf_env
+    from gym_mapf_amd.envs.vec_env import OptimizationCriteria
+    env = create_mapf_env('empty-8-8', 1, 2, 0.0, R_CLASH, R_GOAL, R_LIVING, OptimizationCriteria.Makespan)
+    rng = random.Random(0)
+    acts = [rng.randrange(env.nA) for _ in range(4096)]
+    for a in acts[:64]:
+        if env.step(a)[2]:
+            env.reset()
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        for a in acts[:512]:
+            if env.step(a)[2]:
+                env.reset()
+        n += 512
+    rate = n / (time.perf_counter() - t0)
+    env.close()
+    out = {"value": rate, "unit": "env-steps/s", "config": "BASELINE configs[0]: empty-8-8, 2 agents, slip 0, 1 env, "
+           "MapfEnv.step() through the C ABI (pinned staging, one launch + one sync per call)", "env_steps": n}
+    ref = reference_cpu_figures()
+    if ref and 'c1' in ref:
+        out["reference_build_container_env_steps_per_s"] = ref['c1'].get('env_steps_per_s')
+    return out
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with no launcher: start one child per GPU (before this process makes any GPU
+    call -- it makes none at all), wait for them, and exit with the first failure's code.  Rank 0 prints the line."""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = list(procs)
+    while pending:
+        for p in list(pending):
+            code = p.poll()
+            if code is None:
+                continue
+            pending.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in pending:      # a dead rank would leave the others waiting in a collective
+                    q.terminate()
+        time.sleep(0.05)
+    raise SystemExit(rc)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2048)
-    ap.add_argument('--warmup', type=int, default=128)
-    ap.add_argument('--envs', type=int, default=65536, help='envs per GPU')
-    ap.add_argument('--ring', type=int, default=512, help='distinct pre-generated action steps kept in HBM')
-    ap.add_argument('--rollout-steps', type=int, default=256, help='T of the fused rollout leg')
+    ap.add_argument('--steps', type=int, default=200, help='timed passes (one pass = one fused launch of --rollout-steps env-steps)')
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
+    ap.add_argument('--envs', type=int, default=None, help='override the config: envs per GPU (weak scaling)')
+    ap.add_argument('--rollout-steps', type=int, default=256, help='T: env-steps fused per launch')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-side-legs', action='store_true', help='skip single_step_launches and scalar_env (profiling runs)')
     ap.add_argument('--kernel', default='auto', choices=['auto', 'thread_per_env', 'lane_group'])
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' + --share-device rehearses the N > 1 path on a one-GPU box")
     ap.add_argument('--share-device', action='store_true', help='every rank uses cuda:0 (rehearsal only)')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        spawn_ranks(args.gpus)
+
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d'
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if args.share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -153,14 +289,27 @@ def main():
     coll_dev = 'cuda' if args.dist_backend == 'nccl' else 'cpu'
 
     from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv
-    E, A, K, W = args.envs, N_AGENTS, max(1, args.steps), max(0, args.warmup)
     from gym_mapf_amd import sharding
-    offset = sharding.shard_offset(E, rank)
-    grid, nbr, start, goal = workload_tables(E, offset)
-    env = VecMapfEnv(grid, A, None, None, FAIL_PROB, R_CLASH, R_GOAL, R_LIVING, OptimizationCriteria.Makespan,
+    cfg = CONFIGS[args.config]
+    A, K, W = cfg['agents'], max(1, args.steps), max(0, args.warmup)
+    scaling = cfg['scaling']
+    if args.envs is not None:
+        scaling = 'weak'
+        offset, E = sharding.shard_offset(args.envs, rank), args.envs
+        total_envs = args.envs * world
+    elif scaling == 'weak':
+        offset, E = sharding.shard_offset(cfg['envs'], rank), cfg['envs']
+        total_envs = cfg['envs'] * world
+    else:
+        offset, E = sharding.split_evenly(cfg['envs'], rank, world)
+        total_envs = cfg['envs']
+    grid, _, nbr, start, goal = workload_tables(cfg, E, offset)
+    env = VecMapfEnv(grid, A, None, None, cfg['fail_prob'], R_CLASH, R_GOAL, R_LIVING, OptimizationCriteria.Makespan,
                      seed=SEED, env_id_offset=offset, device=local_rank, device_arrays=True,
                      start_local=start, goal_local=goal, kernel=args.kernel)
-    ring = max(1, min(args.ring, K + W))
+    T = max(1, args.rollout_steps)
+    n_slots = 2
+    ring = n_slots * T
     actions = env.fill_random_actions(0, ring)                      # [ring, E, A] u8, resident in HBM
     env.sync()
 
@@ -176,7 +325,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, 'oracle'))
         import c_oracle
         import mapf_oracle as mo
-        co = c_oracle.COracle(nbr, A, start, goal, FAIL_PROB, R_CLASH, R_GOAL, R_LIVING, mo.MAKESPAN,
+        co = c_oracle.COracle(nbr, A, start, goal, cfg['fail_prob'], R_CLASH, R_GOAL, R_LIVING, mo.MAKESPAN,
                               seed=SEED, env_id_offset=offset)
         n_chk, ok = 6, True
         for t in range(n_chk):
@@ -208,6 +357,7 @@ def main():
                             % (n_chk, n_ro)}
         if not ok:
             raise SystemExit('PARITY FAILURE: HIP path differs from the oracle')
+        del res
         env.reset()
         env.set_state(None, t=0)
 
@@ -217,7 +367,7 @@ def main():
 
     def timed(enqueue, n_warm, n_timed):
         """barrier + sync, n_timed enqueues bracketed by HIP events on the env's stream, barrier + sync;
-        returns (max-over-ranks wall seconds, HIP-event milliseconds)."""
+        returns (max-over-ranks wall seconds, HIP-event milliseconds of this rank)."""
         for k in range(n_warm):
             enqueue(k)
         barrier()
@@ -234,91 +384,103 @@ def main():
             wall = float(tmax.item())
         return wall, gpu_ms
 
-    # ---- headline leg: K steps as fused mapf_rollout launches of T steps each.  Every step's outputs
+    # ---- headline leg: K passes, each ONE fused mapf_rollout launch of T env-steps.  Every env-step's outputs
     # (next cells, reward, done, collision, prob) are written to HBM, actions are streamed from the ring.
-    T = max(1, min(args.rollout_steps, ring, K))
     rec = {'local': env._empty((T, E, A), np.uint16), 'reward': env._empty((T, E), np.float64),
            'prob': env._empty((T, E), np.float64), 'done': env._empty((T, E), np.uint8),
            'collision': env._empty((T, E), np.uint8)}
     acc = {'returns': torch.zeros(E, dtype=torch.float64, device='cuda'),
            'episodes': torch.zeros(E, dtype=torch.int32, device='cuda').view(torch.uint32),
            'collisions': torch.zeros(E, dtype=torch.int32, device='cuda').view(torch.uint32)}
-    n_slots = max(1, ring // T)
 
-    def rollout_io(slot, n_steps):
+    def rollout_io(slot):
         return nat.MapfRolloutIO(
-            struct_size=ctypes.sizeof(nat.MapfRolloutIO), n_steps=n_steps, step_flags=nat.MAPF_STEP_AUTO_RESET,
+            struct_size=ctypes.sizeof(nat.MapfRolloutIO), n_steps=T, step_flags=nat.MAPF_STEP_AUTO_RESET,
             accumulate=1, actions=actions[slot * T].data_ptr(), out_returns=acc['returns'].data_ptr(),
             out_episodes=acc['episodes'].data_ptr(), out_collisions=acc['collisions'].data_ptr(),
             rec_local=rec['local'].data_ptr(), rec_reward=rec['reward'].data_ptr(), rec_done=rec['done'].data_ptr(),
             rec_collision=rec['collision'].data_ptr(), rec_prob=rec['prob'].data_ptr())
 
-    ios = [rollout_io(slot, T) for slot in range(n_slots)]
-    n_full, tail = divmod(K, T)
-    io_tail = rollout_io(n_full % n_slots, tail) if tail else None
-    n_launch = n_full + (1 if tail else 0)
+    ios = [rollout_io(slot) for slot in range(n_slots)]
 
     def enqueue_rollout(k):
-        io = io_tail if (tail and k == W_launch + n_full) else ios[k % n_slots]
-        nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(io)))
+        nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(ios[k % n_slots])))
 
-    W_launch = max(1, W // T)
     env.reset()
-    wall, gpu_ms = timed(enqueue_rollout, W_launch, n_launch)
-    agent_steps = float(K) * E * A * world
+    wall, gpu_ms = timed(enqueue_rollout, W, K)
+    rollout_kernel = env.last_kernel('rollout')
+    agent_steps = float(K) * T * total_envs * A
     value = agent_steps / wall
-    ro_launch_ms = gpu_ms / n_launch
-    ro_bytes = (float(K) / n_launch) * E * A * bpas                 # algorithmic bytes of an average launch
+    ro_launch_ms = gpu_ms / K
+    ro_bytes = float(T) * E * A * bpas                              # algorithmic bytes of one launch of this rank
     ro_achieved = ro_bytes / (ro_launch_ms * 1e-3) / 1e9
     if dist is not None:
         # the one collective of the path: gather per-env episode returns
         env.sync()
+        counts = [sharding.split_evenly(cfg['envs'], r, world)[1] for r in range(world)] if scaling == 'strong' else [E] * world
+        assert len(set(counts)) == 1, 'gather_returns needs equal shards (pad the remainder before gathering)'
         gathered = sharding.gather_returns(acc['returns'] if coll_dev == 'cuda' else acc['returns'].cpu())
         torch.cuda.synchronize()
-        assert gathered.numel() == world * E
+        assert gathered.numel() == total_envs, (gathered.numel(), total_envs)
 
-    # ---- second leg: the same K steps as single-step mapf_step launches (one kernel launch per step)
-    out = None
-    calls = []
-    for r in range(ring):
-        call, out = env.prepare_step(actions[r], auto_reset=True, out=out)
-        calls.append(call)
-    env.reset()
-    K1 = min(K, 4000)
-    wall1, gpu_ms1 = timed(lambda k: calls[k % ring](), min(W, 200), K1)
-    step_ms = gpu_ms1 / K1
-    launch_bytes = E * A * bpas
-    single = {"value": float(K1) * E * A * world / wall1, "unit": "agent-steps/s", "steps": K1,
-              "ms_per_step": wall1 * 1e3 / K1, "kernel": "mapf::lg_step_kernel<4,true,false>",
-              "roofline": {"bound": "hbm", "achieved": launch_bytes / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
-                           "unit": "GB/s", "frac": launch_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "traffic": measured_traffic("lg_step_kernel") if E == 65536 else None,
-                           "bytes_per_launch": launch_bytes, "ms_per_launch_hip_events": step_ms}}
+    # ---- second leg: env-steps as single-step mapf_step launches (one kernel launch per env-step)
+    single = None
+    if not args.no_side_legs:
+        out = None
+        calls = []
+        for r in range(ring):
+            call, out = env.prepare_step(actions[r], auto_reset=True, out=out)
+            calls.append(call)
+        env.reset()
+        K1 = 2000
+        wall1, gpu_ms1 = timed(lambda k: calls[k % ring](), 200, K1)
+        step_kernel = env.last_kernel('step')
+        step_ms = gpu_ms1 / K1
+        launch_bytes = E * A * bpas
+        st_traffic = measured_traffic(step_kernel, E, A, 1)
+        single = {"value": float(K1) * total_envs * A / wall1, "unit": "agent-steps/s", "launches": K1,
+                  "ms_per_launch": wall1 * 1e3 / K1, "kernel": step_kernel,
+                  "roofline": {"bound": "hbm", "achieved": launch_bytes / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+                               "unit": "GB/s", "frac": launch_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                               "traffic": st_traffic,
+                               "traffic_frac": (st_traffic / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if st_traffic else None,
+                               "bytes_per_launch": launch_bytes, "ms_per_launch_hip_events": step_ms}}
 
-    ro_traffic = measured_traffic("rollout_kernel", T) if E == 65536 else None   # PMC bytes per launch (profiles/)
+    ro_traffic = measured_traffic(rollout_kernel, E, A, T)          # PMC bytes per launch (profiles/)
     if rank == 0:
         line = {
             "metric": "agent-steps/sec (batched MapfEnv.step)", "value": value, "unit": "agent-steps/s",
             "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": wall * 1e3 / K, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u16/f64", "data": "synthetic",
-            "config": {"workload": "room-32-32-4 map, 8 agents, slip=0.2, %d envs per GPU (BASELINE configs[2]), Makespan, "
-                                   "auto-reset; steps fused %d per mapf_rollout launch, every step's next cells / reward / "
-                                   "done / collision / prob written to HBM, actions streamed from HBM" % (E, T),
-                       "envs_per_gpu": E, "n_agents": A, "fail_prob": FAIL_PROB, "seed": SEED,
-                       "steps_per_launch": T, "launches": n_launch, "action_ring_steps": ring,
+            "scaling": scaling, "vs_baseline": None, "dtype": "u16/f64", "data": "synthetic",
+            "config": {"workload": "%s: %s map, %d agents, slip=%g, %d envs %s, Makespan, auto-reset; one step = one fused "
+                                   "mapf_rollout launch of %d MapfEnv.step() calls per env, every env-step's next cells / "
+                                   "reward / done / collision / prob written to HBM, actions streamed from HBM"
+                                   % (cfg['baseline'], cfg['map'], A, cfg['fail_prob'],
+                                      E if scaling == 'weak' else total_envs,
+                                      'per GPU' if scaling == 'weak' else 'in total over %d GPU(s)' % world, T),
+                       "name": args.config, "envs_per_gpu": E, "envs_total": total_envs, "n_agents": A,
+                       "fail_prob": cfg['fail_prob'], "seed": SEED, "env_steps_per_step": T,
+                       "agent_steps_per_step": T * total_envs * A, "action_ring_env_steps": ring,
                        "parallelism": "env-sharded x%d" % world},
+            "value_hip_events": float(T) * total_envs * A / (ro_launch_ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": ro_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ro_achieved / HBM_PEAK_GBS,
                          "traffic": ro_traffic,
-                         "traffic_gbs": (ro_traffic / (ro_launch_ms * 1e-3) / 1e9) if ro_traffic else None,
-                         "kernel": "mapf::lq_rollout_kernel<2,true,true> (quad-lane layout: 4 agents per lane)", "bytes_per_launch": ro_bytes,
-                         "ms_per_launch_hip_events": ro_launch_ms},
-            "single_step_launches": single,
+                         "traffic_frac": (ro_traffic / (ro_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ro_traffic else None,
+                         "kernel": rollout_kernel, "bytes_per_launch": ro_bytes,
+                         "ms_per_launch_hip_events": ro_launch_ms,
+                         "note": "achieved = algorithmic bytes (5 + 18/A per agent-step, SURVEY.md 8(d)) per launch / HIP-event "
+                                 "time per launch; traffic = PMC-measured HBM bytes per launch (the fused kernel keeps state "
+                                 "in registers, so it moves fewer bytes than the per-step contract credits)"},
             "parity": parity,
         }
+        if single is not None:
+            line["single_step_launches"] = single
+        if world == 1 and not args.no_side_legs:
+            line["scalar_env"] = scalar_env_rate()
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(line))
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line), flush=True)
     env.close()
     if dist is not None:
         dist.barrier()

@@ -4,6 +4,7 @@
 #include "mapf_kernels.hpp"
 
 #include <cmath>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -14,6 +15,7 @@
 namespace {
 
 thread_local std::string g_last_error;
+thread_local char g_noted_kernel[160] = "";
 
 int fail(int code, const std::string &msg) {
     g_last_error = msg;
@@ -44,10 +46,40 @@ struct DeviceBuf {
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
 };
 
+// Pinned host block mapped into the device's address space: for tiny host-mode calls (the scalar MapfEnv.step()
+// regime: one env, a handful of agents) the kernel reads its inputs from and writes its outputs to this block
+// directly, so a call is one launch + one stream sync instead of up to nine hipMemcpyAsync round trips.
+struct PinnedBlock {
+    char *host = nullptr, *dev = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        release();
+        hipError_t e = hipHostMalloc(reinterpret_cast<void **>(&host), bytes, hipHostMallocMapped);
+        if (e != hipSuccess) { host = nullptr; return e; }
+        e = hipHostGetDevicePointer(reinterpret_cast<void **>(&dev), host, 0);
+        if (e != hipSuccess) { (void)hipHostFree(host); host = dev = nullptr; return e; }
+        cap = bytes;
+        return hipSuccess;
+    }
+    void release() { if (host) (void)hipHostFree(host); host = dev = nullptr; cap = 0; }
+};
+constexpr size_t kZeroCopyMaxBytes = 16 * 1024;   // beyond this the DMA copies win over PCIe-direct accesses
+
 }  // namespace
+
+namespace mapf {
+void note_kernel(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_noted_kernel, sizeof(g_noted_kernel), fmt, ap);
+    va_end(ap);
+}
+}  // namespace mapf
 
 struct mapf_handle_s {
     int device = 0;
+    std::string last_step_kernel, last_rollout_kernel;
     uint32_t V = 0, A = 0, flags = 0;
     uint64_t E = 0, env_id_offset = 0, t = 0;
     mapf::EnvConsts c{};
@@ -56,6 +88,7 @@ struct mapf_handle_s {
     // The thread-per-env rollout specialisations for A >= 8 need SGPR spills (the pointer-heavy argument block
     // plus A-wide unrolling); only spill-free kernels are dispatched, so those sizes use the lane-group rollout.
     bool lane_group_rollout = false;
+    mapf::RolloutTuning tune;
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     mapf::MoveEntry *mv = nullptr;
@@ -66,7 +99,8 @@ struct mapf_handle_s {
     // host-pointer mode staging
     DeviceBuf s_actions, s_uniforms, s_local, s_reward, s_prob, s_done, s_coll, s_term, s_mask, s_ret, s_epi, s_ncoll;
     DeviceBuf x_local, x_reward, x_prob, x_done, x_coll;   // stand-ins for trajectory arrays the caller left out
-    DeviceBuf q_local, q_actions, q_env, q_count, q_next, q_prob, q_reward, q_done, q_coll;   // mapf_transitions staging
+    DeviceBuf q_local, q_actions, q_env, q_count, q_next, q_prob, q_reward, q_done, q_coll, q_next_in;   // mapf_transitions staging
+    PinnedBlock pinned;               // zero-copy staging of tiny host-mode steps
 };
 
 namespace {
@@ -180,8 +214,9 @@ void destroy_impl(mapf_handle_t h) {
     for (DeviceBuf *b : {&h->s_actions, &h->s_uniforms, &h->s_local, &h->s_reward, &h->s_prob, &h->s_done,
                          &h->s_coll, &h->s_term, &h->s_mask, &h->s_ret, &h->s_epi, &h->s_ncoll, &h->x_local, &h->x_reward,
                          &h->x_prob, &h->x_done, &h->x_coll, &h->q_local, &h->q_actions, &h->q_env, &h->q_count, &h->q_next,
-                         &h->q_prob, &h->q_reward, &h->q_done, &h->q_coll})
+                         &h->q_prob, &h->q_reward, &h->q_done, &h->q_coll, &h->q_next_in})
         b->release();
+    h->pinned.release();
     if (h->mv) (void)hipFree(h->mv);
     if (h->policy_cells) (void)hipFree(h->policy_cells);
     if (h->slip) (void)hipFree(h->slip);
@@ -262,6 +297,7 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
     else if (d->flags & MAPF_FLAG_LANE_GROUP) h->lane_group = true;
     else h->lane_group = A > 2;
     h->lane_group_rollout = h->lane_group || A > uint32_t(mapf::kTpeRolloutMaxAgents);
+    h->tune = mapf::default_rollout_tuning(d->device);
 
     mapf::SlipRow slip_host[8];
     h->c.need_rng = build_slip_table(d->fail_prob, slip_host, h->c.p_cand) ? 1u : 0u;
@@ -352,6 +388,11 @@ int mapf_sync(mapf_handle_t h) {
     return MAPF_OK;
 }
 
+const char *mapf_last_kernel(mapf_handle_t h, int which) {
+    if (!h) return "";
+    return which == MAPF_KERNEL_ROLLOUT ? h->last_rollout_kernel.c_str() : h->last_step_kernel.c_str();
+}
+
 int mapf_get_stream(mapf_handle_t h, void **out_stream) {
     if (!h || !out_stream) return fail(MAPF_EINVAL, "null handle or output");
     *out_stream = static_cast<void *>(h->stream);
@@ -397,6 +438,39 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     a.n_envs = h->E; a.env_id_offset = h->env_id_offset; a.t = h->t;
     a.start_broadcast = h->start_broadcast; a.goal_broadcast = h->goal_broadcast;
     a.auto_reset = step_flags & MAPF_STEP_AUTO_RESET;
+    if (!h->device_ptrs) {
+        // tiny host-mode call: inputs and outputs live in one pinned, device-mapped block (16-byte aligned slots)
+        auto slot = [](size_t &off, size_t bytes) { const size_t at = off; off += (bytes + 15u) & ~size_t(15); return at; };
+        size_t total = 0;
+        const size_t o_act = slot(total, EA), o_uni = slot(total, uniforms ? EA * sizeof(double) : 0),
+                     o_loc = slot(total, out_local ? EA * sizeof(uint16_t) : 0), o_rew = slot(total, out_reward ? E * sizeof(double) : 0),
+                     o_prob = slot(total, out_prob ? E * sizeof(double) : 0), o_done = slot(total, out_done ? E : 0),
+                     o_coll = slot(total, out_collision ? E : 0), o_term = slot(total, out_was_terminal ? E : 0);
+        if (total <= kZeroCopyMaxBytes && E > 0) {
+            HIP_TRY(h->pinned.reserve(kZeroCopyMaxBytes));
+            char *hp = h->pinned.host, *dp = h->pinned.dev;
+            std::memcpy(hp + o_act, actions, EA);
+            a.actions = reinterpret_cast<const uint8_t *>(dp + o_act);
+            if (uniforms) { std::memcpy(hp + o_uni, uniforms, EA * sizeof(double)); a.uniforms = reinterpret_cast<const double *>(dp + o_uni); }
+            if (out_local) a.out_local = reinterpret_cast<uint16_t *>(dp + o_loc);
+            if (out_reward) a.out_reward = reinterpret_cast<double *>(dp + o_rew);
+            if (out_prob) a.out_prob = reinterpret_cast<double *>(dp + o_prob);
+            if (out_done) a.out_done = reinterpret_cast<uint8_t *>(dp + o_done);
+            if (out_collision) a.out_collision = reinterpret_cast<uint8_t *>(dp + o_coll);
+            if (out_was_terminal) a.out_was_terminal = reinterpret_cast<uint8_t *>(dp + o_term);
+            HIP_TRY(h->lane_group ? mapf::launch_step_lg(int(h->A), a, h->stream) : mapf::launch_step(int(h->A), a, h->stream));
+            if (h->last_step_kernel != g_noted_kernel) h->last_step_kernel = g_noted_kernel;
+            h->t += 1;
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            if (out_local) std::memcpy(out_local, hp + o_loc, EA * sizeof(uint16_t));
+            if (out_reward) std::memcpy(out_reward, hp + o_rew, E * sizeof(double));
+            if (out_prob) std::memcpy(out_prob, hp + o_prob, E * sizeof(double));
+            if (out_done) std::memcpy(out_done, hp + o_done, E);
+            if (out_collision) std::memcpy(out_collision, hp + o_coll, E);
+            if (out_was_terminal) std::memcpy(out_was_terminal, hp + o_term, E);
+            return MAPF_OK;
+        }
+    }
     if (int rc = stage_in(h, h->s_actions, actions, EA, &a.actions, "actions")) return rc;
     if (int rc = stage_in(h, h->s_uniforms, uniforms, EA, &a.uniforms, "uniforms")) return rc;
     if (int rc = stage_out(h, h->s_local, out_local, EA, &a.out_local, "out_local")) return rc;
@@ -406,6 +480,7 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     if (int rc = stage_out(h, h->s_coll, out_collision, E, &a.out_collision, "out_collision")) return rc;
     if (int rc = stage_out(h, h->s_term, out_was_terminal, E, &a.out_was_terminal, "out_was_terminal")) return rc;
     HIP_TRY(h->lane_group ? mapf::launch_step_lg(int(h->A), a, h->stream) : mapf::launch_step(int(h->A), a, h->stream));
+    if (h->last_step_kernel != g_noted_kernel) h->last_step_kernel = g_noted_kernel;
     h->t += 1;
     if (!h->device_ptrs) {
         if (int rc = fetch_out(h, a.out_local, out_local, EA)) return rc;
@@ -455,7 +530,8 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
         a.out_collisions = io->out_collisions; a.rec_local = io->rec_local; a.rec_reward = io->rec_reward;
         a.rec_done = io->rec_done; a.rec_collision = io->rec_collision; a.rec_prob = io->rec_prob;
         if (int rc = complete_recording(h, a, TE, TEA)) return rc;
-        HIP_TRY(h->lane_group_rollout ? mapf::launch_rollout_lg(int(h->A), a, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
+        HIP_TRY(h->lane_group_rollout ? mapf::launch_rollout_lg(int(h->A), a, h->tune, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
+        if (h->last_rollout_kernel != g_noted_kernel) h->last_rollout_kernel = g_noted_kernel;
         h->t += io->n_steps;
         return MAPF_OK;
     }
@@ -482,7 +558,8 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     if (int rc = stage_out(h, h->s_done, io->rec_done, TE, &a.rec_done, "rec_done")) return rc;
     if (int rc = stage_out(h, h->s_coll, io->rec_collision, TE, &a.rec_collision, "rec_collision")) return rc;
     if (int rc = complete_recording(h, a, TE, TEA)) return rc;
-    HIP_TRY(h->lane_group_rollout ? mapf::launch_rollout_lg(int(h->A), a, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
+    HIP_TRY(h->lane_group_rollout ? mapf::launch_rollout_lg(int(h->A), a, h->tune, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
+    if (h->last_rollout_kernel != g_noted_kernel) h->last_rollout_kernel = g_noted_kernel;
     h->t += io->n_steps;
     if (int rc = fetch_out(h, a.out_returns, io->out_returns, E)) return rc;
     if (int rc = fetch_out(h, a.out_episodes, io->out_episodes, E)) return rc;
@@ -575,6 +652,36 @@ int mapf_transitions(mapf_handle_t h, uint64_t n_queries, const uint16_t *local,
     if (int rc = fetch_out(h, a.out_reward, out_reward, NM)) return rc;
     if (int rc = fetch_out(h, a.out_done, out_done, NM)) return rc;
     if (int rc = fetch_out(h, a.out_collision, out_collision, NM)) return rc;
+    if (!h->device_ptrs) HIP_TRY(hipStreamSynchronize(h->stream));
+    return MAPF_OK;
+}
+
+int mapf_transition_rewards(mapf_handle_t h, uint64_t n_queries, const uint16_t *prev_local, const uint8_t *actions,
+                            const uint16_t *next_local, const uint32_t *env_index, double *out_reward, uint8_t *out_done,
+                            uint8_t *out_collision) {
+    if (int rc = check_handle(h)) return rc;
+    if (!prev_local || !actions || !next_local) return fail(MAPF_EINVAL, "prev_local / actions / next_local are null");
+    const size_t N = size_t(n_queries), NA = N * h->A;
+    if (!h->device_ptrs) {
+        for (size_t i = 0; i < NA; ++i)
+            if (prev_local[i] >= h->V || next_local[i] >= h->V) return fail(MAPF_EINVAL, "transition_rewards: cell out of range");
+        if (env_index) for (size_t i = 0; i < N; ++i) if (env_index[i] >= h->E) return fail(MAPF_EINVAL, "transition_rewards: env_index out of range");
+    }
+    mapf::TransitionsArgs a{};
+    a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.goal = h->goal; a.goal_broadcast = h->goal_broadcast;
+    a.n_queries = n_queries; a.max_branches = 1; a.n_agents = h->A;
+    const uint16_t *d_next = nullptr;
+    if (int rc = stage_in(h, h->q_local, prev_local, NA, &a.local, "prev_local")) return rc;
+    if (int rc = stage_in(h, h->q_actions, actions, NA, &a.actions, "actions")) return rc;
+    if (int rc = stage_in(h, h->q_next_in, next_local, NA, &d_next, "next_local")) return rc;
+    if (int rc = stage_in(h, h->q_env, env_index, N, &a.env_index, "env_index")) return rc;
+    if (int rc = stage_out(h, h->q_reward, out_reward, N, &a.out_reward, "out_reward")) return rc;
+    if (int rc = stage_out(h, h->q_done, out_done, N, &a.out_done, "out_done")) return rc;
+    if (int rc = stage_out(h, h->q_coll, out_collision, N, &a.out_collision, "out_collision")) return rc;
+    HIP_TRY(mapf::launch_transition_rewards(a, d_next, h->stream));
+    if (int rc = fetch_out(h, a.out_reward, out_reward, N)) return rc;
+    if (int rc = fetch_out(h, a.out_done, out_done, N)) return rc;
+    if (int rc = fetch_out(h, a.out_collision, out_collision, N)) return rc;
     if (!h->device_ptrs) HIP_TRY(hipStreamSynchronize(h->stream));
     return MAPF_OK;
 }

@@ -152,6 +152,7 @@ static inline unsigned grid_for(uint64_t n, unsigned block) { return unsigned((n
 hipError_t MAPF_G(launch_step_g)(int n_agents, const StepArgs &args, hipStream_t stream) {
     if (args.n_envs == 0) return hipSuccess;
     const unsigned block = pick_block(args.n_envs), grid = grid_for(args.n_envs, block);
+    note_kernel("step_kernel<A=%d,%s> block=%u (thread per env)", n_agents, args.uniforms ? "EXT_UNIFORMS" : "PHILOX", block);
     switch (n_agents) {
 #define X(N)                                                                                       \
     case N:                                                                                        \
@@ -168,6 +169,7 @@ hipError_t MAPF_G(launch_step_g)(int n_agents, const StepArgs &args, hipStream_t
 hipError_t MAPF_G(launch_rollout_g)(int n_agents, const RolloutArgs &args, hipStream_t stream) {
     if (args.n_envs == 0) return hipSuccess;
     const unsigned block = pick_block(args.n_envs), grid = grid_for(args.n_envs, block);
+    note_kernel("rollout_kernel<A=%d> block=%u (thread per env)", n_agents, block);
     switch (n_agents) {
 #define X(N)                                                                                       \
     case N:                                                                                        \

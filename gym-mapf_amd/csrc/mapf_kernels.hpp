@@ -73,6 +73,10 @@ struct RolloutArgs {
     bool start_broadcast, goal_broadcast, auto_reset, accumulate;
 };
 
+// Every launcher names the kernel instance (and block size) that took the launch; the C ABI keeps the name of a
+// handle's last step / rollout launch (mapf_last_kernel) so a benchmark labels its numbers with what actually ran.
+void note_kernel(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+
 // routed by agent count (mapf_dispatch.hip)
 struct TransitionsArgs {
     EnvConsts c;
@@ -92,6 +96,9 @@ struct TransitionsArgs {
 };
 constexpr int kTransitionsMaxAgents = 8;    // 3^8 = 6561 branches per query; beyond that the enumeration is impractical
 hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream);
+// calc_transition_reward_from_local_states for N (prev = args.local, args.actions, next) triples; fills
+// args.out_reward / out_done / out_collision [N] (max_branches, out_count, out_next, out_prob unused)
+hipError_t launch_transition_rewards(const TransitionsArgs &args, const uint16_t *next, hipStream_t stream);
 
 hipError_t launch_step(int n_agents, const StepArgs &args, hipStream_t stream);
 hipError_t launch_rollout(int n_agents, const RolloutArgs &args, hipStream_t stream);
@@ -106,10 +113,19 @@ hipError_t launch_query_terminal(int n_agents, const uint16_t *state, const uint
 // lane-group family (mapf_lg_kernels.hip): any A up to 128, run-time A
 constexpr int kTpeMaxAgents = 16;         // thread-per-env step kernels are specialised for A = 1..16
 constexpr int kTpeRolloutMaxAgents = 6;   // ... their rollout form is dispatched only where it is spill-free
+// Layout choices of the fused rollout, fixed per handle at mapf_create (environment overrides are read there, so a
+// process can hold handles with different settings -- the tests do).
+struct RolloutTuning {
+    bool quad_lanes = true;          // MAPF_QUAD_LANES=0 forces the pair layout
+    uint64_t quad_min_lanes = 0;     // the quad layout needs at least this many lanes (MAPF_QUAD_MIN_LANES; default: two
+                                     // waves on every SIMD of the device)
+    size_t mv_lds_max_bytes = 0;     // largest move table staged into LDS (MAPF_MV_LDS_MAX_BYTES; default: two blocks per CU)
+};
+RolloutTuning default_rollout_tuning(int device);
 hipError_t launch_step_lg(int n_agents, const StepArgs &args, hipStream_t stream);
-hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, hipStream_t stream);
+hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream);
 // quad-lane layout of the fused rollout (mapf_lq_rollout.hip): true when it took the launch (*err = its status)
-bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, size_t mv_lds_limit, hipStream_t stream, hipError_t *err);
+bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err);
 int lg_group_size(int n_agents);
 
 // per-group entry points: group g holds the kernels specialised for A in 4g+1 .. 4g+4

@@ -150,6 +150,8 @@ hipError_t launch_step_lg(int n_agents, const StepArgs &args, hipStream_t stream
     unsigned grid, block;
     lg_geometry(L, args.n_envs, grid, block);
     const uint32_t A = uint32_t(n_agents);
+    note_kernel("lg_step_kernel<L=%d,%s,%s> block=%u (pair layout: 2 agents per lane)", L, full ? "FULL" : "RAGGED",
+                args.uniforms ? "EXT_UNIFORMS" : "PHILOX", block);
     switch (L) {
 #define X(N)                                                                                                         \
     case N:                                                                                                          \

@@ -239,21 +239,25 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
 static constexpr size_t kLdsBytes = 160 * 1024, kLdsReserve = 1024;
 static_assert(sizeof(SlipRow) * 8 + sizeof(OutcomeRow) * 16 <= kLdsReserve, "static LDS of the rollout kernel");
 
-// Largest move table that is staged into LDS (tuning knob: MAPF_MV_LDS_MAX_BYTES, default = what leaves room
-// for two resident blocks per CU; a table that allows only one block per CU starves the SIMDs of waves).
-static size_t mv_lds_limit() {
-    static const size_t limit = [] {
-        const char *e = getenv("MAPF_MV_LDS_MAX_BYTES");
-        return e ? size_t(strtoull(e, nullptr, 10)) : (kLdsBytes - kLdsReserve) / 2;
-    }();
-    return limit;
+// Defaults of the layout choices: a move table is staged into LDS while two blocks per CU still fit (a table that
+// allows only one block per CU starves the SIMDs of waves); the quad layout needs two waves on every SIMD.
+RolloutTuning default_rollout_tuning(int device) {
+    RolloutTuning t;
+    if (const char *e = getenv("MAPF_QUAD_LANES")) t.quad_lanes = atoi(e) != 0;
+    int n_cu = 256;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) n_cu = 256;
+    t.quad_min_lanes = uint64_t(n_cu) * 4u * 64u * 2u;   // CUs x SIMDs x lanes x two waves
+    if (const char *e = getenv("MAPF_QUAD_MIN_LANES")) t.quad_min_lanes = uint64_t(strtoull(e, nullptr, 10));
+    t.mv_lds_max_bytes = (kLdsBytes - kLdsReserve) / 2;
+    if (const char *e = getenv("MAPF_MV_LDS_MAX_BYTES")) t.mv_lds_max_bytes = size_t(strtoull(e, nullptr, 10));
+    return t;
 }
 
 template <int L, bool FULL, bool RECORD, bool STREAM>
-static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, hipStream_t stream) {
+static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, const RolloutTuning &tune, hipStream_t stream) {
     const size_t mv_bytes = size_t(args.c.n_cells) * 5 * sizeof(MoveEntry);
     const uint64_t threads = args.n_envs * uint64_t(L);
-    if (mv_bytes + kLdsReserve <= mv_lds_limit() && threads >= 64 * 256) {
+    if (mv_bytes + kLdsReserve <= tune.mv_lds_max_bytes && threads >= 64 * 256) {
         // block size: as many waves as can share one table copy while >= 16 waves stay resident per CU
         const size_t copies = (kLdsBytes - kLdsReserve) / (mv_bytes + sizeof(SlipRow) * 8);   // blocks per CU by LDS
         unsigned block = copies >= 4 ? 256u : (copies >= 2 ? 512u : 1024u);
@@ -267,10 +271,15 @@ static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, hi
                                                hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsBytes - kLdsReserve));
             if (e != hipSuccess) return e;
         }
+        note_kernel("lg_rollout_kernel<L=%d,%s,MV_LDS,%s,%s,%s> block=%u (pair layout: 2 agents per lane)", L,
+                    FULL ? "FULL" : "RAGGED", RECORD ? "RECORD" : "TOTALS", STREAM ? "STREAM" : "POLICY", dense ? "DENSE" : "GUARDED", block);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(block), mv_bytes, stream, args, A);
     } else {
         unsigned grid, block;
         lg_geometry(L, args.n_envs, grid, block);
+        note_kernel("lg_rollout_kernel<L=%d,%s,MV_GLOBAL,%s,%s,%s> block=%u (pair layout: 2 agents per lane)", L,
+                    FULL ? "FULL" : "RAGGED", RECORD ? "RECORD" : "TOTALS", STREAM ? "STREAM" : "POLICY",
+                    (FULL && args.n_envs % (block / unsigned(L)) == 0) ? "DENSE" : "GUARDED", block);
         if (FULL && args.n_envs % (block / unsigned(L)) == 0)
             hipLaunchKernelGGL((lg_rollout_kernel<L, FULL, false, RECORD, STREAM, FULL>), dim3(grid), dim3(block), 0, stream, args, A);
         else
@@ -279,7 +288,7 @@ static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, hi
     return hipGetLastError();
 }
 
-hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, hipStream_t stream) {
+hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream) {
     if (args.n_envs == 0) return hipSuccess;
     const int L = lg_group_size(n_agents);
     const bool full = n_agents == 2 * L;
@@ -288,18 +297,18 @@ hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, hipStream_t 
     const bool record = args.rec_local != nullptr, stream_actions = args.actions != nullptr;
     if (record && !(args.rec_reward && args.rec_prob && args.rec_done && args.rec_collision)) return hipErrorInvalidValue;
     hipError_t quad_status;
-    if (try_launch_rollout_lq(n_agents, args, mv_lds_limit(), stream, &quad_status)) return quad_status;
+    if (try_launch_rollout_lq(n_agents, args, tune, stream, &quad_status)) return quad_status;
     switch (L) {
 #define X(N)                                                                                                         \
     case N:                                                                                                          \
-        if (full) return record ? (stream_actions ? launch_rollout_lg_impl<N, true, true, true>(args, A, stream)          \
-                                                  : launch_rollout_lg_impl<N, true, true, false>(args, A, stream))        \
-                                : (stream_actions ? launch_rollout_lg_impl<N, true, false, true>(args, A, stream)         \
-                                                  : launch_rollout_lg_impl<N, true, false, false>(args, A, stream));      \
-        return record ? (stream_actions ? launch_rollout_lg_impl<N, false, true, true>(args, A, stream)                   \
-                                        : launch_rollout_lg_impl<N, false, true, false>(args, A, stream))                 \
-                      : (stream_actions ? launch_rollout_lg_impl<N, false, false, true>(args, A, stream)                  \
-                                        : launch_rollout_lg_impl<N, false, false, false>(args, A, stream));
+        if (full) return record ? (stream_actions ? launch_rollout_lg_impl<N, true, true, true>(args, A, tune, stream)          \
+                                                  : launch_rollout_lg_impl<N, true, true, false>(args, A, tune, stream))        \
+                                : (stream_actions ? launch_rollout_lg_impl<N, true, false, true>(args, A, tune, stream)         \
+                                                  : launch_rollout_lg_impl<N, true, false, false>(args, A, tune, stream));      \
+        return record ? (stream_actions ? launch_rollout_lg_impl<N, false, true, true>(args, A, tune, stream)                   \
+                                        : launch_rollout_lg_impl<N, false, true, false>(args, A, tune, stream))                 \
+                      : (stream_actions ? launch_rollout_lg_impl<N, false, false, true>(args, A, tune, stream)                  \
+                                        : launch_rollout_lg_impl<N, false, false, false>(args, A, tune, stream));
         MAPF_FOR_EACH_L(X)
 #undef X
         default: return hipErrorInvalidValue;

@@ -393,6 +393,8 @@ hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size
         if (e != hipSuccess) return e;
     }
     const unsigned grid = unsigned(args.n_envs / (block / unsigned(Q)));
+    note_kernel("lq_rollout_kernel<Q=%d,%s,%s> block=%u (quad layout: 4 agents per lane)", Q, RECORD ? "RECORD" : "TOTALS",
+                STREAM ? "STREAM" : "POLICY", block);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), mv_bytes, stream, args, A);
     return hipGetLastError();
 }
@@ -400,19 +402,13 @@ hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size
 }  // namespace
 
 // true when the quad layout took the launch (*err = its status); false = not applicable, use the pair layout
-bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, size_t mv_lds_limit, hipStream_t stream, hipError_t *err) {
-    static const bool enabled = [] { const char *e = getenv("MAPF_QUAD_LANES"); return !e || atoi(e) != 0; }();
-    if (!enabled || n_agents < 4 || n_agents % 4 != 0) return false;
+bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err) {
+    if (!tune.quad_lanes || n_agents < 4 || n_agents % 4 != 0) return false;
     // Half as many lanes per env means half as many waves: the quad layout only pays while it still keeps two waves on
     // every SIMD (measured: 65536 envs x 8 agents = 2 waves/SIMD -> 460 G vs 413 G agent-steps/s for the pair layout;
-    // 32768 envs = 1 wave/SIMD -> 233 G vs 300 G).  MAPF_QUAD_MIN_LANES overrides the threshold (tests use 0).
-    static const uint64_t min_lanes = [] {
-        if (const char *e = getenv("MAPF_QUAD_MIN_LANES")) return uint64_t(strtoull(e, nullptr, 10));
-        int dev = 0, n_cu = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            n_cu = 256;
-        return uint64_t(n_cu) * 4u * 64u * 2u;   // CUs x SIMDs x lanes x two waves
-    }();
+    // 32768 envs = 1 wave/SIMD -> 233 G vs 300 G): tune.quad_min_lanes.
+    const uint64_t min_lanes = tune.quad_min_lanes;
+    const size_t mv_lds_limit = tune.mv_lds_max_bytes;
     const int Q = n_agents / 4;
     if (Q > 16 || (Q & (Q - 1)) != 0) return false;
     const size_t mv_bytes = size_t(args.c.n_cells) * 5 * sizeof(MoveEntry);

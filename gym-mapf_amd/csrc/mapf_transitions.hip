@@ -102,6 +102,45 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
     if (p.out_collision) p.out_collision[o] = coll ? 1 : 0;
 }
 
+// MapfEnv.calc_transition_reward_from_local_states (mapf_env.py:225-235) for N given (prev, joint action, next)
+// triples: _living_reward (:436-446), then collision (:378-389, vertex or swap over every agent pair) before goal.
+// Unlike step() it does not look at is_terminal(prev) -- neither does the reference method.  One thread per query,
+// run-time A (the reference's own double loop; queries are independent, so lanes never diverge on the trip count).
+__global__ void __launch_bounds__(256) transition_reward_kernel(const TransitionsArgs p, const uint16_t *next) {
+    const uint64_t q = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (q >= p.n_queries) return;
+    const uint32_t A = p.n_agents;
+    const uint64_t env = p.env_index ? p.env_index[q] : 0;
+    const uint16_t *goal = p.goal + (p.goal_broadcast ? 0 : env * A);
+    const uint16_t *prev = p.local + q * A, *nxt = next + q * A;
+    const uint8_t *act = p.actions + q * A;
+    uint32_t coll_acc = 0xFFFFFFFFu, goal_next_acc = 0u;
+    int stayed = 0;
+    for (uint32_t i = 0; i < A; ++i) {
+        const uint32_t pi = prev[i], ni = nxt[i], a = act[i] > 4u ? 0u : act[i];
+        stayed += (pi == goal[i] && a == 0u) ? 1 : 0;
+        goal_next_acc |= ni ^ goal[i];
+        for (uint32_t j = i + 1; j < A; ++j) {
+            const uint32_t pj = prev[j], nj = nxt[j];
+            coll_acc = min(coll_acc, min(ni ^ nj, (pi ^ nj) | (pj ^ ni)));
+        }
+    }
+    const bool coll = coll_acc == 0u, goal_next = goal_next_acc == 0u;
+    double living = p.c.r_living;
+    if (p.c.criteria == 1u) living = __dmul_rn(double(int(A) - stayed), p.c.r_living);
+    if (p.out_reward) p.out_reward[q] = coll ? __dadd_rn(p.c.r_clash, living) : (goal_next ? __dadd_rn(p.c.r_goal, living) : living);
+    if (p.out_done) p.out_done[q] = (coll || goal_next) ? 1 : 0;
+    if (p.out_collision) p.out_collision[q] = coll ? 1 : 0;
+}
+
+hipError_t launch_transition_rewards(const TransitionsArgs &args, const uint16_t *next, hipStream_t stream) {
+    if (args.n_queries == 0) return hipSuccess;
+    const uint64_t grid64 = (args.n_queries + 255) / 256;
+    if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(transition_reward_kernel, dim3(unsigned(grid64)), dim3(256), 0, stream, args, next);
+    return hipGetLastError();
+}
+
 hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream) {
     const uint64_t threads = args.n_queries * uint64_t(args.max_branches);
     if (threads == 0) return hipSuccess;

@@ -17,6 +17,7 @@ MAPF_FLAG_THREAD_PER_ENV, MAPF_FLAG_LANE_GROUP = 0x10, 0x20
 MAPF_TPE_MAX_AGENTS = 16
 MAPF_POLICY_RANDOM, MAPF_POLICY_GREEDY = 0, 1
 MAPF_STEP_AUTO_RESET = 0x1
+MAPF_KERNEL_STEP, MAPF_KERNEL_ROLLOUT = 0, 1
 
 
 class MapfNativeError(RuntimeError):
@@ -51,6 +52,7 @@ SIGNATURES = {
     'mapf_set_policy': (c_int, [c_void_p, c_int, c_void_p]),
     'mapf_transitions': (c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
+    'mapf_transition_rewards': (c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mapf_query_terminal': (c_int, [c_void_p, c_void_p]),
     'mapf_get_state': (c_int, [c_void_p, c_void_p, POINTER(c_uint64)]),
     'mapf_set_state': (c_int, [c_void_p, c_void_p, c_uint64]),
@@ -58,6 +60,7 @@ SIGNATURES = {
     'mapf_timer_begin': (c_int, [c_void_p]),
     'mapf_timer_end': (c_int, [c_void_p, POINTER(c_double)]),
     'mapf_get_stream': (c_int, [c_void_p, POINTER(c_void_p)]),
+    'mapf_last_kernel': (c_char_p, [c_void_p, c_int]),
     'mapf_device_count': (c_int, [POINTER(c_int)]),
     'mapf_last_error': (c_char_p, []),
     'mapf_version': (c_char_p, []),

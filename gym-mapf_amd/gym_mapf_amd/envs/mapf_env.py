@@ -84,6 +84,39 @@ def np_random(seed=None):
 _DELTA = {UP: (-1, 0), DOWN: (1, 0), LEFT: (0, -1), RIGHT: (0, 1), STAY: (0, 0)}
 
 
+def stay_if_hit_obstacle(exec_func):
+    """Decorator of the single-location movers (reference mapf_env.py:43-51): a move whose target cell is an
+    obstacle leaves the location unchanged."""
+    def guarded(loc, map):
+        target = exec_func(loc, map)
+        return loc if map[target] is ObstacleCell else target
+    guarded.__name__ = getattr(exec_func, '__name__', 'guarded')
+    return guarded
+
+
+def _clamped_move(action):
+    dr, dc = _DELTA[action]
+
+    def move(loc, map):
+        return (min(max(loc[0] + dr, 0), len(map) - 1), min(max(loc[1] + dc, 0), len(map[0]) - 1))
+    move.__name__ = 'execute_' + action.lower()
+    return move
+
+
+# one-location movers with the reference's names and (loc, map) signature (mapf_env.py:54-75)
+execute_up = stay_if_hit_obstacle(_clamped_move(UP))
+execute_down = stay_if_hit_obstacle(_clamped_move(DOWN))
+execute_right = stay_if_hit_obstacle(_clamped_move(RIGHT))
+execute_left = stay_if_hit_obstacle(_clamped_move(LEFT))
+
+
+def execute_stay(loc, _):
+    return loc
+
+
+ACTION_TO_FUNC = {UP: execute_up, DOWN: execute_down, RIGHT: execute_right, LEFT: execute_left, STAY: execute_stay}
+
+
 def execute_action(grid, s, noised_action):
     """Move every location of ``s`` by its action: clamp at the map border, stay put if the
     clamped target is an obstacle (reference mapf_env.py:43-94).  Host-side helper for callers
@@ -175,6 +208,10 @@ class MapfEnv(_EnvBase):
                                    self.fail_prob, self.reward_of_clash, self.reward_of_goal,
                                    self.reward_of_living, self.optimization_criteria, n_envs=1)
             self._vec.set_state(np.asarray([self._local], dtype=np.uint16))
+            # step() reuses one set of arrays and one validated call (see VecMapfEnv.prepare_step)
+            n = self.n_agents
+            self._act_buf, self._uni_buf = np.zeros((1, n), np.uint8), np.zeros((1, n), np.float64)
+            self._step_call, self._step_out = self._vec.prepare_step(self._act_buf, uniforms=self._uni_buf)
         return self._vec
 
     def __copy__(self):
@@ -205,16 +242,25 @@ class MapfEnv(_EnvBase):
             self._terminal = bool(dev.query_terminal()[0])
         if self._terminal:
             return self.s, 0, True, {"prob": 0}
-        digits = integer_to_vector(a, [len(ACTIONS)] * self.n_agents, self.n_agents, lambda n: n)
-        uniforms = [self.np_random.rand() for _ in range(self.n_agents)]
-        local, reward, done, info = dev.step(np.asarray([digits], dtype=np.uint8),
-                                             uniforms=np.asarray([uniforms], dtype=np.float64))
-        self._local = tuple(int(x) for x in local[0])
-        self._s = vector_to_integer(self._local, [len(self.valid_locations)] * self.n_agents, lambda x: x)
-        done = bool(done[0])
-        self._terminal = None if done else False   # a done state may (vertex/goal) or may not (swap) be terminal
-        return self._s, float(reward[0]), done, {"prob": float(info['prob'][0]),
-                                                 "collision": bool(info['collision'][0])}
+        n = self.n_agents
+        act, uni, rand = self._act_buf[0], self._uni_buf[0], self.np_random.rand
+        for i in range(n):                     # joint action digits, agent 0 least significant (:242-243)
+            a, act[i] = divmod(a, 5)
+        for i in range(n):                     # one draw per agent, in agent order (:253-255)
+            uni[i] = rand()
+        self._step_call()                      # one launch + one stream sync (host mode)
+        out = self._step_out
+        self._local = local = tuple(out['local'][0].tolist())
+        state, weight, V = 0, 1, len(self.valid_locations)
+        for c in local:
+            state += c * weight
+            weight *= V
+        self._s = state
+        done, collision = bool(out['done'][0]), bool(out['collision'][0])
+        # is_terminal of the returned state, from what the kernel reported: not done -> no; goal reached -> yes;
+        # collision -> only a vertex collision leaves two agents in one cell (a swap alone does not, :210-223)
+        self._terminal = done and (not collision or len(set(local)) < n)
+        return state, float(out['reward'][0]), done, {"prob": float(out['prob'][0]), "collision": collision}
 
     def _get_transitions(self, s, a):
         """All branches of taking joint action ``a`` in joint state ``s``, in the reference's order
@@ -229,6 +275,36 @@ class MapfEnv(_EnvBase):
             out.append(((float(res['prob'][0, b]), bool(res['collision'][0, b])), nxt,
                         float(res['reward'][0, b]), bool(res['done'][0, b])))
         return out
+
+    def _locals_query(self, *rows):
+        return [np.asarray([list(r)], dtype=np.uint16) for r in rows]
+
+    def calc_transition_reward_from_local_states(self, prev_local_states, action: int, next_local_states):
+        """``(reward, done, is_collision)`` of moving from ``prev_local_states`` to ``next_local_states`` (tuples of
+        local cell ids) under joint action ``action``: collision reward first, then goal, else the living reward
+        (reference :225-235).  Evaluated by the ``mapf_transition_rewards`` kernel."""
+        n = self.n_agents
+        digits = integer_to_vector(action, [len(ACTIONS)] * n, n, lambda x: x)
+        prev, nxt = self._locals_query(prev_local_states, next_local_states)
+        reward, done, coll = self._device().transition_rewards(prev, np.asarray([digits], dtype=np.uint8), nxt)
+        return float(reward[0]), bool(done[0]), bool(coll[0])
+
+    def _is_collision_transition_from_local_states(self, prev_local_states, next_local_states):
+        """Vertex collision (two agents end in one cell) or swap (two agents exchange cells); reference :378-389."""
+        prev, nxt = self._locals_query(prev_local_states, next_local_states)
+        _, _, coll = self._device().transition_rewards(prev, np.zeros((1, self.n_agents), np.uint8), nxt)
+        return bool(coll[0])
+
+    def _living_reward(self, prev_local_states, a: int):
+        """Makespan: ``reward_of_living``; SoC: every agent pays it unless it sits on its goal and stays
+        (reference :436-446).  Host arithmetic (an int count times the reward, like the reference's); the device
+        evaluates the same rule inside ``calc_transition_reward_from_local_states`` and the tests compare the two."""
+        if self.optimization_criteria == OptimizationCriteria.Makespan:
+            return self.reward_of_living
+        vector_a = integer_to_vector(a, [len(ACTIONS)] * self.n_agents, self.n_agents, lambda x: x)
+        stayed = sum(1 for i in range(self.n_agents)
+                     if prev_local_states[i] == self.loc_to_int[tuple(self.agents_goals[i])] and vector_a[i] == 0)
+        return (self.n_agents - stayed) * self.reward_of_living
 
     def is_terminal(self, s):
         """``s``: tuple of agent locations.  True when two agents share a cell or every agent is on its goal

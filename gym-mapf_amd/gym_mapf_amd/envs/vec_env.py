@@ -274,6 +274,25 @@ class VecMapfEnv:
             self._ptr(res['collision'], np.uint8, (N, M), 'collision')))
         return res
 
+    def transition_rewards(self, prev_local, actions, next_local, env_index=None):
+        """``calc_transition_reward_from_local_states`` (reference mapf_env.py:225-235) for N given transitions:
+        ``prev_local`` / ``next_local`` uint16 [N, A], ``actions`` uint8 [N, A].  Returns ``(reward f64 [N],
+        done u8 [N], collision u8 [N])``."""
+        A = self.n_agents
+        prev_local = np.asarray(prev_local) if not self.device_arrays else prev_local
+        N = int(prev_local.shape[0])
+        prev_local = self._coerce(prev_local, np.uint16, (N, A), 'prev_local')
+        next_local = self._coerce(next_local, np.uint16, (N, A), 'next_local')
+        actions = self._coerce(actions, np.uint8, (N, A), 'actions')
+        env_index = self._coerce(env_index, np.uint32, (N,), 'env_index')
+        reward, done, coll = self._empty((N,), np.float64), self._empty((N,), np.uint8), self._empty((N,), np.uint8)
+        nat.check(self._lib.mapf_transition_rewards(
+            self._h, N, self._ptr(prev_local, np.uint16, (N, A), 'prev_local'),
+            self._ptr(actions, np.uint8, (N, A), 'actions'), self._ptr(next_local, np.uint16, (N, A), 'next_local'),
+            self._ptr(env_index, np.uint32, (N,), 'env_index'), self._ptr(reward, np.float64, (N,), 'reward'),
+            self._ptr(done, np.uint8, (N,), 'done'), self._ptr(coll, np.uint8, (N,), 'collision')))
+        return reward, done, coll
+
     def fill_random_actions(self, t0, n_steps, out=None):
         """Synthetic policy stream: uint8 [n_steps, E, A] uniform over the 5 actions."""
         shape = (int(n_steps), self.n_envs, self.n_agents)
@@ -337,6 +356,12 @@ class VecMapfEnv:
         ms = ctypes.c_double(0.0)
         nat.check(self._lib.mapf_timer_end(self._h, ctypes.byref(ms)))
         return ms.value
+
+    def last_kernel(self, which='rollout'):
+        """Name of the kernel instance that took this env's last ``step`` / ``rollout`` launch (the library picks
+        the lane layout from A, E and the table size); '' before the first launch."""
+        code = {'step': nat.MAPF_KERNEL_STEP, 'rollout': nat.MAPF_KERNEL_ROLLOUT}[which]
+        return self._lib.mapf_last_kernel(self._h, code).decode()
 
     @property
     def stream(self):

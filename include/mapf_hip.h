@@ -180,6 +180,18 @@ int mapf_transitions(mapf_handle_t h, uint64_t n_queries, const uint16_t *local,
                      const uint32_t *env_index, uint32_t max_branches, uint32_t *out_count, uint16_t *out_next,
                      double *out_prob, double *out_reward, uint8_t *out_done, uint8_t *out_collision);
 
+/*
+ * MapfEnv.calc_transition_reward_from_local_states (mapf_env.py:225-235, with _living_reward :436-446 and
+ * _is_collision_transition_from_local_states :378-389) for n_queries given transitions:
+ *   prev_local u16[N*A], actions u8[N*A] (the decoded joint action), next_local u16[N*A];
+ *   env_index u32[N] selects whose goals apply (NULL: env 0);
+ *   out_reward f64[N], out_done u8[N], out_collision u8[N]  (the method's (reward, done, collision) triple).
+ * Like the reference method it does not test is_terminal(prev).  Any n_agents; any out_* may be NULL.
+ */
+int mapf_transition_rewards(mapf_handle_t h, uint64_t n_queries, const uint16_t *prev_local, const uint8_t *actions,
+                            const uint16_t *next_local, const uint32_t *env_index, double *out_reward, uint8_t *out_done,
+                            uint8_t *out_collision);
+
 /* MapfEnv.is_terminal (mapf_env.py:210-223) of every env's CURRENT state: out_terminal u8[E] is 1
  * where two agents share a cell or every agent is on its goal (a step there is a no-op). */
 int mapf_query_terminal(mapf_handle_t h, uint8_t *out_terminal);
@@ -199,6 +211,15 @@ int mapf_timer_end(mapf_handle_t h, double *out_ms);
 
 /* The hipStream_t the handle enqueues on (for interop with other libraries). */
 int mapf_get_stream(mapf_handle_t h, void **out_stream);
+
+/* Which kernel instance took the handle's most recent mapf_step (MAPF_KERNEL_STEP) or mapf_rollout
+ * (MAPF_KERNEL_ROLLOUT) launch, e.g. "lq_rollout_kernel<Q=2,RECORD,STREAM> block=512": the library chooses the
+ * lane layout from A, E and the table size, so measurements label themselves with what actually ran (no reference
+ * counterpart: the reference has one code path, mapf_env.py:237-266).  "" before the first launch.  The string is
+ * owned by the handle and valid until its next launch of that kind. */
+#define MAPF_KERNEL_STEP    0
+#define MAPF_KERNEL_ROLLOUT 1
+const char *mapf_last_kernel(mapf_handle_t h, int which);
 
 int mapf_device_count(int *out_count);
 const char *mapf_last_error(void);

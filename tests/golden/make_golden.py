@@ -36,6 +36,7 @@ REFERENCE = '/root/reference'
 sys.dont_write_bytecode = True
 sys.path.insert(0, os.path.join(ROOT, 'oracle'))
 import philox  # noqa: E402
+import goal_scenarios  # noqa: E402
 
 
 # ----------------------------------------------------------------- stand-ins
@@ -151,8 +152,9 @@ def movement_tables(env):
 
 
 def run_trajectories(name, lines, per_env_locs, n_agents, fail_prob, criteria, env_ids, T,
-                     auto_reset, map_name=None, n_uniform_steps=32):
-    """Lock-step run of one reference env per env id; returns dict of arrays."""
+                     auto_reset, map_name=None, n_uniform_steps=32, action_fn=None):
+    """Lock-step run of one reference env per env id; returns dict of arrays.  ``action_fn(env, env_id, t)`` ->
+    per-agent action indices, or None for the uniform-random policy stream."""
     E, A = len(env_ids), n_agents
     grid = MapfGrid(lines)
     out = dict(
@@ -180,6 +182,10 @@ def run_trajectories(name, lines, per_env_locs, n_agents, fail_prob, criteria, e
         env_s = []
         for t in range(T):
             rng.begin(t)
+            if action_fn is not None:
+                picked = action_fn(env, int(env_id), t)
+                if picked is not None:
+                    acts[t] = picked
             a_vec = tuple(ACTIONS[k] for k in acts[t])
             s, r, done, info = env.step(vector_action_to_integer(a_vec))
             out['actions'][t, j] = acts[t]
@@ -203,6 +209,8 @@ def run_trajectories(name, lines, per_env_locs, n_agents, fail_prob, criteria, e
                 fail_prob=fail_prob, criteria=criteria, r_clash=R_CLASH, r_goal=R_GOAL,
                 r_living=R_LIVING, seed=SEED, T=T, auto_reset=auto_reset, V=len(first.valid_locations),
                 nS=str(first.nS), nA=str(first.nA), joint_state_first_steps=s_dec)
+    if action_fn is not None:   # (key absent = the uniform-random policy stream, as in the round-1 sets)
+        meta['actions_from'] = 'towards_goal, every fifth step (t % 5 == 4) the policy stream'  # see main()
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
     with open(os.path.join(HERE, name + '.json'), 'w') as f:
         json.dump(meta, f, indent=0)
@@ -417,6 +425,39 @@ def host_api_cases():
     for locs in (((0, 0), (1, 2)), ((2, 2), (0, 0)), ((1, 1), (1, 1)), ((2, 2), (1, 0)), ((0, 3), (0, 3))):
         term.append(dict(locs=[list(l) for l in locs], terminal=bool(e.is_terminal(locs))))
     out['is_terminal'] = dict(lines=['..@.', '....', '.@..'], starts=[[0, 0], [1, 2]], goals=[[2, 2], [0, 0]], cases=term)
+    # hot-path helper methods planners call directly (mapf_env.py:225-235, :378-389, :436-446), on local cell ids
+    helper = []
+    lines3 = ['..@.', '....', '.@..']
+    for crit, rewards in (('SoC', (-1000.0, 100.0, -1.0)), ('Makespan', (-33.25, 7.125, -0.1)), ('SoC', (-5, 3, -2))):
+        e = MapfEnv(MapfGrid(lines3), 3, ((0, 0), (1, 2), (2, 3)), ((2, 2), (0, 0), (1, 3)), 0.2,
+                    rewards[0], rewards[1], rewards[2], CRITERIA[crit])
+        l2i = e.loc_to_int
+        trips = []
+        for prev, acts, nxt in ((((0, 0), (1, 2), (2, 3)), ('DOWN', 'LEFT', 'UP'), ((1, 0), (1, 1), (1, 3))),
+                                (((2, 2), (0, 0), (1, 3)), ('STAY', 'STAY', 'STAY'), ((2, 2), (0, 0), (1, 3))),
+                                (((2, 2), (0, 1), (1, 3)), ('STAY', 'LEFT', 'STAY'), ((2, 2), (0, 0), (1, 3))),
+                                (((1, 1), (1, 2), (2, 3)), ('RIGHT', 'LEFT', 'STAY'), ((1, 2), (1, 1), (2, 3))),
+                                (((1, 0), (1, 2), (2, 3)), ('RIGHT', 'LEFT', 'UP'), ((1, 1), (1, 1), (1, 3))),
+                                (((2, 2), (0, 0), (1, 3)), ('STAY', 'RIGHT', 'STAY'), ((2, 2), (0, 1), (1, 3))),
+                                (((2, 3), (0, 0), (2, 2)), ('LEFT', 'STAY', 'RIGHT'), ((2, 2), (0, 0), (2, 3)))):
+            pl, nl = tuple(l2i[x] for x in prev), tuple(l2i[x] for x in nxt)
+            a = vector_action_to_integer(acts)
+            r, d, c = e.calc_transition_reward_from_local_states(pl, a, nl)
+            trips.append(dict(prev_local=list(pl), action=a, next_local=list(nl), reward=float(r), done=bool(d), collision=bool(c),
+                              living=float(e._living_reward(pl, a)),
+                              is_collision=bool(e._is_collision_transition_from_local_states(pl, nl))))
+        helper.append(dict(lines=lines3, starts=[[0, 0], [1, 2], [2, 3]], goals=[[2, 2], [0, 0], [1, 3]], criteria=crit,
+                           rewards=list(rewards), fail_prob=0.2, cases=trips))
+    out['transition_reward_helpers'] = helper
+    # the single-location movers (mapf_env.py:43-75)
+    import gym_mapf.envs.mapf_env as ref_env
+    g3 = MapfGrid(lines3)
+    movers = []
+    for name in ('execute_up', 'execute_down', 'execute_right', 'execute_left', 'execute_stay'):
+        fn = getattr(ref_env, name)
+        movers.append(dict(name=name, results=[[list(loc), list(fn(loc, g3))]
+                                               for loc in ((0, 0), (0, 1), (1, 1), (1, 2), (2, 0), (0, 3), (2, 3), (2, 2), (1, 3))]))
+    out['single_location_movers'] = dict(lines=lines3, movers=movers)
     with open(os.path.join(HERE, 'host_api_cases.json'), 'w') as f:
         json.dump(out, f, indent=0)
     print('host api cases: %d sanity, %d views, %d predecessor envs, %d render frames' % (len(san), len(views), len(preds), len(rend)))
@@ -479,6 +520,23 @@ def main():
     maze = ref_map_lines('maze-32-32-4')
     run_trajectories('maze32_a5_slip05', maze, scen_locs('maze-32-32-4', [10, 12, 16, 24], 5), 5, 0.5, 'SoC',
                      list(range(8)), 300, True, 'maze-32-32-4')
+    # episodes that END ON GOALS at 4..32 agents (oracle/goal_scenarios.py): starts one move from the goals on an
+    # open map, every agent driven towards its goal (every fifth step: the random policy stream instead); every
+    # third env lets two agents share a goal cell -> vertex collision with every agent on its goal
+    for A, fp, crit, auto, T in ((4, 0.2, 'Makespan', True, 60), (8, 0.2, 'SoC', True, 60), (8, 0.0, 'Makespan', False, 6),
+                                 (16, 0.2, 'Makespan', True, 60), (32, 0.2, 'SoC', True, 80), (32, 0.0, 'Makespan', True, 12)):
+        n_env = 12
+        lines, st, gl = goal_scenarios.goal_scenario(A, n_env, 7000 + A)
+
+        def towards(env, env_id, t, gl=gl, lines=lines):
+            if t % 5 == 4:
+                return None
+            locs = env.state_to_locations(env.s)
+            return [goal_scenarios.towards_goal_action(locs[i], tuple(gl[env_id, i]), len(lines), len(lines[0]))
+                    for i in range(len(locs))]
+        run_trajectories('goals_a%d_slip%s_%s%s' % (A, str(fp).replace('.', ''), crit.lower(), '' if auto else '_noreset'),
+                         lines, lambda j, env_id, st=st, gl=gl: (tuple(map(tuple, st[env_id].tolist())), tuple(map(tuple, gl[env_id].tolist()))),
+                         A, fp, crit, list(range(n_env)), T, auto, None, action_fn=towards)
 
     with open(os.path.join(HERE, 'generation_info.json'), 'w') as f:
         json.dump(info, f, indent=1)

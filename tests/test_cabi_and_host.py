@@ -90,21 +90,45 @@ def test_product_never_imports_the_oracle():
                 assert 'mapf_oracle' not in text and 'c_oracle' not in text and 'import philox' not in text, f
 
 
-def test_dispatched_lane_group_kernels_have_no_register_spills(tmp_path):
-    """The lane-group family serves every agent count; its code objects must not spill (spilled
-    SGPRs/VGPRs both cost time and were the one place a miscompile was ever observed)."""
-    text = ''
-    procs = []
+def _kernel_resources(asm_text):
+    """{kernel symbol: (sgpr spills, vgpr spills, scratch bytes)} from the .amdgpu_metadata of a -S listing."""
+    out = {}
+    for block in asm_text.split('  - .agpr_count:')[1:]:
+        name = re.search(r'\.name:\s+(\S+)', block).group(1)
+        out[name] = (int(re.search(r'\.sgpr_spill_count:\s+(\d+)', block).group(1)),
+                     int(re.search(r'\.vgpr_spill_count:\s+(\d+)', block).group(1)),
+                     int(re.search(r'\.private_segment_fixed_size:\s+(\d+)', block).group(1)))
+    return out
+
+
+def test_every_dispatchable_kernel_is_free_of_register_spills(tmp_path):
+    """No code object the launchers can reach may spill registers: a spilling thread-per-env rollout kernel is the
+    one place a wrong result was ever observed on the GPU (compiler notes), and spills cost time.  Covers
+    the lane-group and quad-lane families, the transition kernels AND the thread-per-env family (mapf_kernels.hip,
+    compiled once per agent-count group like the Makefile does); of the latter's rollout kernels only those
+    launch_rollout_g* dispatches (A <= kTpeRolloutMaxAgents) are held to it -- the others are never launched."""
+    jobs = []
+    flags = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-I' + os.path.join(ROOT, 'include'),
+             '-S', '--cuda-device-only']
     for unit in ('mapf_lg_kernels', 'mapf_lg_rollout', 'mapf_lq_rollout', 'mapf_transitions'):
-        out = tmp_path / (unit + '.s')
-        procs.append((out, subprocess.Popen(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off',
-                                             '-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only',
-                                             os.path.join(CSRC, unit + '.hip'), '-o', str(out)], stderr=subprocess.DEVNULL)))
+        jobs.append((unit, [], tmp_path / (unit + '.s')))
+    for g in range(4):
+        jobs.append(('mapf_kernels', ['-DMAPF_GROUP=%d' % g], tmp_path / ('mapf_kernels_g%d.s' % g)))
+    procs = [(out, subprocess.Popen(flags + extra + [os.path.join(CSRC, unit + '.hip'), '-o', str(out)],
+                                    stderr=subprocess.DEVNULL)) for unit, extra, out in jobs]
+    resources = {}
     for out, proc in procs:
         assert proc.wait() == 0
-        text += out.read_text()
-    kernels = re.findall(r'\.name:\s+(_ZN4mapf\w+)', text)
-    assert len(kernels) >= 100
-    spills = [int(x) for x in re.findall(r'\.(?:sgpr|vgpr)_spill_count:\s+(\d+)', text)]
-    scratch = [int(x) for x in re.findall(r'\.private_segment_fixed_size:\s+(\d+)', text)]
-    assert spills and all(v == 0 for v in spills) and all(v == 0 for v in scratch)
+        resources.update(_kernel_resources(out.read_text()))
+    assert len(resources) >= 150
+    max_tpe_rollout = int(re.search(r'kTpeRolloutMaxAgents\s*=\s*(\d+)', open(os.path.join(CSRC, 'mapf_kernels.hpp')).read()).group(1))
+    checked = tpe_step = tpe_rollout = 0
+    for name, (sgpr, vgpr, scratch) in resources.items():
+        m = re.match(r'_ZN4mapf14rollout_kernelILi(\d+)E', name)
+        if m and int(m.group(1)) > max_tpe_rollout:
+            continue                                              # compiled, never dispatched
+        tpe_rollout += bool(m)
+        tpe_step += name.startswith('_ZN4mapf11step_kernelILi')
+        assert (sgpr, vgpr, scratch) == (0, 0, 0), (name, sgpr, vgpr, scratch)
+        checked += 1
+    assert tpe_step == 32 and tpe_rollout == max_tpe_rollout and checked >= 130

@@ -87,7 +87,8 @@ def test_fused_rollout_matches_reference(trajectory_set):
     T = meta['T']
     for kernel, (lo, hi) in [(k, r) for k in _families(meta['n_agents']) for r in _id_runs(g['env_ids'])]:
         sel = np.arange(lo, hi)
-        for actions in (np.ascontiguousarray(g['actions'][:, sel]), None):
+        # (sets with scripted actions -- the goal-seeking ones -- have no in-kernel counterpart of their action source)
+        for actions in (np.ascontiguousarray(g['actions'][:, sel]),) + (() if 'actions_from' in meta else (None,)):
             env = _vec(meta, g, sel, env_id_offset=int(g['env_ids'][lo]), kernel=kernel)
             res = env.rollout(T, actions=actions, auto_reset=meta['auto_reset'], record=True)
             assert np.array_equal(res['local'], g['next_local'][:, sel])
@@ -373,13 +374,82 @@ def test_greedy_policy_rollout_against_c_oracle(n_agents, n_envs, kernel):
     env.close()
 
 
+# ----------------------------------------------------------------------- episodes that end on goals
+def _goal_scenario_tables(n_agents, n_envs, seed):
+    import goal_scenarios
+    lines, start_loc, goal_loc = goal_scenarios.goal_scenario(n_agents, n_envs, seed)
+    grid = MapfGrid(lines)
+    valid, l2i, nbr = grid.tables()
+    ids = np.zeros((len(lines), len(lines[0])), np.uint16)
+    for loc, k in l2i.items():
+        ids[loc] = k
+    start = np.ascontiguousarray(ids[start_loc[..., 0], start_loc[..., 1]])
+    goal = np.ascontiguousarray(ids[goal_loc[..., 0], goal_loc[..., 1]])
+    rc = np.asarray([r | (c << 16) for r, c in valid], np.uint32)
+    return grid, nbr, rc, start, goal
+
+
+@pytest.mark.parametrize('n_agents,n_envs,layout', [
+    (4, 16384, 'lq_'), (4, 16512, 'lg_'), (8, 8192, 'lq_'), (8, 16448, 'lg_'), (16, 4096, 'lq_'), (16, 4128, 'lg_'),
+    (32, 2048, 'lq_'), (32, 1024, 'lg_'), (8, 300, 'lg_'), (5, 600, 'lg_'), (6, 512, 'rollout_kernel<A=6>')])
+def test_goal_reaching_episodes_against_c_oracle(n_agents, n_envs, layout):
+    """The goal-reached branch (reward_of_goal + living, done, no collision, then terminal / auto-reset) and "vertex
+    collision while every agent sits on its goal" (collision wins) at 4..32 agents, in the quad-lane rollout, the
+    pair-layout rollout (LDS and global table), the thread-per-env rollout and the single-step kernel: agents start
+    one move from their goals on an open map and are driven towards them (oracle/goal_scenarios.py -- the family
+    the reference itself stepped for tests/golden/goals_*).  Every recorded step against the C oracle; each pass must
+    actually contain both outcomes."""
+    A, E = n_agents, n_envs
+    grid, nbr, rc, start, goal = _goal_scenario_tables(A, E, 8100 + A)
+    for fail_prob, crit, ocrit, auto, mode, T in (
+            (0.2, OptimizationCriteria.Makespan, mo.MAKESPAN, True, 'streamed', 10),
+            (0.0, OptimizationCriteria.SoC, mo.SOC, False, 'policy', 4),
+            (0.2, OptimizationCriteria.SoC, mo.SOC, True, 'single', 8),
+            (0.2, OptimizationCriteria.Makespan, mo.MAKESPAN, False, 'policy', 10),
+            (0.0, OptimizationCriteria.Makespan, mo.MAKESPAN, True, 'streamed', 3)):
+        env = VecMapfEnv(grid, A, None, None, fail_prob, -1000.0, 100.0, -1.0, crit, seed=31, env_id_offset=5,
+                         start_local=start, goal_local=goal,
+                         kernel='thread_per_env' if layout.startswith('rollout_kernel') else 'auto')
+        co = c_oracle.COracle(nbr, A, start, goal, fail_prob, -1000.0, 100.0, -1.0, ocrit, seed=31, env_id_offset=5)
+        acts, refs = [], []
+        for t in range(T):
+            acts.append(co.greedy_actions(rc))
+            refs.append(co.step(acts[-1], auto_reset=auto))
+        if mode == 'single':
+            got = []
+            for t in range(T):
+                local, reward, done, info = env.step(acts[t], auto_reset=auto)
+                got.append((local, reward, info['prob'], done, info['collision']))
+            assert 'step_kernel' in env.last_kernel('step')
+        else:
+            if mode == 'policy':
+                env.set_policy('greedy')
+            res = env.rollout(T, actions=np.stack(acts) if mode == 'streamed' else None, auto_reset=auto, record=True)
+            got = [(res['local'][t], res['reward'][t], res['prob'][t], res['done'][t], res['collision'][t]) for t in range(T)]
+            assert layout in env.last_kernel('rollout'), env.last_kernel('rollout')
+        goals = clash_on_goal = 0
+        for t in range(T):
+            ref, (local, reward, prob, done, coll) = refs[t], got[t]
+            tag = (A, E, mode, fail_prob, t)
+            assert np.array_equal(local, ref['local']), tag
+            assert np.array_equal(_bits(reward), _bits(ref['reward'])) and np.array_equal(_bits(prob), _bits(ref['prob'])), tag
+            assert np.array_equal(done, ref['done']) and np.array_equal(coll, ref['collision']), tag
+            fresh = ref['was_terminal'] == 0
+            on_goal = (ref['local'] == goal).all(axis=1)
+            goals += int((fresh & (ref['done'] == 1) & (ref['collision'] == 0)).sum())
+            clash_on_goal += int((fresh & (ref['collision'] == 1) & on_goal).sum())
+        assert np.array_equal(env.get_state()[0], co.state)
+        assert goals > 0 and clash_on_goal > 0, (A, E, mode, fail_prob, goals, clash_on_goal)
+        env.close()
+
+
 # ----------------------------------------------------------------------- BASELINE.json full sizes
-def _full_size_check(grid, nbr, A, start, goal, fail_prob, crit, ocrit, n_step, n_roll, kernel='auto'):
+def _full_size_check(grid, nbr, A, start, goal, fail_prob, crit, ocrit, n_step, n_roll, kernel='auto', env_id_offset=0):
     E = start.shape[0]
     env = VecMapfEnv(grid, A, None, None, fail_prob, -1000.0, 100.0, -1.0, crit, seed=42, start_local=start,
-                     goal_local=goal, kernel=kernel)
-    co = c_oracle.COracle(nbr, A, start, goal, fail_prob, -1000.0, 100.0, -1.0, ocrit, seed=42)
-    ids = np.arange(E)
+                     goal_local=goal, kernel=kernel, env_id_offset=env_id_offset)
+    co = c_oracle.COracle(nbr, A, start, goal, fail_prob, -1000.0, 100.0, -1.0, ocrit, seed=42, env_id_offset=env_id_offset)
+    ids = env_id_offset + np.arange(E)
     for t in range(n_step):
         acts = philox.random_actions_np(42, ids, t, A)
         local, reward, done, info = env.step(acts, auto_reset=True)
@@ -422,7 +492,7 @@ def test_config3_room32_8agents_65536_envs():
     """BASELINE configs[2] (the bench workload): room-32-32-4, 8 agents, slip 0.2, 65536 envs; every env of
     every step against the C oracle, both criteria."""
     import bench
-    grid, nbr, start, goal = bench.workload_tables(65536, 0)
+    grid, _, nbr, start, goal = bench.workload_tables(bench.CONFIGS['c3'], 65536, 0)
     # the run below is large enough to take the kernel's tie path (top 16 bits of a uniform equal to those of a
     # threshold -> 53-bit refinement) many times: thresholds 0.8 and 0.9 have top-16-bit values 52428 and 58982
     ties = 0
@@ -432,6 +502,35 @@ def test_config3_room32_8agents_65536_envs():
     assert ties > 50
     assert _full_size_check(grid, nbr, 8, start, goal, 0.2, OptimizationCriteria.Makespan, mo.MAKESPAN, 12, 48) > 0
     assert _full_size_check(grid, nbr, 8, start, goal, 0.2, OptimizationCriteria.SoC, mo.SOC, 4, 24, 'thread_per_env') > 0
+
+
+def test_config4_share_32768_envs_under_default_dispatch(monkeypatch):
+    """BASELINE configs[3]: 262144 room-32-32-4 envs over 8 GPUs -- rank 3's share (global env ids 98304 .. 131071)
+    with the library's DEFAULT layout choice (the suite otherwise lifts the quad-layout threshold, conftest.py)."""
+    import bench
+    from gym_mapf_amd import sharding
+    monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    offset, count = sharding.split_evenly(bench.CONFIGS['c4']['envs'], 3, 8)
+    assert (offset, count) == (98304, 32768)
+    grid, _, nbr, start, goal = bench.workload_tables(bench.CONFIGS['c4'], count, offset)
+    assert _full_size_check(grid, nbr, 8, start, goal, 0.2, OptimizationCriteria.Makespan, mo.MAKESPAN, 6, 40,
+                            env_id_offset=offset) > 0
+
+
+def test_config5_bench_tables_16384_envs_under_default_dispatch(monkeypatch):
+    """BASELINE configs[4] exactly as `bench.py --config c5 --gpus 8` builds rank 5's share (synthetic map, per-env
+    seeded distinct start / goal cells that depend on the global env id only), default layout choice."""
+    import bench
+    from gym_mapf_amd import sharding
+    monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    cfg = bench.CONFIGS['c5']
+    offset, count = sharding.split_evenly(cfg['envs'], 5, 8)
+    grid, _, nbr, start, goal = bench.workload_tables(cfg, count, offset)
+    whole = bench.workload_tables(cfg, 4096 + 64, offset - 64)          # a slice that straddles the shard boundary
+    assert np.array_equal(whole[3][64:], start[:4096]) and np.array_equal(whole[4][64:], goal[:4096])
+    assert all(len(set(r.tolist())) == cfg['agents'] for r in start[:512])
+    assert _full_size_check(grid, nbr, cfg['agents'], start, goal, cfg['fail_prob'], OptimizationCriteria.Makespan,
+                            mo.MAKESPAN, 4, 16, env_id_offset=offset) > 500
 
 
 def test_config5_random64_32agents_16384_envs():

@@ -94,3 +94,40 @@ def test_get_possible_actions_matches_reference():          # mapf_env.py:186-20
                       -1000.0, 100.0, -1, SOC)
         got = env.get_possible_actions(tuple(case['action']))
         assert [[p, list(a)] for p, a in got] == case['result']      # same order, same float64 products
+
+
+def test_single_location_movers_match_reference():          # mapf_env.py:43-75
+    import gym_mapf_amd.envs.mapf_env as me
+    case = G['single_location_movers']
+    grid = MapfGrid(case['lines'])
+    for mover in case['movers']:
+        fn = getattr(me, mover['name'])
+        for loc, expected in mover['results']:
+            assert list(fn(tuple(loc), grid)) == expected, (mover['name'], loc)
+    assert me.ACTION_TO_FUNC['UP'] is me.execute_up and me.ACTION_TO_FUNC['STAY'] is me.execute_stay
+    bumped = me.stay_if_hit_obstacle(lambda loc, m: (0, 2))          # (0, 2) is an obstacle of this map
+    assert bumped((1, 2), grid) == (1, 2) and me.stay_if_hit_obstacle(lambda loc, m: (1, 1))((1, 2), grid) == (1, 1)
+
+
+def test_living_reward_matches_reference():                 # mapf_env.py:436-446 (host arithmetic; device check: -m gpu)
+    for case in G['transition_reward_helpers']:
+        env = MapfEnv(MapfGrid(case['lines']), 3, tuple(map(tuple, case['starts'])), tuple(map(tuple, case['goals'])),
+                      case['fail_prob'], case['rewards'][0], case['rewards'][1], case['rewards'][2],
+                      OptimizationCriteria(case['criteria']))
+        for c in case['cases']:
+            assert env._living_reward(tuple(c['prev_local']), c['action']) == c['living']
+
+
+@pytest.mark.gpu
+def test_transition_reward_helpers_match_reference():       # mapf_env.py:225-235, :378-389 via mapf_transition_rewards
+    import numpy as np
+    for case in G['transition_reward_helpers']:
+        env = MapfEnv(MapfGrid(case['lines']), 3, tuple(map(tuple, case['starts'])), tuple(map(tuple, case['goals'])),
+                      case['fail_prob'], case['rewards'][0], case['rewards'][1], case['rewards'][2],
+                      OptimizationCriteria(case['criteria']))
+        for c in case['cases']:
+            prev, nxt = tuple(c['prev_local']), tuple(c['next_local'])
+            r, d, coll = env.calc_transition_reward_from_local_states(prev, c['action'], nxt)
+            assert np.float64(r).tobytes() == np.float64(c['reward']).tobytes() and (d, coll) == (c['done'], c['collision'])
+            assert env._is_collision_transition_from_local_states(prev, nxt) == c['is_collision']
+        env.close()

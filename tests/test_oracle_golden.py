@@ -76,8 +76,17 @@ def test_trajectories_match_reference(trajectory_set):
         nu = g['uniforms'].shape[0]
         assert np.array_equal(_bits(us[:nu]), _bits(g['uniforms'][:, j]))
         acts = np.stack([philox.random_actions_np(meta['seed'], [env_id], t, A)[0] for t in range(T)])
-        assert np.array_equal(acts, g['actions'][:, j])
+        scripted = 'actions_from' in meta            # goal-seeking sets: only every fifth step is the policy stream
+        if scripted:
+            assert np.array_equal(acts[4::5], g['actions'][4::5, j])
+            acts = g['actions'][:, j]
+        else:
+            assert np.array_equal(acts, g['actions'][:, j])
         for t in range(T):
+            if scripted and t % 5 != 4 and not g['was_terminal'][t, j]:
+                # the recorded action is "towards the goal" of the REFERENCE's state: the greedy policy restated in
+                # the oracle picks the same one from the oracle's state
+                assert env.greedy_actions() == acts[t].tolist(), (meta['name'], int(env_id), t)
             nxt, r, done, coll, prob, was_term = env.step(acts[t].tolist(), us[t].tolist())
             tag = '%s env %d t %d' % (meta['name'], int(env_id), t)
             assert list(nxt) == list(g['next_local'][t, j]), tag
@@ -134,7 +143,7 @@ def test_c_oracle_philox_stream_matches_reference(trajectory_set):
 
 def test_c_oracle_rollout_returns(trajectory_set):
     meta, g = trajectory_set
-    if not meta['auto_reset']:
+    if not meta['auto_reset'] or 'actions_from' in meta:
         return
     T = meta['T']
     for j, env_id in enumerate(g['env_ids'][:6]):

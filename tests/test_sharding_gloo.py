@@ -26,7 +26,7 @@ def _worker(rank, world, port, envs_per_rank, out_dir):
     sys.path.insert(0, ROOT)
     import bench
     offset = sharding.shard_offset(envs_per_rank, rank)
-    _, _, start, goal = bench.workload_tables(envs_per_rank, offset)
+    _, _, _, start, goal = bench.workload_tables(bench.CONFIGS['c3'], envs_per_rank, offset)
     ids = offset + np.arange(envs_per_rank)
     local = torch.from_numpy(ids.astype(np.float64) * 0.5 + start[:, 0])       # a value tied to the global id
     gathered = sharding.gather_returns(local)
@@ -44,7 +44,7 @@ def test_two_rank_sharding_and_gather(tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), per_rank, str(tmp_path)), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
     import bench
-    _, _, start_all, _ = bench.workload_tables(world * per_rank, 0)
+    _, _, _, start_all, _ = bench.workload_tables(bench.CONFIGS['c3'], world * per_rank, 0)
     got = [np.load(tmp_path / ('r%d.npy' % r)) for r in range(world)]
     assert np.array_equal(got[0], got[1])                                       # every rank sees the same gather
     expect = np.arange(world * per_rank) * 0.5 + start_all[:, 0]
@@ -62,3 +62,26 @@ def test_split_evenly_covers_every_env_once():
             assert off == pos
             pos += cnt
     assert sharding.shard_offset(65536, 3) == 196608
+
+
+def test_bench_workloads_depend_on_global_env_ids_only():
+    """bench.py --config c4 / c5 split a fixed env population over the ranks (sharding.split_evenly): whatever the
+    rank count, env e gets the same scenario -- here for the per-env seeded cells of the synthetic C5 workload and
+    the scen-id pattern of C3/C4 -- so results cannot depend on the number of GPUs."""
+    import numpy as np
+    import bench
+    from gym_mapf_amd import sharding
+    c5 = bench.CONFIGS['c5']
+    whole = bench.workload_tables(c5, 9000, 1000)
+    assert whole[3].shape == (9000, 32) and whole[3].max() < len(whole[0].tables()[0])
+    assert all(len(set(r.tolist())) == 32 for r in whole[3][::97]) and all(len(set(r.tolist())) == 32 for r in whole[4][::97])
+    part = bench.workload_tables(c5, 500, 4000)                 # straddles a 4096-id generator chunk
+    assert np.array_equal(part[3], whole[3][3000:3500]) and np.array_equal(part[4], whole[4][3000:3500])
+    assert not np.array_equal(whole[3], whole[4])
+    c4 = bench.CONFIGS['c4']
+    shares = [sharding.split_evenly(c4['envs'], r, 8) for r in range(8)]
+    assert shares[3] == (98304, 32768) and sum(c for _, c in shares) == c4['envs']
+    a = bench.workload_tables(c4, 12, 98304 + 7)
+    b = bench.workload_tables(bench.CONFIGS['c3'], 24, 98304)
+    assert np.array_equal(a[3], b[3][7:19]) and np.array_equal(a[4], b[4][7:19])
+    assert bench.bytes_per_agent_step(8) == 7.25 and bench.bytes_per_agent_step(32) == 5.5625
