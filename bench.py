@@ -78,7 +78,7 @@ def measured_traffic(kernel, n_envs, n_agents, steps_per_launch):
             entries = json.load(f)['kernels']
     except (OSError, KeyError, ValueError):
         return None
-    for entry in entries:
+    for entry in entries if isinstance(entries, list) else ():
         if entry.get('kernel') == kernel and entry.get('n_envs') == n_envs and entry.get('n_agents') == n_agents:
             return entry['fixed_bytes'] + entry['bytes_per_env_step_launch'] * steps_per_launch
     return None

@@ -1,20 +1,36 @@
-// Quad-lane rollout kernel: FOUR agents per lane (two packed cell pairs), Q = A/4 lanes per env.
+// Packed-lane rollout kernel: K = 2 or 4 agents per lane (one or two packed cell pairs), Q = A/K lanes per env.
 //
-// Why a second lane layout: in the pair layout (mapf_lg.hpp, two agents per lane) everything that is per ENV --
-// flag reduction, outcome lookup, totals, reset handling, the hand-over steps of the probability product -- is
-// replicated over the L = A/2 lanes of a group, and that part is about 40 % of a step's vector instructions at
-// A = 8.  Four agents per lane halve the lanes per env, so the replicated part halves, the in-lane half of the
-// pair tests needs no cross-lane move at all, and each lane carries two independent Philox calls / four
-// independent table gathers (more instruction-level parallelism per wave, which matters because the same env
-// count now fills only half as many waves).
+// Why a second lane layout beside mapf_lg.hpp's: there everything that is per ENV -- flag reduction, outcome lookup,
+// totals, reset handling, the hand-over steps of the probability product -- is replicated over the L = A/2 lanes of a
+// group, and that part is about 40 % of a step's vector instructions at A = 8.  Four agents per lane halve the lanes
+// per env, so the replicated part halves, the in-lane half of the pair tests needs no cross-lane move at all, and
+// each lane carries two independent Philox calls / four independent table gathers.
 //
-// Scope: the fused rollout of FULL groups only (A = 4Q, Q in {1, 2, 4, 8, 16}), every block full, move table in
-// LDS -- the bench configuration and its neighbours.  Everything else (odd agent counts, ragged batches, tables
-// beyond the LDS budget, single steps) stays with the pair layout; launch_rollout_lg() picks.  Same stream,
-// same arithmetic, same outputs: the parity tests run both layouts against the oracle.
+// How the step loop is written (measured: tools/microbench/single_wave_latency.hip, profiles/r02_single_wave_costs.txt).
+// At the sizes that matter only one or two waves share a SIMD, and a wave alone issues ONE instruction per ~4.6 cycles
+// whatever its kind or dependences; a scalar branch costs ~12 cycles when it falls through and ~25 when taken, and a
+// vector compare whose mask goes through a scalar AND/OR back into a vector select ~15 on top.  So the loop
+//   * is unrolled by FOUR steps aligned to the slip stream's call granularity: which of a call's four words a step
+//     uses, and whether it refreshes the call, are compile-time facts there (generic steps run before / after the
+//     aligned part of a launch);
+//   * derives the per-env facts with integer arithmetic in vector registers (zero-half-word tests, min / shifts)
+//     and feeds selects from VCC written by the instruction before them -- no scalar mask algebra in the loop;
+//   * keeps the auto-reset / terminal bookkeeping as one integer code = vertex | swap << 1 | off_goal << 2 |
+//     was_terminal << 3 per env that indexes the LDS outcome table and, compared against wave-uniform constants,
+//     drives every select;
+//   * owns the whole LDS image (slip rows at 0, outcome rows at 768, move table at 1024), so every LDS address is a
+//     register plus an immediate offset, and stages the move table with SIX columns per cell (column 5 = STAY again):
+//     an action byte is extracted and clamped by one v_min_u32 with a byte select, a table address is
+//     cell * 96 + action * 16.
+//
+// Scope: the fused rollout of FULL groups only (A = K * Q, Q a power of two <= 16), every block full, move table in
+// LDS -- the bench configurations and their neighbours.  Everything else (odd agent counts, ragged batches, tables
+// beyond the LDS budget, single steps) stays with mapf_lg_rollout.hip; launch_rollout_lg() picks.  Same stream,
+// same arithmetic, same outputs: the parity tests run all layouts against the oracle.
 #include "mapf_lg.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace mapf {
 
@@ -25,9 +41,29 @@ static_assert(sizeof(SlipRow) * 8 + sizeof(OutcomeRow) * 16 <= kLdsReserve, "sta
 
 using gf64 = __attribute__((address_space(1))) double *;
 using gu32 = __attribute__((address_space(1))) uint32_t *;
+using gu16 = __attribute__((address_space(1))) uint16_t *;
 using gu8 = __attribute__((address_space(1))) uint8_t *;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-using gu32x2 = __attribute__((address_space(1))) u32x2 *;
+
+// P packed dwords (2P cells) of a lane, moved as one global access
+template <int P> struct Packed;
+template <> struct Packed<1> {
+    uint32_t v[1];
+    static __device__ __forceinline__ Packed load(const void *p) { return Packed{{*reinterpret_cast<const uint32_t *>(p)}}; }
+    __device__ __forceinline__ void store(void *p) const { *reinterpret_cast<uint32_t *>(p) = v[0]; }
+    __device__ __forceinline__ void store_global(gu16 p) const { *(gu32)p = v[0]; }
+};
+template <> struct Packed<2> {
+    uint32_t v[2];
+    static __device__ __forceinline__ Packed load(const void *p) {
+        const u32x2 w = *reinterpret_cast<const u32x2 *>(p);
+        return Packed{{w.x, w.y}};
+    }
+    __device__ __forceinline__ void store(void *p) const { *reinterpret_cast<u32x2 *>(p) = u32x2{v[0], v[1]}; }
+    __device__ __forceinline__ void store_global(gu16 p) const {
+        *(__attribute__((address_space(1))) u32x2 *)p = u32x2{v[0], v[1]};
+    }
+};
 
 // sampled list slot of one agent from the top 16 bits of its uniform (see slip_move_hi): idx, its probability, and
 // the tie distance (0 <=> hi equals a threshold -> exact path)
@@ -57,83 +93,115 @@ __device__ __forceinline__ void pair_apply_same(uint32_t pk_prev, uint32_t pk_ne
     }
 }
 
-// full rotations 1 .. Q/2-1: my two pairs against both pairs of group position g + S
-template <int Q, int S, bool DUP, bool MOVES>
-struct QuadRounds {
-    static __device__ __forceinline__ void run(const LaneCtx<Q> &x, uint32_t ca, uint32_t cb, uint32_t na, uint32_t nb,
+// full rotations 1 .. Q/2-1: my pairs against every pair of group position g + S
+template <int Q, int P, int S, bool DUP, bool MOVES>
+struct PackedRounds {
+    static __device__ __forceinline__ void run(const LaneCtx<Q> &x, const uint32_t (&c)[P], const uint32_t (&n)[P],
                                                PairAcc<true> &acc) {
         if constexpr (S <= Q / 2 - 1) {
-            const uint32_t oa_c = group_rot<Q, S>(ca, x), ob_c = group_rot<Q, S>(cb, x);
-            const uint32_t oa_n = MOVES ? group_rot<Q, S>(na, x) : 0u, ob_n = MOVES ? group_rot<Q, S>(nb, x) : 0u;
-            pair_apply_packed<DUP, MOVES>(ca, na, oa_c, oa_n, acc);
-            pair_apply_packed<DUP, MOVES>(ca, na, ob_c, ob_n, acc);
-            pair_apply_packed<DUP, MOVES>(cb, nb, oa_c, oa_n, acc);
-            pair_apply_packed<DUP, MOVES>(cb, nb, ob_c, ob_n, acc);
-            QuadRounds<Q, S + 1, DUP, MOVES>::run(x, ca, cb, na, nb, acc);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const uint32_t oc = group_rot<Q, S>(c[j], x);
+                const uint32_t on = MOVES ? group_rot<Q, S>(n[j], x) : 0u;
+#pragma unroll
+                for (int i = 0; i < P; ++i) pair_apply_packed<DUP, MOVES>(c[i], n[i], oc, on, acc);
+            }
+            PackedRounds<Q, P, S + 1, DUP, MOVES>::run(x, c, n, acc);
         }
     }
 };
 
-// all agent pairs of the env.  ca/cb: my packed current cells (agents 4g,4g+1 / 4g+2,4g+3), na/nb: next cells.
-template <int Q, bool DUP, bool MOVES>
-__device__ __forceinline__ PairAcc<true> quad_pair_tests(const LaneCtx<Q> &x, uint32_t ca, uint32_t cb, uint32_t na,
-                                                         uint32_t nb) {
+// all agent pairs of the env.  c: my packed current cells (agents K*g .. K*g+K-1, two per dword), n: next cells.
+template <int Q, int P, bool DUP, bool MOVES>
+__device__ __forceinline__ PairAcc<true> packed_pair_tests(const LaneCtx<Q> &x, const uint32_t (&c)[P], const uint32_t (&n)[P]) {
     PairAcc<true> acc;
-    const uint32_t ca_sw = swap_halves(ca), cb_sw = swap_halves(cb);
-    const uint32_t na_sw = MOVES ? swap_halves(na) : 0u, nb_sw = MOVES ? swap_halves(nb) : 0u;
-    // inside each pair (both half-words carry the same test), then pair A against pair B
-    if (DUP) acc.dup = pk_min_u16(ca ^ ca_sw, cb ^ cb_sw);
-    if (MOVES) {
-        acc.vertex = pk_min_u16(na ^ na_sw, nb ^ nb_sw);
-        acc.swap = pk_min_u16((na ^ ca_sw) | (ca ^ na_sw), (nb ^ cb_sw) | (cb ^ nb_sw));
+    uint32_t csw[P], nsw[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        csw[i] = swap_halves(c[i]);
+        nsw[i] = MOVES ? swap_halves(n[i]) : 0u;
     }
-    pair_apply_packed<DUP, MOVES>(ca, na, cb, nb, acc);
+    // inside each pair (both half-words carry the same test) ...
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const uint32_t d = c[i] ^ csw[i], v = n[i] ^ nsw[i], w = (n[i] ^ csw[i]) | (c[i] ^ nsw[i]);
+        if (DUP) acc.dup = i == 0 ? d : pk_min_u16(acc.dup, d);
+        if (MOVES) {
+            acc.vertex = i == 0 ? v : pk_min_u16(acc.vertex, v);
+            acc.swap = i == 0 ? w : pk_min_u16(acc.swap, w);
+        }
+    }
+    // ... then pair against pair inside the lane
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+#pragma unroll
+        for (int j = i + 1; j < P; ++j) pair_apply_packed<DUP, MOVES>(c[i], n[i], c[j], n[j], acc);
     if constexpr (Q >= 2) {
-        QuadRounds<Q, 1, DUP, MOVES>::run(x, ca, cb, na, nb, acc);
-        // half rotation: lane g meets lane g + Q/2 from both sides, so the two lanes split the 16 agent pairs --
+        PackedRounds<Q, P, 1, DUP, MOVES>::run(x, c, n, acc);
+        // half rotation: lane g meets lane g + Q/2 from both sides, so the two lanes split the agent pairs --
         // lower-half lanes offer their pairs half-swapped; whoever receives runs only the same-half-word tests
         const bool lower = x.g < uint32_t(Q / 2);
-        const uint32_t oa_c = group_rot<Q, (Q + 1) / 2>(lower ? ca_sw : ca, x), ob_c = group_rot<Q, (Q + 1) / 2>(lower ? cb_sw : cb, x);
-        const uint32_t oa_n = MOVES ? group_rot<Q, (Q + 1) / 2>(lower ? na_sw : na, x) : 0u;
-        const uint32_t ob_n = MOVES ? group_rot<Q, (Q + 1) / 2>(lower ? nb_sw : nb, x) : 0u;
-        pair_apply_same<DUP, MOVES>(ca, na, oa_c, oa_n, acc);
-        pair_apply_same<DUP, MOVES>(ca, na, ob_c, ob_n, acc);
-        pair_apply_same<DUP, MOVES>(cb, nb, oa_c, oa_n, acc);
-        pair_apply_same<DUP, MOVES>(cb, nb, ob_c, ob_n, acc);
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const uint32_t oc = group_rot<Q, Q / 2>(lower ? csw[j] : c[j], x);
+            const uint32_t on = MOVES ? group_rot<Q, Q / 2>(lower ? nsw[j] : n[j], x) : 0u;
+#pragma unroll
+            for (int i = 0; i < P; ++i) pair_apply_same<DUP, MOVES>(c[i], n[i], oc, on, acc);
+        }
     }
     return acc;
 }
 
+// non-zero <=> one of the two half-words of a is zero (the classic "has a zero byte" test on 16-bit fields): the only
+// bits that can be set are 15 and 31
+__device__ __forceinline__ uint32_t zero_half(uint32_t a) {
+    return (a - 0x00010001u) & ~a & 0x80008000u;
+}
+
 // MapfEnv.is_terminal (mapf_env.py:210-223) of the group's env, in every lane
-template <int Q>
-__device__ __forceinline__ bool quad_is_terminal(const LaneCtx<Q> &x, uint32_t ca, uint32_t cb, uint32_t ga, uint32_t gb) {
-    const PairAcc<true> acc = quad_pair_tests<Q, true, false>(x, ca, cb, 0u, 0u);
-    const bool off_goal = ca != ga || cb != gb;
+template <int Q, int P>
+__device__ __forceinline__ bool packed_is_terminal(const LaneCtx<Q> &x, const uint32_t (&c)[P], const uint32_t (&g)[P]) {
+    const uint32_t none[P] = {};
+    const PairAcc<true> acc = packed_pair_tests<Q, P, true, false>(x, c, none);
+    bool off_goal = false;
+#pragma unroll
+    for (int i = 0; i < P; ++i) off_goal |= c[i] != g[i];
     const uint32_t flags = group_reduce<Q, false>((PairAcc<true>::hit(acc.dup) ? 1u : 0u) | (off_goal ? 2u : 0u), x);
     return (flags & 1u) != 0u || (flags & 2u) == 0u;
 }
 
 // ordered product over agents 0..A-1: every lane continues the product handed over by the lane before it (see
 // prob_product in mapf_lg.hpp); the total ends in lane Q-1
-template <int Q>
-__device__ __forceinline__ double quad_prob_product(double q0, double q1, double q2, double q3) {
-    double run = __dmul_rn(__dmul_rn(__dmul_rn(q0, q1), q2), q3);
+template <int Q, int K>
+__device__ __forceinline__ double packed_prob_product(const double (&q)[K]) {
+    double run = q[0];
+#pragma unroll
+    for (int i = 1; i < K; ++i) run = __dmul_rn(run, q[i]);
 #pragma unroll
     for (int k = 1; k < Q; ++k) {
         const uint32_t lo = from_prev_lane<Q>(uint32_t(__double2loint(run)));
         const uint32_t hi = from_prev_lane<Q>(uint32_t(__double2hiint(run)));
-        run = __dmul_rn(__dmul_rn(__dmul_rn(__dmul_rn(__hiloint2double(int(hi), int(lo)), q0), q1), q2), q3);
+        run = __hiloint2double(int(hi), int(lo));
+#pragma unroll
+        for (int i = 0; i < K; ++i) run = __dmul_rn(run, q[i]);
     }
     return run;
 }
 
 // RECORD: all five trajectory arrays are written every step; STREAM: actions come from memory, else from the
-// in-kernel policy stream.  Loop structure, software pipeline and store scheme as lg_rollout_kernel<DENSE>.
-template <int Q, bool RECORD, bool STREAM>
+// in-kernel policy.  Memory pipeline and store scheme as lg_rollout_kernel<DENSE>.
+constexpr uint32_t kSlipAt = 0, kOutcomeAt = sizeof(SlipRow) * 8, kMoveAt = kLdsReserve, kMoveCols = 6;
+static_assert(kOutcomeAt + sizeof(OutcomeRow) * 16 <= kMoveAt, "LDS image: slip rows, outcome rows, then the move table");
+
+template <int Q, int K, bool RECORD, bool STREAM, bool SOC>
 __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
-    __shared__ SlipRow slip[8];
-    __shared__ OutcomeRow outcome[16];
-    extern __shared__ __attribute__((aligned(16))) MoveEntry lds_mv[];
+    constexpr int P = K / 2;   // packed dwords per lane
+    static_assert(K == 2 || K == 4, "two or four agents per lane");
+    // the kernel's only LDS object, so it sits at LDS address 0 and every offset below is an instruction immediate
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_image[];
+    SlipRow *slip = reinterpret_cast<SlipRow *>(lds_image + kSlipAt);
+    OutcomeRow *outcome = reinterpret_cast<OutcomeRow *>(lds_image + kOutcomeAt);
+    MoveEntry *lds_mv = reinterpret_cast<MoveEntry *>(lds_image + kMoveAt);
     LaneCtx<Q> x;
     x.lane = threadIdx.x & 63u;
     x.g = x.lane & uint32_t(Q - 1);
@@ -141,23 +209,28 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
     x.e = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * uint32_t(64 / Q) + x.lane / uint32_t(Q);
     x.v0 = x.v1 = true;
     const uint32_t e = x.e;
-    const uint32_t lane_cell = e * n_agents + 4u * x.g;             // my first agent's element index
-    const uint32_t fixed_cell = 4u * x.g;                           // ... in a broadcast row
+    const uint32_t lane_cell = e * n_agents + uint32_t(K) * x.g;    // my first agent's element index
+    const uint32_t fixed_cell = uint32_t(K) * x.g;                  // ... in a broadcast row
 
-    const u32x2 cells = *reinterpret_cast<const u32x2 *>(at(p.state, lane_cell));
-    const u32x2 gl = *reinterpret_cast<const u32x2 *>(at(p.goal, p.goal_broadcast ? fixed_cell : lane_cell));
-    u32x2 sc = {0u, 0u};
-    if (p.auto_reset) sc = *reinterpret_cast<const u32x2 *>(at(p.start, p.start_broadcast ? fixed_cell : lane_cell));
-    uint32_t ca = cells.x, cb = cells.y;                                   // packed current cells
-    const uint32_t ga = gl.x, gb = gl.y, sa = sc.x, sb = sc.y;
-    {   // move table -> LDS, batches of four independent loads per thread
-        const uint32_t n_words = p.c.n_cells * 5u;
+    uint32_t c[P], g[P], st[P];
+    {
+        const Packed<P> cells = Packed<P>::load(at(p.state, lane_cell));
+        const Packed<P> gl = Packed<P>::load(at(p.goal, p.goal_broadcast ? fixed_cell : lane_cell));
+        Packed<P> sc{};
+        if (p.auto_reset) sc = Packed<P>::load(at(p.start, p.start_broadcast ? fixed_cell : lane_cell));
+#pragma unroll
+        for (int i = 0; i < P; ++i) { c[i] = cells.v[i]; g[i] = gl.v[i]; st[i] = sc.v[i]; }
+    }
+    {   // move table -> LDS with six columns per cell (0..4 = the actions, 5 = STAY again: where out-of-range action
+        // bytes are clamped to), batches of four independent loads per thread
+        const uint32_t n_words = p.c.n_cells * kMoveCols;
         for (uint32_t w0 = threadIdx.x; w0 < n_words; w0 += 4u * blockDim.x) {
             MoveEntry part[4];
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) {
-                const uint32_t w = w0 + k * blockDim.x;
-                part[k] = p.mv[w < n_words ? w : n_words - 1u];
+                const uint32_t w = min(w0 + k * blockDim.x, n_words - 1u);
+                const uint32_t cell = w / kMoveCols, col = w - cell * kMoveCols;
+                part[k] = p.mv[cell * 5u + (col == 5u ? 0u : col)];
             }
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) {
@@ -169,8 +242,12 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
     stage_outcome_table(p.c, outcome);
     stage_slip_table(p.slip, slip);   // ends with __syncthreads()
 
-    uint32_t terminal = quad_is_terminal<Q>(x, ca, cb, ga, gb) ? 1u : 0u;
-    const uint32_t start_terminal = (p.auto_reset && quad_is_terminal<Q>(x, sa, sb, ga, gb)) ? 1u : 0u;
+    uint32_t terminal = packed_is_terminal<Q, P>(x, c, g) ? 1u : 0u;
+    const uint32_t start_terminal = (p.auto_reset && packed_is_terminal<Q, P>(x, st, g)) ? 1u : 0u;
+    // Every select of the reset logic compares the env's integer code against a wave-uniform constant:
+    // (code ^ 4) > 0 <=> the step ended the episode (or the env was terminal already); with auto-reset off the
+    // threshold is unreachable, so "reset" never fires and the state simply stays where the step left it.
+    const uint32_t reset_above = p.auto_reset ? 0u : 0xFFFFFFFFu;
 
     const bool leader = x.g == 0u, tail = x.g == uint32_t(Q - 1);
     gf64 ret_p = (gf64)(p.out_returns ? at(p.out_returns, e) : nullptr);
@@ -189,7 +266,7 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
     const uint32_t flag_shift = (x.g & 1u) * 8u;
     gf64 wide_lane = nullptr, prob_lane = nullptr;
     gu8 narrow_lane = nullptr, coll_lane = nullptr;
-    gu32x2 rec_lane = nullptr;
+    gu16 rec_lane = nullptr;
     if (RECORD) {
         gf64 reward_lane = (gf64)p.rec_reward + e;
         prob_lane = (gf64)p.rec_prob + e;
@@ -198,46 +275,64 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         // Q >= 2: the last lane writes prob, the others reward; even lanes write done, odd lanes collision
         wide_lane = (Q > 1 && tail) ? prob_lane : reward_lane;
         narrow_lane = (Q > 1 && odd) ? coll_lane : done_lane;
-        rec_lane = (gu32x2)((__attribute__((address_space(1))) uint16_t *)p.rec_local + lane_cell);
+        rec_lane = (gu16)p.rec_local + lane_cell;
     }
     asm volatile("" : "+v"(wide_lane), "+v"(prob_lane), "+v"(narrow_lane), "+v"(coll_lane), "+v"(rec_lane));
     const uint8_t *act_lane = STREAM ? p.actions + lane_cell : nullptr;
 
-    // Action words are fetched TWO steps ahead (one step is shorter than a loaded HBM round trip): two registers take
-    // turns -- even steps use raw_even, odd steps raw_odd, each reloading its own register for two steps later --
-    // so the loop is unrolled by two (rotating one register through a move would be a use, i.e. a wait).
+    // Action words are fetched TWO steps ahead (one step is shorter than a loaded HBM round trip).  Invariant at the top
+    // of step s: raw_even holds row s, raw_odd row s+1, act_lane points at row min(s+1, last).  A step consumes the
+    // register that holds its row and reloads THAT register with row s+2, so in the unrolled part of the loop the two
+    // registers simply take turns (rotating a register through a move would be a use, i.e. a wait); a generic step
+    // swaps them afterwards.
     const uint32_t last_row = p.n_steps ? p.n_steps - 1u : 0u;
+    auto load_raw = [&]() __attribute__((always_inline)) {
+        return K == 4 ? *reinterpret_cast<const uint32_t *>(act_lane) : uint32_t(*reinterpret_cast<const uint16_t *>(act_lane));
+    };
     uint32_t raw_even = 0u, raw_odd = 0u;
     if (STREAM && p.n_steps > 0) {
-        raw_even = *reinterpret_cast<const uint32_t *>(act_lane);
+        raw_even = load_raw();
         act_lane += last_row >= 1u ? step_cells : 0u;             // clamped, not guarded: late rows are re-read
-        raw_odd = *reinterpret_cast<const uint32_t *>(act_lane);
+        raw_odd = load_raw();
     }
     asm volatile("" : "+v"(raw_even), "+v"(raw_odd));   // consumed here: the loop's waits are the back edge's counted ones
-    Words4 rng_a{0u, 0u, 0u, 0u}, rng_b{0u, 0u, 0u, 0u};
+    Words4 rng[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) rng[i] = Words4{0u, 0u, 0u, 0u};
     // "Pending" = what is left of step s-1 when step s begins: its probability chain, its totals and its trajectory
     // stores.  They are finished at the top of step s, right after step s's table reads have been issued, so the
     // chain of dependent float64 multiplies runs while those reads are in flight, and the outcome row / probability
     // reads of step s-1 (requested in step s-1, consumed only here) never stall anything.  Step 0 finishes a dummy:
     // reward -0.0 leaves the running return unchanged bit for bit, the stores hit row 0 and are overwritten by step 1.
-    double pq0 = 0.0, pq1 = 0.0, pq2 = 0.0, pq3 = 0.0, p_reward = -0.0;
-    uint32_t p_a = 0u, p_b = 0u, p_status = 0u;
+    double pq[K], p_reward = -0.0;
+#pragma unroll
+    for (int i = 0; i < K; ++i) pq[i] = 0.0;
+    uint32_t p_cells[P], p_status = 0u;
+#pragma unroll
+    for (int i = 0; i < P; ++i) p_cells[i] = 0u;
 
 #ifdef MAPF_STAMPS
-    StampCtx st{};
+    StampCtx st_{};
+    StampCtx &st = st_;
     { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); st.last = _t; }
 #endif
     auto finish_pending = [&]() __attribute__((always_inline)) {
         // opaque from here on: otherwise the optimiser moves these consumers back to where the values are produced
         // (the end of the previous step), which is exactly the stall this pipeline removes
         asm volatile("" : "+v"(p_reward), "+v"(p_status));
-        if (RECORD) asm volatile("" : "+v"(pq0), "+v"(pq1), "+v"(pq2), "+v"(pq3));
+        if (RECORD) {
+#pragma unroll
+            for (int i = 0; i < K; ++i) asm volatile("" : "+v"(pq[i]));
+        }
         ret = __dadd_rn(ret, p_reward);
         episodes += p_status & 0xFFu;                          // byte 0 done, byte 1 collision
         collisions += (p_status >> 8) & 0xFFu;
         if (RECORD) {
-            const double prob = quad_prob_product<Q>(pq0, pq1, pq2, pq3);   // total in the last lane
-            *rec_lane = u32x2{p_a, p_b};
+            const double prob = packed_prob_product<Q, K>(pq);   // total in the last lane
+            Packed<P> out;
+#pragma unroll
+            for (int i = 0; i < P; ++i) out.v[i] = p_cells[i];
+            out.store_global(rec_lane);
             *wide_lane = (Q > 1 && tail) ? prob : p_reward;
             *narrow_lane = uint8_t(Q > 1 ? p_status >> flag_shift : p_status);
             if (Q == 1) {
@@ -247,128 +342,190 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         }
     };
 
-    uint32_t goal_rc[4] = {0u, 0u, 0u, 0u};   // greedy policy: my agents' goal coordinates
-    if (!STREAM && p.policy_cells) {
-        const uint32_t goal_cell[4] = {ga & 0xFFFFu, ga >> 16, gb & 0xFFFFu, gb >> 16};
+    uint32_t goal_rc[K];   // greedy policy: my agents' goal coordinates
 #pragma unroll
-        for (int k = 0; k < 4; ++k) goal_rc[k] = p.policy_cells[goal_cell[k]].x;
+    for (int k = 0; k < K; ++k) goal_rc[k] = 0u;
+    if (!STREAM && p.policy_cells) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) goal_rc[k] = p.policy_cells[(k & 1) ? g[k / 2] >> 16 : g[k / 2] & 0xFFFFu].x;
     }
 
-    auto one_step = [&](const uint32_t s, uint32_t &raw) __attribute__((always_inline)) {
+    // One step.  W = which word of the slip calls this step uses (t & 3) when that is a compile-time fact, -1 = generic
+    // (word picked at run time, call refreshed when t is a multiple of four).  FIRST = the launch's first step: nothing
+    // is pending yet and the slip call is refreshed whatever t is.  TAIL = the action rows run out within two steps, so
+    // the prefetch address is clamped.  `raw` is the register that holds this step's action word.
+    auto one_step = [&](const uint32_t s, uint32_t &raw, auto w_tag, auto first_tag, auto tail_tag) __attribute__((always_inline)) {
+        constexpr int W = decltype(w_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value, TAIL = decltype(tail_tag)::value;
         const uint64_t t = p.t + s;
-        uint32_t act[4];
+        uint32_t cur[K], act[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) cur[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu;
         if (STREAM) {
-            act[0] = raw & 0xFFu; act[1] = (raw >> 8) & 0xFFu; act[2] = (raw >> 16) & 0xFFu; act[3] = raw >> 24;
-            asm volatile("" : "+v"(act[0]), "+v"(act[1]), "+v"(act[2]), "+v"(act[3]));   // the wait for `raw` sits here
-            act_lane += (s + 2u <= last_row) ? step_cells : 0u;   // row min(s + 2, last)
-            raw = *reinterpret_cast<const uint32_t *>(act_lane);
+#pragma unroll
+            for (int k = 0; k < K; ++k) act[k] = min((raw >> (8 * k)) & 0xFFu, 5u);   // extract + clamp: one v_min_u32 (byte select)
+#pragma unroll
+            for (int k = 0; k < K; ++k) asm volatile("" : "+v"(act[k]));   // the wait for `raw` sits here
+            act_lane += (!TAIL || s + 2u <= last_row) ? step_cells : 0u;   // row min(s + 2, last)
+            raw = load_raw();
         } else if (p.policy_cells) {   // greedy policy
-            const uint32_t at_cell[4] = {ca & 0xFFFFu, ca >> 16, cb & 0xFFFFu, cb >> 16};
 #pragma unroll
-            for (int k = 0; k < 4; ++k) act[k] = greedy_action(p.policy_cells, p.c.n_cells, at_cell[k], goal_rc[k]);
-        } else {   // policy stream: one Philox call covers exactly my agents 4g .. 4g+3
+            for (int k = 0; k < K; ++k) act[k] = greedy_action(p.policy_cells, p.c.n_cells, cur[k], goal_rc[k]);
+        } else {   // policy stream: one Philox call covers agents 4j .. 4j+3
             uint32_t w[4];
-            const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | (x.g << 24);
+            const uint32_t quad = K == 4 ? x.g : x.g >> 1;
+            const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | (quad << 24);
             philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, p.c.pol_lo, p.c.pol_hi, w);
+            if (K == 4) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) act[k] = __umulhi(w[k], 5u);
+                for (int k = 0; k < K; ++k) act[k] = __umulhi(w[k], 5u);
+            } else {
+                const bool upper = (x.g & 1u) != 0u;
+                act[0] = __umulhi(upper ? w[2] : w[0], 5u);
+                act[1] = __umulhi(upper ? w[3] : w[1], 5u);
+            }
         }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) act[k] = act[k] > 4u ? 0u : act[k];
 
-        // --- my four agents' table rows: requested first ...
-        const uint32_t cur[4] = {ca & 0xFFFFu, ca >> 16, cb & 0xFFFFu, cb >> 16};
-        MoveEntry entry[4];
+        // --- my agents' table rows (cell * 96 + action * 16, the table's LDS offset is an immediate): requested first ...
+        MoveEntry entry[K];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) entry[k] = move_entry<false>(lds_mv, p.c.n_cells, cur[k], act[k]);
+        for (int k = 0; k < K; ++k) {
+            const uint32_t byte_off = __umul24(cur[k], kMoveCols * uint32_t(sizeof(MoveEntry))) + act[k] * uint32_t(sizeof(MoveEntry));
+            entry[k] = *reinterpret_cast<const MoveEntry *>(lds_image + kMoveAt + byte_off);
+        }
         STAMP(0);   // loop top: action fetch / policy, table read issue
         // --- ... then the previous step is finished while they are in flight
-        finish_pending();
-        if (RECORD && s > 0) {
-            rec_lane = (gu32x2)((__attribute__((address_space(1))) uint16_t *)rec_lane + step_cells);
-            wide_lane += step_rows;
-            narrow_lane += step_rows;
-            if (Q == 1) { prob_lane += step_rows; coll_lane += step_rows; }
+        if (!FIRST) {
+            finish_pending();
+            if (RECORD) {
+                rec_lane += step_cells;
+                wide_lane += step_rows;
+                narrow_lane += step_rows;
+                if (Q == 1) { prob_lane += step_rows; coll_lane += step_rows; }
+            }
         }
         STAMP(1);   // previous step: probability chain, totals, trajectory stores
-        // one slip-stream call per pair serves four steps: refresh when t is a multiple of 4 (and at the first step)
-        if (p.c.need_rng && ((t & 3u) == 0u || s == 0u)) {
-            slip_words_x2(p.c, env_id, t >> 2, 2u * x.g, 2u * x.g + 1u, rng_a, rng_b);
+        // one slip-stream call per pair serves four steps
+        const bool refresh = FIRST || W == 0 || (W < 0 && (t & 3u) == 0u);
+        if (refresh && p.c.need_rng) {
+            if constexpr (P == 2) slip_words_x2(p.c, env_id, t >> 2, 2u * x.g, 2u * x.g + 1u, rng[0], rng[1]);
+            else rng[0] = slip_words(p.c, env_id, t >> 2, x.g, 0u, 0u);
         }
         STAMP(2);   // slip Philox (1 step in 4)
-        const uint32_t word_a = step_word(rng_a, t), word_b = step_word(rng_b, t);
-        const uint32_t hi[4] = {word_a & 0xFFFFu, word_a >> 16, word_b & 0xFFFFu, word_b >> 16};
-        double q[4];
-        uint32_t idx[4], tie[4];
+        uint32_t hi[K];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) idx[k] = sample_slot(slip, entry[k], hi[k], q[k], tie[k]);
-        uint32_t na = cell_lo(entry[0], idx[0]) | (cell_lo(entry[1], idx[1]) << 16);   // one v_lshl_or_b32 per pair
-        uint32_t nb = cell_lo(entry[2], idx[2]) | (cell_lo(entry[3], idx[3]) << 16);
-        if (__builtin_expect(__any(min(min(tie[0], tie[1]), min(tie[2], tie[3])) == 0u && p.c.need_rng), 0)) {
+        for (int i = 0; i < P; ++i) {
+            const uint32_t word = W == 0 ? rng[i].w0 : W == 1 ? rng[i].w1 : W == 2 ? rng[i].w2 : W == 3 ? rng[i].w3 : step_word(rng[i], t);
+            hi[2 * i] = word & 0xFFFFu;
+            hi[2 * i + 1] = word >> 16;
+        }
+        double q[K];
+        uint32_t idx[K], tie[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) idx[k] = sample_slot(slip, entry[k], hi[k], q[k], tie[k]);
+        uint32_t n[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) n[i] = cell_lo(entry[2 * i], idx[2 * i]) | (cell_lo(entry[2 * i + 1], idx[2 * i + 1]) << 16);
+        uint32_t tie_all = tie[0];
+#pragma unroll
+        for (int k = 1; k < K; ++k) tie_all = min(tie_all, tie[k]);
+        // (without slip the words stay zero and every threshold is 65535: no tie can fire, so need_rng is not asked here)
+        if (__builtin_expect(__any(tie_all == 0u), 0)) {
             // a top-16-bit tie somewhere in the wave: redo with all 53 bits
-            uint32_t nx[4];
+            uint32_t nx[K];
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                slip_move<false>(slip, entry[k], refine_mantissa(p.c, env_id, t, 4u * x.g + uint32_t(k), hi[k]), 0.0, nx[k], q[k]);
-            na = nx[0] | (nx[1] << 16);
-            nb = nx[2] | (nx[3] << 16);
+            for (int k = 0; k < K; ++k)
+                slip_move<false>(slip, entry[k], refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi[k]), 0.0, nx[k], q[k]);
+#pragma unroll
+            for (int i = 0; i < P; ++i) n[i] = nx[2 * i] | (nx[2 * i + 1] << 16);
         }
         STAMP(3);   // sampling (table wait, thresholds, probability read issue)
 
-        // --- pair tests, per-env facts
-        const PairAcc<true> acc = quad_pair_tests<Q, false, true>(x, ca, cb, na, nb);
+        // --- pair tests, then the per-env facts as ONE integer: f = vertex | swap << 1 | off_goal << 2
+        const PairAcc<true> acc = packed_pair_tests<Q, P, false, true>(x, c, n);
         STAMP(4);   // pair tests
-        const bool off_goal_next = na != ga || nb != gb;
-        uint32_t flags = (PairAcc<true>::hit(acc.vertex) ? 1u : 0u) | (PairAcc<true>::hit(acc.swap) ? 2u : 0u) | (off_goal_next ? 4u : 0u);
+        uint32_t away = n[0] ^ g[0];
+#pragma unroll
+        for (int i = 1; i < P; ++i) away |= n[i] ^ g[i];
+        asm volatile("" : "+v"(away));   // stays an integer: as a compare it would travel through scalar masks
+        // zero_half() leaves bits 15 / 31: vertex -> bits 0 / 16, swap -> bits 1 / 17; both halves folded onto bits 0, 1
+        uint32_t bits = (zero_half(acc.vertex) >> 15) | (zero_half(acc.swap) >> 14);
+        bits |= bits >> 16;
+        uint32_t flags = (min(away, 1u) << 2) | bits;
         flags = group_reduce<Q, false>(flags, x);
-        const uint32_t f = flags & 7u;
+        const uint32_t code = (flags & 7u) | (terminal << 3);   // terminal is 0 / 1
         STAMP(5);   // flags + group reduce
 
         // --- outcome: the row (status for both criteria, reward for Makespan) is only REQUESTED here; everything the
-        // next step's table address depends on is re-derived from f without waiting for it
-        const bool was_terminal = terminal != 0u;
-        const OutcomeRow *row = &outcome[f | (terminal << 3)];   // terminal is 0 / 1
+        // next step's table address depends on is derived from `code` without waiting for it
+        const OutcomeRow *row = reinterpret_cast<const OutcomeRow *>(lds_image + kOutcomeAt + code * uint32_t(sizeof(OutcomeRow)));
         const uint32_t row_status = row->status;
-        const double row_reward = row->reward;                 // two plain reads, both unconditional
-        double soc_reward = 0.0;
-        if (p.c.criteria != 0u) {
+        double reward = row->reward;
+        const bool was_terminal = code > 7u;
+        if (SOC) {
             // _living_reward: mapf_env.py:436-446
-            const uint32_t goal[4] = {ga & 0xFFFFu, ga >> 16, gb & 0xFFFFu, gb >> 16};
             uint32_t mine = 0u;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) mine += (cur[k] == goal[k] && act[k] == 0u) ? 1u : 0u;
+            for (int k = 0; k < K; ++k) {
+                const uint32_t goal_k = (k & 1) ? g[k / 2] >> 16 : g[k / 2] & 0xFFFFu;
+                mine += (cur[k] == goal_k && (act[k] == 0u || act[k] == 5u)) ? 1u : 0u;
+            }
             const int stayed = int(group_reduce<Q, true>(mine, x));
             const double living = __dmul_rn(double(int(n_agents) - stayed), p.c.r_living);
+            const uint32_t f = code & 7u;
             const bool coll = (f & 3u) != 0u, goal_next = (f & 4u) == 0u;
             const double r = coll ? __dadd_rn(p.c.r_clash, living) : (goal_next ? __dadd_rn(p.c.r_goal, living) : living);
-            soc_reward = was_terminal ? 0.0 : r;
+            reward = was_terminal ? 0.0 : r;
         }
-        const double reward = p.c.criteria != 0u ? soc_reward : row_reward;
-        if (was_terminal) { na = ca; nb = cb; }                // mapf_env.py:239-240 -- (s, 0, True, {"prob": 0})
+        // a step from a terminal state changes nothing: mapf_env.py:239-240 -- (s, 0, True, {"prob": 0})
+#pragma unroll
+        for (int i = 0; i < P; ++i) n[i] = was_terminal ? c[i] : n[i];
         p_reward = reward;
         p_status = row_status;
-        p_a = na; p_b = nb;
+#pragma unroll
+        for (int i = 0; i < P; ++i) p_cells[i] = n[i];
         if (RECORD) {                                          // a zero factor makes the whole product +0.0
-            pq0 = was_terminal ? 0.0 : q[0];
-            pq1 = q[1]; pq2 = q[2]; pq3 = q[3];
+            pq[0] = was_terminal ? 0.0 : q[0];
+#pragma unroll
+            for (int k = 1; k < K; ++k) pq[k] = q[k];
         }
         STAMP(6);   // outcome request, SoC living reward
-        // MapfEnv.reset(): start cells, no reseed.  Every f except "off goal, no collision" ends the episode; the
-        // returned state is terminal after a vertex collision or on goal (mapf_env.py:210-223), a swap alone is not
-        const bool done = f != 4u || was_terminal;
-        const bool next_terminal = ((f ^ 4u) & 5u) != 0u || was_terminal;
-        const bool back = p.auto_reset && done;
-        ca = back ? sa : na;
-        cb = back ? sb : nb;
-        terminal = back ? start_terminal : (next_terminal ? 1u : 0u);
+        // MapfEnv.reset(): start cells, no reseed.  Every code except "off goal, no collision, not terminal" (= 4) ends
+        // the episode; the returned state is terminal after a vertex collision or on goal (mapf_env.py:210-223), a swap
+        // alone is not: bits 0 (vertex), 2 (flipped: on goal) and 3 (was terminal) of code ^ 4
+        const uint32_t ended = code ^ 4u;
+        const bool back = ended > reset_above;                 // never with auto-reset off
+#pragma unroll
+        for (int i = 0; i < P; ++i) c[i] = back ? st[i] : n[i];
+        terminal = back ? start_terminal : min(ended & 13u, 1u);
         STAMP(7);   // reset handling
     };
+    using Generic = std::integral_constant<int, -1>;
+    using Yes = std::true_type;
+    using No = std::false_type;
+    auto swap_raw = [&]() __attribute__((always_inline)) { const uint32_t tmp = raw_even; raw_even = raw_odd; raw_odd = tmp; };
     uint32_t s = 0;
-    for (; s + 1u < p.n_steps; s += 2u) {
-        one_step(s, raw_even);
-        one_step(s + 1u, raw_odd);
+    // the first step, generic steps up to the slip stream's call boundary, four steps per iteration with static word
+    // selection while the action rows last, generic steps for the rest
+    if (p.n_steps > 0) {
+        one_step(0u, raw_even, Generic{}, Yes{}, Yes{});
+        swap_raw();
+        s = 1;
     }
-    if (s < p.n_steps) one_step(s, raw_even);
+    for (; s < p.n_steps && ((p.t + s) & 3u) != 0u; ++s) {
+        one_step(s, raw_even, Generic{}, No{}, Yes{});
+        swap_raw();
+    }
+    for (; s + 6u <= p.n_steps; s += 4u) {                     // the last of the four steps prefetches row s + 5
+        one_step(s, raw_even, std::integral_constant<int, 0>{}, No{}, No{});
+        one_step(s + 1u, raw_odd, std::integral_constant<int, 1>{}, No{}, No{});
+        one_step(s + 2u, raw_even, std::integral_constant<int, 2>{}, No{}, No{});
+        one_step(s + 3u, raw_odd, std::integral_constant<int, 3>{}, No{}, No{});
+    }
+    for (; s < p.n_steps; ++s) {
+        one_step(s, raw_even, Generic{}, No{}, Yes{});
+        swap_raw();
+    }
     if (p.n_steps > 0) finish_pending();                       // the last step's chain, totals and stores
 #ifdef MAPF_STAMPS
     if (x.lane == 0u && epi_p) {   // diagnostic build: segment sums replace the episode counts
@@ -376,7 +533,12 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         return;
     }
 #endif
-    *reinterpret_cast<u32x2 *>(at(p.state, lane_cell)) = u32x2{ca, cb};
+    {
+        Packed<P> fin;
+#pragma unroll
+        for (int i = 0; i < P; ++i) fin.v[i] = c[i];
+        fin.store(at(p.state, lane_cell));
+    }
     if (leader) {
         if (ret_p) *ret_p = ret;
         if (epi_p) *epi_p = episodes;
@@ -384,58 +546,69 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
     }
 }
 
-template <int Q, bool RECORD, bool STREAM>
-hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size_t mv_bytes, hipStream_t stream) {
-    auto kern = lq_rollout_kernel<Q, RECORD, STREAM>;
+template <int Q, int K, bool RECORD, bool STREAM>
+hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream) {
+    auto kern = args.c.criteria != 0u ? lq_rollout_kernel<Q, K, RECORD, STREAM, true> : lq_rollout_kernel<Q, K, RECORD, STREAM, false>;
+    const size_t mv_bytes = lds_bytes;
     if (mv_bytes > 32 * 1024) {   // dynamic LDS beyond the default cap needs an explicit opt-in (per device: not cached)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            int(kLdsBytes - kLdsReserve));
         if (e != hipSuccess) return e;
     }
     const unsigned grid = unsigned(args.n_envs / (block / unsigned(Q)));
-    note_kernel("lq_rollout_kernel<Q=%d,%s,%s> block=%u (quad layout: 4 agents per lane)", Q, RECORD ? "RECORD" : "TOTALS",
-                STREAM ? "STREAM" : "POLICY", block);
+    note_kernel("lq_rollout_kernel<Q=%d,K=%d,%s,%s,%s> block=%u (packed layout: %d agents per lane)", Q, K, RECORD ? "RECORD" : "TOTALS",
+                STREAM ? "STREAM" : "POLICY", args.c.criteria != 0u ? "SOC" : "MAKESPAN", block, K);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), mv_bytes, stream, args, A);
     return hipGetLastError();
 }
 
-}  // namespace
-
-// true when the quad layout took the launch (*err = its status); false = not applicable, use the pair layout
-bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err) {
-    if (!tune.quad_lanes || n_agents < 4 || n_agents % 4 != 0) return false;
-    // Half as many lanes per env means half as many waves: the quad layout only pays while it still keeps two waves on
-    // every SIMD (measured: 65536 envs x 8 agents = 2 waves/SIMD -> 460 G vs 413 G agent-steps/s for the pair layout;
-    // 32768 envs = 1 wave/SIMD -> 233 G vs 300 G): tune.quad_min_lanes.
-    const uint64_t min_lanes = tune.quad_min_lanes;
-    const size_t mv_lds_limit = tune.mv_lds_max_bytes;
-    const int Q = n_agents / 4;
+// does the K-agents-per-lane form apply to this launch?  (full groups, power-of-two group size, full blocks)
+bool layout_fits(int n_agents, int K, const RolloutArgs &args, size_t lds_bytes, unsigned *block_out, int *q_out) {
+    if (n_agents < K || n_agents % K != 0) return false;
+    const int Q = n_agents / K;
     if (Q > 16 || (Q & (Q - 1)) != 0) return false;
-    const size_t mv_bytes = size_t(args.c.n_cells) * 5 * sizeof(MoveEntry);
-    if (mv_bytes + kLdsReserve > mv_lds_limit) return false;
-    const size_t copies = (kLdsBytes - kLdsReserve) / (mv_bytes + kLdsReserve);   // blocks per CU by LDS
+    const size_t copies = kLdsBytes / lds_bytes;   // blocks per CU by LDS
     const unsigned block = copies >= 4 ? 256u : 512u;
     const uint64_t per_block = block / unsigned(Q);
     const uint64_t lanes = args.n_envs * uint64_t(Q);
-    if (args.n_envs % per_block != 0 || lanes < 64 * 256 || lanes < min_lanes) return false;
+    if (args.n_envs % per_block != 0 || lanes < 64 * 256) return false;
+    *block_out = block;
+    *q_out = Q;
+    return true;
+}
+
+}  // namespace
+
+// true when a packed layout took the launch (*err = its status); false = not applicable, use the lane-group kernel
+bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err) {
+    if (!tune.quad_lanes) return false;
+    const size_t mv_bytes = kMoveAt + size_t(args.c.n_cells) * kMoveCols * sizeof(MoveEntry);   // the kernel's whole LDS image
+    if (mv_bytes > tune.mv_lds_max_bytes) return false;
+    // Four agents per lane halve the waves: that form needs tune.quad_min_lanes lanes (default: enough to put two waves
+    // on every SIMD); below that the two-agents-per-lane form of the same kernel runs.
+    unsigned block = 0;
+    int Q = 0, K = 0;
+    if (layout_fits(n_agents, 4, args, mv_bytes, &block, &Q) && args.n_envs * uint64_t(Q) >= tune.quad_min_lanes) K = 4;
+    else if (layout_fits(n_agents, 2, args, mv_bytes, &block, &Q)) K = 2;
+    else return false;
     const bool record = args.rec_local != nullptr, stream_actions = args.actions != nullptr;
     if (record && !(args.rec_reward && args.rec_prob && args.rec_done && args.rec_collision)) {
         *err = hipErrorInvalidValue;
         return true;
     }
     const uint32_t A = uint32_t(n_agents);
-    switch (Q) {
-#define X(N)                                                                                                         \
-    case N:                                                                                                          \
-        *err = record ? (stream_actions ? launch_impl<N, true, true>(args, A, block, mv_bytes, stream)                    \
-                                        : launch_impl<N, true, false>(args, A, block, mv_bytes, stream))                  \
-                      : (stream_actions ? launch_impl<N, false, true>(args, A, block, mv_bytes, stream)                   \
-                                        : launch_impl<N, false, false>(args, A, block, mv_bytes, stream));                \
-        return true;
-        X(1) X(2) X(4) X(8) X(16)
-#undef X
-        default: return false;
+#define MAPF_LQ_CASE(QQ, KK)                                                                                              \
+    if (Q == QQ && K == KK) {                                                                                             \
+        *err = record ? (stream_actions ? launch_impl<QQ, KK, true, true>(args, A, block, mv_bytes, stream)              \
+                                        : launch_impl<QQ, KK, true, false>(args, A, block, mv_bytes, stream))            \
+                      : (stream_actions ? launch_impl<QQ, KK, false, true>(args, A, block, mv_bytes, stream)             \
+                                        : launch_impl<QQ, KK, false, false>(args, A, block, mv_bytes, stream));          \
+        return true;                                                                                                      \
     }
+    MAPF_LQ_CASE(1, 4) MAPF_LQ_CASE(2, 4) MAPF_LQ_CASE(4, 4) MAPF_LQ_CASE(8, 4) MAPF_LQ_CASE(16, 4)
+    MAPF_LQ_CASE(2, 2) MAPF_LQ_CASE(4, 2) MAPF_LQ_CASE(8, 2) MAPF_LQ_CASE(16, 2)
+#undef MAPF_LQ_CASE
+    return false;
 }
 
 }  // namespace mapf

@@ -188,6 +188,7 @@ class MapfEnv(_EnvBase):
         self._terminal = None   # is_terminal(self.s) if known
         self.reset()
         self.locations_to_state(self.agents_goals)   # KeyError if a goal is an obstacle
+        self._goal_local = tuple(self.loc_to_int[tuple(loc)] for loc in self.agents_goals)
         self.lastaction = None
 
     # -------------------------------------------------------------- state <-> device
@@ -257,9 +258,9 @@ class MapfEnv(_EnvBase):
             weight *= V
         self._s = state
         done, collision = bool(out['done'][0]), bool(out['collision'][0])
-        # is_terminal of the returned state, from what the kernel reported: not done -> no; goal reached -> yes;
-        # collision -> only a vertex collision leaves two agents in one cell (a swap alone does not, :210-223)
-        self._terminal = done and (not collision or len(set(local)) < n)
+        # is_terminal of the returned state (:210-223): a state the kernel did not report done has neither two agents
+        # in one cell nor everyone on goal; a done one is re-examined (a swap alone is a collision but not terminal)
+        self._terminal = done and (len(set(local)) < n or local == self._goal_local)
         return state, float(out['reward'][0]), done, {"prob": float(out['prob'][0]), "collision": collision}
 
     def _get_transitions(self, s, a):

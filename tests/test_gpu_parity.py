@@ -389,16 +389,25 @@ def _goal_scenario_tables(n_agents, n_envs, seed):
     return grid, nbr, rc, start, goal
 
 
-@pytest.mark.parametrize('n_agents,n_envs,layout', [
-    (4, 16384, 'lq_'), (4, 16512, 'lg_'), (8, 8192, 'lq_'), (8, 16448, 'lg_'), (16, 4096, 'lq_'), (16, 4128, 'lg_'),
-    (32, 2048, 'lq_'), (32, 1024, 'lg_'), (8, 300, 'lg_'), (5, 600, 'lg_'), (6, 512, 'rollout_kernel<A=6>')])
-def test_goal_reaching_episodes_against_c_oracle(n_agents, n_envs, layout):
+@pytest.mark.parametrize('n_agents,n_envs,layout,env_vars', [
+    (4, 16384, 'lq_rollout_kernel<Q=1,K=4', {}), (4, 16512, 'lq_rollout_kernel<Q=2,K=2', {}),
+    (8, 8192, 'lq_rollout_kernel<Q=2,K=4', {}), (8, 16448, 'lq_rollout_kernel<Q=4,K=2', {}),
+    (8, 16448, 'lg_rollout_kernel<L=4,FULL,MV_LDS', {'MAPF_QUAD_LANES': '0'}),
+    (16, 4096, 'lq_rollout_kernel<Q=4,K=4', {}), (16, 4128, 'lq_rollout_kernel<Q=8,K=2', {}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4', {}), (32, 1024, 'lq_rollout_kernel<Q=16,K=2', {}),
+    (32, 1024, 'lg_rollout_kernel<L=16,FULL,MV_GLOBAL', {'MAPF_MV_LDS_MAX_BYTES': '0'}),
+    (8, 300, 'lg_rollout_kernel<L=4,FULL,MV_GLOBAL', {}), (5, 600, 'lg_rollout_kernel<L=4,RAGGED', {}),
+    (8, 16417, 'lg_rollout_kernel<L=4,FULL,MV_LDS', {}), (6, 512, 'rollout_kernel<A=6>', {})])
+def test_goal_reaching_episodes_against_c_oracle(n_agents, n_envs, layout, env_vars, monkeypatch):
     """The goal-reached branch (reward_of_goal + living, done, no collision, then terminal / auto-reset) and "vertex
-    collision while every agent sits on its goal" (collision wins) at 4..32 agents, in the quad-lane rollout, the
-    pair-layout rollout (LDS and global table), the thread-per-env rollout and the single-step kernel: agents start
-    one move from their goals on an open map and are driven towards them (oracle/goal_scenarios.py -- the family
-    the reference itself stepped for tests/golden/goals_*).  Every recorded step against the C oracle; each pass must
-    actually contain both outcomes."""
+    collision while every agent sits on its goal" (collision wins) at 4..32 agents, in every rollout kernel -- the
+    packed layout with four and with two agents per lane, the lane-group layout (LDS and global table, dense and
+    guarded), the thread-per-env kernel -- and in the single-step kernel: agents start one move from their goals on an
+    open map and are driven towards them (oracle/goal_scenarios.py -- the family the reference itself stepped for
+    tests/golden/goals_*).  Every recorded step against the C oracle; each pass must actually contain both outcomes,
+    and the library must report the kernel this case is meant to reach."""
+    for k, v in env_vars.items():
+        monkeypatch.setenv(k, v)
     A, E = n_agents, n_envs
     grid, nbr, rc, start, goal = _goal_scenario_tables(A, E, 8100 + A)
     for fail_prob, crit, ocrit, auto, mode, T in (

@@ -1,9 +1,13 @@
-"""Derive profiles/traffic.json from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of `python3 bench.py
---no-cpu-baseline`.  usage: python tools/derive_traffic.py <fetch counter_collection.csv> <write ...csv> [out.json]
+"""Derive profiles/traffic.json from rocprofv3 PMC passes of `python3 bench.py --no-cpu-baseline` run at TWO launch
+lengths (--rollout-steps T1 and T2): per kernel instance and batch, HBM bytes per launch = fixed + per_env_step * T.
+
+usage: python tools/derive_traffic.py <label> <E> <A> <T1> <fetch1.csv> <write1.csv> <T2> <fetch2.csv> <write2.csv> [...]
+       (label = the kernel name the library reports for that batch: bench line `roofline.kernel`; a group of nine
+        arguments per configuration; the single-step kernel of each group is recorded too)
 
 hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per dispatch: the counters are KB per dispatch and gfx950 tallies
-128-byte read requests at 64 B (MI355X_MICROARCH.md, HBM / rocprofv3 section).  reset_kernel and
-fill_actions_kernel move known byte counts and are kept in the output as the calibration of that rule.
+128-byte read requests at 64 B (MI355X_MICROARCH.md, HBM / rocprofv3 section).  reset_kernel and fill_actions_kernel
+move known byte counts and are kept in the output as the calibration of that rule.
 """
 import collections
 import csv
@@ -12,24 +16,22 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-E, A, T = 65536, 8, 256   # bench.py defaults
-BYTES_PER_AGENT_STEP = 5.0 + 18.0 / A   # SURVEY.md 8(d), same figure as bench.py bytes_per_agent_step
-ALGORITHMIC = {"rollout_kernel": int(T * E * A * BYTES_PER_AGENT_STEP), "lg_step_kernel": int(E * A * BYTES_PER_AGENT_STEP)}
 
 
 def per_kernel(path, counter):
-    """{kernel key: (mean counter value, dispatches, full name)}.  The bench also launches one short rollout (the
-    8-step parity leg): dispatches whose value is below half of the kernel's largest are left out of the mean."""
+    """{kernel key: (mean counter value over the full-length dispatches, dispatches, full name)}.  The bench also
+    launches one short rollout (the 8-step parity leg): rollout dispatches below half of the largest are left out."""
     values, names = collections.defaultdict(list), {}
     with open(path) as f:
         for r in csv.DictReader(f):
             if r["Counter_Name"] != counter:
                 continue
             name = r["Kernel_Name"]
-            for key in ("rollout_kernel", "lg_step_kernel", "reset_kernel", "fill_actions_kernel"):
+            for key in ("rollout_kernel", "step_kernel", "reset_kernel", "fill_actions_kernel"):
                 if key in name:   # "rollout_kernel" matches the quad-lane (lq_) and the pair (lg_) layout
                     values[key].append(float(r["Counter_Value"]))
                     names[key] = name
+                    break
     out = {}
     for k, v in values.items():
         full = [x for x in v if x >= 0.5 * max(v)] if k == "rollout_kernel" else v
@@ -37,24 +39,43 @@ def per_kernel(path, counter):
     return out
 
 
+def hbm_bytes(fetch, write, key):
+    return (2.0 * fetch[key][0] + write[key][0]) * 1024.0
+
+
 def main():
-    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
-    write = per_kernel(sys.argv[2], "WRITE_SIZE")
-    out = {"_how": __doc__.strip().split("\n\n", 1)[1].replace("\n", " "), "kernels": {}}
-    for k in ("rollout_kernel", "lg_step_kernel", "reset_kernel", "fill_actions_kernel"):
-        if k not in fetch or k not in write:
-            continue
-        f_kb, n, name = fetch[k]
-        w_kb = write[k][0]
-        entry = {"instance": name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", ""), "dispatches": n,
-                 "FETCH_SIZE_KB": round(f_kb, 2), "WRITE_SIZE_KB": round(w_kb, 2),
-                 "hbm_bytes_per_launch": int(round((2 * f_kb + w_kb) * 1024))}
-        if k in ALGORITHMIC:
-            entry["algorithmic_bytes_per_launch"] = ALGORITHMIC[k]
-        if k == "rollout_kernel":
-            entry["steps_per_launch"] = T
-        out["kernels"][k] = entry
-    dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "traffic.json")
+    args = sys.argv[1:]
+    out = {"_how": __doc__.strip().split("\n\n")[2].replace("\n", " "), "kernels": [], "calibration": {}}
+    while len(args) >= 9:
+        label, E, A, T1, f1, w1, T2, f2, w2 = args[:9]
+        args = args[9:]
+        E, A, T1, T2 = int(E), int(A), int(T1), int(T2)
+        F1, W1, F2, W2 = per_kernel(f1, "FETCH_SIZE"), per_kernel(w1, "WRITE_SIZE"), per_kernel(f2, "FETCH_SIZE"), per_kernel(w2, "WRITE_SIZE")
+        b1, b2 = hbm_bytes(F1, W1, "rollout_kernel"), hbm_bytes(F2, W2, "rollout_kernel")
+        per_step = (b1 - b2) / (T1 - T2)
+        alg = E * A * (5.0 + 18.0 / A)
+        out["kernels"].append({
+            "kernel": label, "instance": F1["rollout_kernel"][2].split("(mapf::")[0].replace("void ", "").strip(),
+            "n_envs": E, "n_agents": A, "bytes_per_env_step_launch": round(per_step, 1), "fixed_bytes": round(b1 - per_step * T1, 1),
+            "algorithmic_bytes_per_env_step_launch": alg,
+            "measured": {str(T1): {"FETCH_SIZE_KB": round(F1["rollout_kernel"][0], 2), "WRITE_SIZE_KB": round(W1["rollout_kernel"][0], 2),
+                                   "hbm_bytes_per_launch": int(b1), "dispatches": F1["rollout_kernel"][1]},
+                         str(T2): {"FETCH_SIZE_KB": round(F2["rollout_kernel"][0], 2), "WRITE_SIZE_KB": round(W2["rollout_kernel"][0], 2),
+                                   "hbm_bytes_per_launch": int(b2), "dispatches": F2["rollout_kernel"][1]}}})
+        if "step_kernel" in F1 and "step_kernel" in W1:
+            name = F1["step_kernel"][2]
+            out["kernels"].append({
+                "kernel": None, "instance": name.split("(mapf::")[0].replace("void ", "").strip(), "single_step_of": label,
+                "n_envs": E, "n_agents": A, "bytes_per_env_step_launch": round(hbm_bytes(F1, W1, "step_kernel"), 1), "fixed_bytes": 0.0,
+                "algorithmic_bytes_per_env_step_launch": alg,
+                "measured": {"1": {"FETCH_SIZE_KB": round(F1["step_kernel"][0], 2), "WRITE_SIZE_KB": round(W1["step_kernel"][0], 2),
+                                   "dispatches": F1["step_kernel"][1]}}})
+        for k in ("reset_kernel", "fill_actions_kernel"):
+            if k in F1 and k in W1:
+                out["calibration"]["%s E=%d A=%d" % (k, E, A)] = {
+                    "FETCH_SIZE_KB": round(F1[k][0], 2), "WRITE_SIZE_KB": round(W1[k][0], 2), "hbm_bytes_per_launch": int(hbm_bytes(F1, W1, k)),
+                    "known_bytes": (E * A * 2 * 2) if k == "reset_kernel" else None}
+    dst = os.path.join(ROOT, "profiles", "traffic.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out["kernels"], indent=1))

@@ -4,7 +4,7 @@
 episode counters, so this build's outputs are not valid results) and prints median cycles per step and segment.
 
     make -C gym-mapf_amd/csrc stamps
-    MAPF_HIP_LIB=gym-mapf_amd/csrc/build/libmapf_hip_stamps.so python tools/stamp_profile.py
+    MAPF_HIP_LIB=gym-mapf_amd/csrc/build/libmapf_hip_stamps.so python tools/stamp_profile.py [envs]
     (MAPF_QUAD_LANES=0 in the environment profiles the pair layout instead of the quad-lane one)
 
 Stamps serialise the segments (a fence on each side), so read the SHARES, not the total (cdna_hip_programming.md
@@ -22,11 +22,12 @@ from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv  # noqa: 
 
 if 'stamps' not in os.environ.get('MAPF_HIP_LIB', ''):
     raise SystemExit('set MAPF_HIP_LIB to the stamps build (see the docstring)')
-E, A, T = 65536, 8, 64
+E, A, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 65536), 8, 64
 # envs per wave: 32 in the quad-lane layout (default), 16 in the pair layout (MAPF_QUAD_LANES=0)
 PER_WAVE = 16 if os.environ.get('MAPF_QUAD_LANES') == '0' else 32
 print('layout: %s' % ('pair (2 agents per lane)' if PER_WAVE == 16 else 'quad (4 agents per lane)'))
-grid, nbr, start, goal = bench.workload_tables(E, 0)
+grid, _, nbr, start, goal = bench.workload_tables(bench.CONFIGS['c3'], E, 0)
+print('envs: %d' % E)
 env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=42,
                  device_arrays=True, start_local=start, goal_local=goal)
 actions = env.fill_random_actions(0, T)
