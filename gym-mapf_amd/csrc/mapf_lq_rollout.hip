@@ -65,16 +65,29 @@ template <> struct Packed<2> {
     }
 };
 
+// The kernel's LDS image starts at LDS address 0 (it is the kernel's only LDS object; checked once at kernel entry), so
+// an LDS location is named by its BYTE ADDRESS: plain integer arithmetic ending in one v_lshl_add_u32, the constant
+// part of the address folded into the ds instruction's offset field.
+template <typename T>
+__device__ __forceinline__ T lds_at(uint32_t byte_address) {
+    return *(const __attribute__((address_space(3))) T *)(uintptr_t(byte_address));
+}
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ MoveEntry lds_entry_at(uint32_t byte_address) {   // one ds_read_b128
+    const u32x4 v = lds_at<u32x4>(byte_address);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // sampled list slot of one agent from the top 16 bits of its uniform (see slip_move_hi): idx, its probability, and
 // the tie distance (0 <=> hi equals a threshold -> exact path)
-__device__ __forceinline__ uint32_t sample_slot(const SlipRow *lds_slip, const MoveEntry &entry, uint32_t hi, double &q,
+__device__ __forceinline__ uint32_t sample_slot(uint32_t slip_at, const MoveEntry &entry, uint32_t hi, double &q,
                                                 uint32_t &tie_dist) {
     // (slot = how many of the first two thresholds hi has passed: see slip_move_hi in mapf_device.hpp)
     const uint32_t t0 = entry.z & 0xFFFFu, t1 = entry.z >> 16;
     const uint32_t d0 = hi - t0, d1 = hi - t1, d2 = hi - 0xFFFFu;
     tie_dist = min(d0, min(d1, d2));
     const uint32_t idx = 2u - (d0 >> 31) - (d1 >> 31);
-    q = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(lds_slip) + entry_row_offset(entry) + idx * 8u);
+    q = lds_at<double>(slip_at + (idx << 3) + entry_row_offset(entry));
     return idx;
 }
 // list slot idx of an entry, zero-extended: one v_perm_b32
@@ -202,6 +215,7 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
     SlipRow *slip = reinterpret_cast<SlipRow *>(lds_image + kSlipAt);
     OutcomeRow *outcome = reinterpret_cast<OutcomeRow *>(lds_image + kOutcomeAt);
     MoveEntry *lds_mv = reinterpret_cast<MoveEntry *>(lds_image + kMoveAt);
+    if (uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lds_image)) != 0u) __builtin_trap();
     LaneCtx<Q> x;
     x.lane = threadIdx.x & 63u;
     x.g = x.lane & uint32_t(Q - 1);
@@ -280,22 +294,30 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
     asm volatile("" : "+v"(wide_lane), "+v"(prob_lane), "+v"(narrow_lane), "+v"(coll_lane), "+v"(rec_lane));
     const uint8_t *act_lane = STREAM ? p.actions + lane_cell : nullptr;
 
-    // Action words are fetched TWO steps ahead (one step is shorter than a loaded HBM round trip).  Invariant at the top
-    // of step s: raw_even holds row s, raw_odd row s+1, act_lane points at row min(s+1, last).  A step consumes the
-    // register that holds its row and reloads THAT register with row s+2, so in the unrolled part of the loop the two
-    // registers simply take turns (rotating a register through a move would be a use, i.e. a wait); a generic step
-    // swaps them afterwards.
+    // Action words are fetched kAhead steps ahead of their use (four with four agents per lane, eight with two, whose
+    // steps are shorter): the loaded-HBM round trip, with the trajectory stores of the same wave queued in front of it
+    // (vmcnt counts loads and stores in order), is longer than two steps -- fetched two ahead, the two-agents-per-lane
+    // form ran 23 % slower than with L2-resident actions, the wait for the action word being the largest stall left.
+    // Invariant at the top of step s: raw[j] holds row s+j (j < kAhead), act_lane points at row min(s+kAhead-1, last).
+    // A step consumes the register that holds its row and reloads THAT register with row s+kAhead, so in the unrolled
+    // part of the loop the registers simply take turns (rotating a register through a move would be a use, i.e. a
+    // wait); a single step outside it uses raw[0] and shifts the others down afterwards.
+    constexpr uint32_t kAhead = K == 4 ? 4 : 8;
     const uint32_t last_row = p.n_steps ? p.n_steps - 1u : 0u;
     auto load_raw = [&]() __attribute__((always_inline)) {
         return K == 4 ? *reinterpret_cast<const uint32_t *>(act_lane) : uint32_t(*reinterpret_cast<const uint16_t *>(act_lane));
     };
-    uint32_t raw_even = 0u, raw_odd = 0u;
+    uint32_t raw[kAhead] = {};
     if (STREAM && p.n_steps > 0) {
-        raw_even = load_raw();
-        act_lane += last_row >= 1u ? step_cells : 0u;             // clamped, not guarded: late rows are re-read
-        raw_odd = load_raw();
+        raw[0] = load_raw();
+#pragma unroll
+        for (uint32_t j = 1; j < kAhead; ++j) {
+            act_lane += last_row >= j ? step_cells : 0u;          // clamped, not guarded: late rows are re-read
+            raw[j] = load_raw();
+        }
     }
-    asm volatile("" : "+v"(raw_even), "+v"(raw_odd));   // consumed here: the loop's waits are the back edge's counted ones
+#pragma unroll
+    for (uint32_t j = 0; j < kAhead; ++j) asm volatile("" : "+v"(raw[j]));   // consumed here: the loop's waits are counted ones
     Words4 rng[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) rng[i] = Words4{0u, 0u, 0u, 0u};
@@ -366,7 +388,9 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
             for (int k = 0; k < K; ++k) act[k] = min((raw >> (8 * k)) & 0xFFu, 5u);   // extract + clamp: one v_min_u32 (byte select)
 #pragma unroll
             for (int k = 0; k < K; ++k) asm volatile("" : "+v"(act[k]));   // the wait for `raw` sits here
-            act_lane += (!TAIL || s + 2u <= last_row) ? step_cells : 0u;   // row min(s + 2, last)
+#ifndef MAPF_EXP_NO_ACT_ADVANCE   // (experiment builds only: every step re-reads one row, i.e. the action stream hits in L2)
+            act_lane += (!TAIL || s + kAhead <= last_row) ? step_cells : 0u;   // row min(s + kAhead, last)
+#endif
             raw = load_raw();
         } else if (p.policy_cells) {   // greedy policy
 #pragma unroll
@@ -390,14 +414,17 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         MoveEntry entry[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const uint32_t byte_off = __umul24(cur[k], kMoveCols * uint32_t(sizeof(MoveEntry))) + act[k] * uint32_t(sizeof(MoveEntry));
-            entry[k] = *reinterpret_cast<const MoveEntry *>(lds_image + kMoveAt + byte_off);
+            entry[k] = lds_entry_at(kMoveAt + (act[k] << 4) + __umul24(cur[k], kMoveCols * uint32_t(sizeof(MoveEntry))));
         }
         STAMP(0);   // loop top: action fetch / policy, table read issue
         // --- ... then the previous step is finished while they are in flight
         if (!FIRST) {
             finish_pending();
+#ifdef MAPF_EXP_NO_ADVANCE   // (experiment builds only: every step overwrites row 0, i.e. no HBM write stream)
+            if (false) {
+#else
             if (RECORD) {
+#endif
                 rec_lane += step_cells;
                 wide_lane += step_rows;
                 narrow_lane += step_rows;
@@ -422,7 +449,7 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         double q[K];
         uint32_t idx[K], tie[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k) idx[k] = sample_slot(slip, entry[k], hi[k], q[k], tie[k]);
+        for (int k = 0; k < K; ++k) idx[k] = sample_slot(kSlipAt, entry[k], hi[k], q[k], tie[k]);
         uint32_t n[P];
 #pragma unroll
         for (int i = 0; i < P; ++i) n[i] = cell_lo(entry[2 * i], idx[2 * i]) | (cell_lo(entry[2 * i + 1], idx[2 * i + 1]) << 16);
@@ -458,9 +485,9 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
 
         // --- outcome: the row (status for both criteria, reward for Makespan) is only REQUESTED here; everything the
         // next step's table address depends on is derived from `code` without waiting for it
-        const OutcomeRow *row = reinterpret_cast<const OutcomeRow *>(lds_image + kOutcomeAt + code * uint32_t(sizeof(OutcomeRow)));
-        const uint32_t row_status = row->status;
-        double reward = row->reward;
+        const uint32_t row_at = kOutcomeAt + code * uint32_t(sizeof(OutcomeRow));
+        const uint32_t row_status = lds_at<uint32_t>(row_at + uint32_t(offsetof(OutcomeRow, status)));
+        double reward = lds_at<double>(row_at + uint32_t(offsetof(OutcomeRow, reward)));
         const bool was_terminal = code > 7u;
         if (SOC) {
             // _living_reward: mapf_env.py:436-446
@@ -501,31 +528,51 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         STAMP(7);   // reset handling
     };
     using Generic = std::integral_constant<int, -1>;
+    using W0 = std::integral_constant<int, 0>;
+    using W1 = std::integral_constant<int, 1>;
+    using W2 = std::integral_constant<int, 2>;
+    using W3 = std::integral_constant<int, 3>;
     using Yes = std::true_type;
     using No = std::false_type;
-    auto swap_raw = [&]() __attribute__((always_inline)) { const uint32_t tmp = raw_even; raw_even = raw_odd; raw_odd = tmp; };
+    auto shift_raw = [&]() __attribute__((always_inline)) {   // after a single step: raw[0] was reloaded with row s + kAhead
+        const uint32_t newest = raw[0];
+#pragma unroll
+        for (uint32_t j = 0; j + 1 < kAhead; ++j) raw[j] = raw[j + 1];
+        raw[kAhead - 1] = newest;
+    };
+    // a single step outside the unrolled loop: its slip word is still picked statically (one four-way branch instead of
+    // the word selects inside the step), its prefetch address is clamped
+    auto single_step = [&](const uint32_t s) __attribute__((always_inline)) {
+        switch (uint32_t(p.t + s) & 3u) {
+            case 0: one_step(s, raw[0], W0{}, No{}, Yes{}); break;
+            case 1: one_step(s, raw[0], W1{}, No{}, Yes{}); break;
+            case 2: one_step(s, raw[0], W2{}, No{}, Yes{}); break;
+            default: one_step(s, raw[0], W3{}, No{}, Yes{}); break;
+        }
+        shift_raw();
+    };
     uint32_t s = 0;
-    // the first step, generic steps up to the slip stream's call boundary, four steps per iteration with static word
-    // selection while the action rows last, generic steps for the rest
+    // the first step; single steps up to the slip stream's call boundary; kAhead steps per iteration with static word
+    // and register selection and unclamped prefetch while the action rows last; single steps for the rest
     if (p.n_steps > 0) {
-        one_step(0u, raw_even, Generic{}, Yes{}, Yes{});
-        swap_raw();
+        one_step(0u, raw[0], Generic{}, Yes{}, Yes{});
+        shift_raw();
         s = 1;
     }
-    for (; s < p.n_steps && ((p.t + s) & 3u) != 0u; ++s) {
-        one_step(s, raw_even, Generic{}, No{}, Yes{});
-        swap_raw();
+    for (; s < p.n_steps && ((p.t + s) & 3u) != 0u; ++s) single_step(s);
+    for (; s + 2u * kAhead <= p.n_steps; s += kAhead) {        // the group's last step prefetches row s + 2 kAhead - 1
+        one_step(s, raw[0], W0{}, No{}, No{});
+        one_step(s + 1u, raw[1], W1{}, No{}, No{});
+        one_step(s + 2u, raw[2], W2{}, No{}, No{});
+        one_step(s + 3u, raw[3], W3{}, No{}, No{});
+        if constexpr (kAhead == 8) {
+            one_step(s + 4u, raw[4], W0{}, No{}, No{});
+            one_step(s + 5u, raw[5], W1{}, No{}, No{});
+            one_step(s + 6u, raw[6], W2{}, No{}, No{});
+            one_step(s + 7u, raw[7], W3{}, No{}, No{});
+        }
     }
-    for (; s + 6u <= p.n_steps; s += 4u) {                     // the last of the four steps prefetches row s + 5
-        one_step(s, raw_even, std::integral_constant<int, 0>{}, No{}, No{});
-        one_step(s + 1u, raw_odd, std::integral_constant<int, 1>{}, No{}, No{});
-        one_step(s + 2u, raw_even, std::integral_constant<int, 2>{}, No{}, No{});
-        one_step(s + 3u, raw_odd, std::integral_constant<int, 3>{}, No{}, No{});
-    }
-    for (; s < p.n_steps; ++s) {
-        one_step(s, raw_even, Generic{}, No{}, Yes{});
-        swap_raw();
-    }
+    for (; s < p.n_steps; ++s) single_step(s);
     if (p.n_steps > 0) finish_pending();                       // the last step's chain, totals and stores
 #ifdef MAPF_STAMPS
     if (x.lane == 0u && epi_p) {   // diagnostic build: segment sums replace the episode counts
@@ -549,8 +596,7 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
 template <int Q, int K, bool RECORD, bool STREAM>
 hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream) {
     auto kern = args.c.criteria != 0u ? lq_rollout_kernel<Q, K, RECORD, STREAM, true> : lq_rollout_kernel<Q, K, RECORD, STREAM, false>;
-    const size_t mv_bytes = lds_bytes;
-    if (mv_bytes > 32 * 1024) {   // dynamic LDS beyond the default cap needs an explicit opt-in (per device: not cached)
+    if (lds_bytes > 32 * 1024) {   // dynamic LDS beyond the default cap needs an explicit opt-in (per device: not cached)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            int(kLdsBytes - kLdsReserve));
         if (e != hipSuccess) return e;
@@ -558,15 +604,47 @@ hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size
     const unsigned grid = unsigned(args.n_envs / (block / unsigned(Q)));
     note_kernel("lq_rollout_kernel<Q=%d,K=%d,%s,%s,%s> block=%u (packed layout: %d agents per lane)", Q, K, RECORD ? "RECORD" : "TOTALS",
                 STREAM ? "STREAM" : "POLICY", args.c.criteria != 0u ? "SOC" : "MAKESPAN", block, K);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), mv_bytes, stream, args, A);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds_bytes, stream, args, A);
     return hipGetLastError();
 }
 
+}  // namespace
+
+// This file is compiled once per (agents per lane, recording) pair -- -DMAPF_LQ_K=4|2 -DMAPF_LQ_RECORD=1|0 -- so that
+// its 72 kernel instances build in parallel; each object exports one launcher, the K=4 / RECORD=1 object also the router.
+#if !defined(MAPF_LQ_K) || !defined(MAPF_LQ_RECORD)
+#error "compile with -DMAPF_LQ_K=4|2 -DMAPF_LQ_RECORD=1|0"
+#endif
+#define MAPF_LQ_CAT3(a, b, c) a##b##_r##c
+#define MAPF_LQ_NAME(k, r) MAPF_LQ_CAT3(launch_rollout_lq_k, k, r)
+
+hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream) {
+    constexpr int K = MAPF_LQ_K;
+    constexpr bool R = MAPF_LQ_RECORD != 0;
+    const bool stream_actions = args.actions != nullptr;
+    switch (Q) {
+#define X(QQ)                                                                                                        \
+    case QQ: return stream_actions ? launch_impl<QQ, K, R, true>(args, A, block, lds_bytes, stream)                        \
+                                   : launch_impl<QQ, K, R, false>(args, A, block, lds_bytes, stream);
+#if MAPF_LQ_K == 4
+        X(1)
+#endif
+        X(2) X(4) X(8) X(16)
+#undef X
+        default: return hipErrorInvalidValue;
+    }
+}
+
+#if MAPF_LQ_K == 4 && MAPF_LQ_RECORD == 1
+hipError_t launch_rollout_lq_k4_r0(int Q, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_rollout_lq_k2_r1(int Q, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_rollout_lq_k2_r0(int Q, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
+
 // does the K-agents-per-lane form apply to this launch?  (full groups, power-of-two group size, full blocks)
-bool layout_fits(int n_agents, int K, const RolloutArgs &args, size_t lds_bytes, unsigned *block_out, int *q_out) {
+static bool layout_fits(int n_agents, int K, const RolloutArgs &args, size_t lds_bytes, unsigned *block_out, int *q_out) {
     if (n_agents < K || n_agents % K != 0) return false;
     const int Q = n_agents / K;
-    if (Q > 16 || (Q & (Q - 1)) != 0) return false;
+    if (Q > 16 || (Q & (Q - 1)) != 0 || (K == 2 && Q < 2)) return false;
     const size_t copies = kLdsBytes / lds_bytes;   // blocks per CU by LDS
     const unsigned block = copies >= 4 ? 256u : 512u;
     const uint64_t per_block = block / unsigned(Q);
@@ -577,38 +655,28 @@ bool layout_fits(int n_agents, int K, const RolloutArgs &args, size_t lds_bytes,
     return true;
 }
 
-}  // namespace
-
 // true when a packed layout took the launch (*err = its status); false = not applicable, use the lane-group kernel
 bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err) {
     if (!tune.quad_lanes) return false;
-    const size_t mv_bytes = kMoveAt + size_t(args.c.n_cells) * kMoveCols * sizeof(MoveEntry);   // the kernel's whole LDS image
-    if (mv_bytes > tune.mv_lds_max_bytes) return false;
+    const size_t lds_bytes = kMoveAt + size_t(args.c.n_cells) * kMoveCols * sizeof(MoveEntry);   // the kernel's whole LDS image
+    if (lds_bytes > tune.mv_lds_max_bytes) return false;
     // Four agents per lane halve the waves: that form needs tune.quad_min_lanes lanes (default: enough to put two waves
     // on every SIMD); below that the two-agents-per-lane form of the same kernel runs.
     unsigned block = 0;
     int Q = 0, K = 0;
-    if (layout_fits(n_agents, 4, args, mv_bytes, &block, &Q) && args.n_envs * uint64_t(Q) >= tune.quad_min_lanes) K = 4;
-    else if (layout_fits(n_agents, 2, args, mv_bytes, &block, &Q)) K = 2;
+    if (layout_fits(n_agents, 4, args, lds_bytes, &block, &Q) && args.n_envs * uint64_t(Q) >= tune.quad_min_lanes) K = 4;
+    else if (layout_fits(n_agents, 2, args, lds_bytes, &block, &Q)) K = 2;
     else return false;
-    const bool record = args.rec_local != nullptr, stream_actions = args.actions != nullptr;
+    const bool record = args.rec_local != nullptr;
     if (record && !(args.rec_reward && args.rec_prob && args.rec_done && args.rec_collision)) {
         *err = hipErrorInvalidValue;
         return true;
     }
     const uint32_t A = uint32_t(n_agents);
-#define MAPF_LQ_CASE(QQ, KK)                                                                                              \
-    if (Q == QQ && K == KK) {                                                                                             \
-        *err = record ? (stream_actions ? launch_impl<QQ, KK, true, true>(args, A, block, mv_bytes, stream)              \
-                                        : launch_impl<QQ, KK, true, false>(args, A, block, mv_bytes, stream))            \
-                      : (stream_actions ? launch_impl<QQ, KK, false, true>(args, A, block, mv_bytes, stream)             \
-                                        : launch_impl<QQ, KK, false, false>(args, A, block, mv_bytes, stream));          \
-        return true;                                                                                                      \
-    }
-    MAPF_LQ_CASE(1, 4) MAPF_LQ_CASE(2, 4) MAPF_LQ_CASE(4, 4) MAPF_LQ_CASE(8, 4) MAPF_LQ_CASE(16, 4)
-    MAPF_LQ_CASE(2, 2) MAPF_LQ_CASE(4, 2) MAPF_LQ_CASE(8, 2) MAPF_LQ_CASE(16, 2)
-#undef MAPF_LQ_CASE
-    return false;
+    if (K == 4) *err = record ? launch_rollout_lq_k4_r1(Q, args, A, block, lds_bytes, stream) : launch_rollout_lq_k4_r0(Q, args, A, block, lds_bytes, stream);
+    else *err = record ? launch_rollout_lq_k2_r1(Q, args, A, block, lds_bytes, stream) : launch_rollout_lq_k2_r0(Q, args, A, block, lds_bytes, stream);
+    return true;
 }
+#endif
 
 }  // namespace mapf

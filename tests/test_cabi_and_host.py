@@ -110,8 +110,11 @@ def test_every_dispatchable_kernel_is_free_of_register_spills(tmp_path):
     jobs = []
     flags = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-I' + os.path.join(ROOT, 'include'),
              '-S', '--cuda-device-only']
-    for unit in ('mapf_lg_kernels', 'mapf_lg_rollout', 'mapf_lq_rollout', 'mapf_transitions'):
+    for unit in ('mapf_lg_kernels', 'mapf_lg_rollout', 'mapf_transitions'):
         jobs.append((unit, [], tmp_path / (unit + '.s')))
+    for k in (4, 2):                                              # packed-layout rollout: one object per (K, RECORD)
+        for r in (1, 0):
+            jobs.append(('mapf_lq_rollout', ['-DMAPF_LQ_K=%d' % k, '-DMAPF_LQ_RECORD=%d' % r], tmp_path / ('mapf_lq_k%d_r%d.s' % (k, r))))
     for g in range(4):
         jobs.append(('mapf_kernels', ['-DMAPF_GROUP=%d' % g], tmp_path / ('mapf_kernels_g%d.s' % g)))
     procs = [(out, subprocess.Popen(flags + extra + [os.path.join(CSRC, unit + '.hip'), '-o', str(out)],
@@ -120,7 +123,7 @@ def test_every_dispatchable_kernel_is_free_of_register_spills(tmp_path):
     for out, proc in procs:
         assert proc.wait() == 0
         resources.update(_kernel_resources(out.read_text()))
-    assert len(resources) >= 150
+    assert len(resources) >= 200
     max_tpe_rollout = int(re.search(r'kTpeRolloutMaxAgents\s*=\s*(\d+)', open(os.path.join(CSRC, 'mapf_kernels.hpp')).read()).group(1))
     checked = tpe_step = tpe_rollout = 0
     for name, (sgpr, vgpr, scratch) in resources.items():

@@ -15,7 +15,8 @@ for path in sys.argv[1:]:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
             if "rollout_kernel" in name or "step_kernel" in name:
-                vals[name.split("(mapf::")[0].replace("void ", "").strip()][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                key = name.split("(mapf::")[0].replace("void ", "").strip() + "  grid=" + r["Grid_Size"]
+                vals[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for kern, counters in vals.items():
     print(kern)
     mean = {}
@@ -41,3 +42,9 @@ for kern, counters in vals.items():
     ratio("SQ_INSTS_VMEM_RD", "SQ_WAVES", "vector loads per wave")
     ratio("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "LDS bank-conflict cycles / LDS active cycles")
     ratio("SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "quad-cycles per VALU wave-instruction (x4 = cycles)")
+    ratio("SQ_ACTIVE_INST_MISC", "SQ_WAVE_CYCLES", "misc (branch, waitcnt, nop, sendmsg) active / wave cycles")
+    ratio("SQ_INST_CYCLES_VMEM_WR", "SQ_WAVE_CYCLES", "vector-store issue cycles / wave cycles")
+    ratio("SQ_INST_CYCLES_VMEM_RD", "SQ_WAVE_CYCLES", "vector-load issue cycles / wave cycles")
+    ratio("SQ_INST_CYCLES_SALU", "SQ_WAVE_CYCLES", "SALU issue cycles / wave cycles")
+    ratio("SQ_WAIT_INST_LDS", "SQ_WAVE_CYCLES", "LDS issue stalls / wave cycles")
+    ratio("SQ_INSTS_BRANCH", "SQ_WAVES", "branch instructions per wave")
