@@ -258,8 +258,11 @@ def main():
     ap.add_argument('--config', default='c3', choices=sorted(CONFIGS))
     ap.add_argument('--envs', type=int, default=None, help='override the config: envs per GPU (weak scaling)')
     ap.add_argument('--rollout-steps', type=int, default=256, help='T: env-steps fused per launch')
+    ap.add_argument('--preroll-ms', type=float, default=150.0,
+                    help='untimed launches before the warm-up steps, so that the timed region sees sustained clocks')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-side-legs', action='store_true', help='skip single_step_launches and scalar_env (profiling runs)')
+    ap.add_argument('--no-scalar-env', action='store_true', help='skip the scalar_env leg (its ~100k one-env launches swamp a profile)')
     ap.add_argument('--kernel', default='auto', choices=['auto', 'thread_per_env', 'lane_group'])
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' + --share-device rehearses the N > 1 path on a one-GPU box")
@@ -367,7 +370,16 @@ def main():
 
     def timed(enqueue, n_warm, n_timed):
         """barrier + sync, n_timed enqueues bracketed by HIP events on the env's stream, barrier + sync;
-        returns (max-over-ranks wall seconds, HIP-event milliseconds of this rank)."""
+        returns (max-over-ranks wall seconds, HIP-event milliseconds of this rank).  Before the warm-up steps the same
+        launches run untimed for --preroll-ms: after an idle period the device needs ~25 ms of work to reach the clocks
+        it sustains (profiles/r02_launch_series.txt: the first 25 launches run 15 % slower than the 100th)."""
+        t_end = time.perf_counter() + args.preroll_ms * 1e-3
+        k = 0
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                enqueue(k)
+                k += 1
+            env.sync()
         for k in range(n_warm):
             enqueue(k)
         barrier()
@@ -461,6 +473,7 @@ def main():
                        "name": args.config, "envs_per_gpu": E, "envs_total": total_envs, "n_agents": A,
                        "fail_prob": cfg['fail_prob'], "seed": SEED, "env_steps_per_step": T,
                        "agent_steps_per_step": T * total_envs * A, "action_ring_env_steps": ring,
+                       "preroll_ms": args.preroll_ms,
                        "parallelism": "env-sharded x%d" % world},
             "value_hip_events": float(T) * total_envs * A / (ro_launch_ms * 1e-3),
             "roofline": {"bound": "hbm", "achieved": ro_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -476,7 +489,7 @@ def main():
         }
         if single is not None:
             line["single_step_launches"] = single
-        if world == 1 and not args.no_side_legs:
+        if world == 1 and not args.no_side_legs and not args.no_scalar_env:
             line["scalar_env"] = scalar_env_rate()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)

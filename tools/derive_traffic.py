@@ -28,7 +28,7 @@ def per_kernel(path, counter):
                 continue
             name = r["Kernel_Name"]
             for key in ("rollout_kernel", "step_kernel", "reset_kernel", "fill_actions_kernel"):
-                if key in name:   # "rollout_kernel" matches the quad-lane (lq_) and the pair (lg_) layout
+                if key in name and not (key == "step_kernel" and "lg_step_kernel" not in name and "mapf::step_kernel<2," in name):   # (the scalar_env leg runs step_kernel<2, true> on ONE env: not a batch kernel)
                     values[key].append(float(r["Counter_Value"]))
                     names[key] = name
                     break

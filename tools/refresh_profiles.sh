@@ -10,7 +10,7 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 P=/tmp/prof
 rm -rf $P && mkdir -p $P
-BENCH="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-scalar-env"
 
 # 1. the driver's command under the profiler: per-kernel durations
 rocprofv3 --kernel-trace --stats --output-format csv -d $P/stats -- $BENCH > "$out/${tag}_bench_under_rocprof.json"
@@ -43,6 +43,7 @@ python3 tools/sq_summary.py $P/sq1/*/*counter_collection.csv $P/sq2/*/*counter_c
 echo "sq done"
 
 # 4. the un-profiled lines: the driver's command and the default
+python3 tools/exp/launch_series.py 300 > "$out/${tag}_launch_series.txt" 2>&1
 python3 bench.py --steps 20 --warmup 5 > "$out/${tag}_bench_steps20_warmup5.json"
 python3 bench.py > "$out/${tag}_bench_default.json"
 cat "$out/${tag}_bench_default.json"
