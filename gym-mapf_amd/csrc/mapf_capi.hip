@@ -192,14 +192,14 @@ bool build_slip_table(double fail_prob, mapf::SlipRow (&rows)[8], double (&cand_
                 row.q[k] = q[k];
                 const double scaled = std::ceil(std::ldexp(run, 53));          // exact: power-of-two scaling
                 row.thr[k] = scaled >= 9007199254740992.0 ? (uint64_t(1) << 53) : (scaled <= 0 ? 0 : uint64_t(scaled));
-                row.th[k] = uint32_t(row.thr[k] >> 37);
+                row.th[k] = uint32_t(row.thr[k] >> 37) > 65535u ? 65535u : uint32_t(row.thr[k] >> 37);   // saturated (see SlipRow)
                 row.src |= uint32_t(src[k]) << (8 * k);
                 row.members |= uint32_t(members[k]) << (3 * k);
             } else {
                 row.cum[k] = -HUGE_VAL;
                 row.q[k] = 0.0;
                 row.thr[k] = 0;
-                row.th[k] = 0;
+                row.th[k] = 65535u;
             }
         }
         any_multi |= n > 1;
@@ -352,7 +352,7 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
             uint32_t t16[3];
             // (past the list end: 65535 as well -- `hi < 65535` only fails in a tie, and an earlier slot has matched by then)
             for (int k = 0; k < 3; ++k)
-                t16[k] = (k >= int(slip_host[code].n) || slip_host[code].th[k] > 65535u) ? 65535u : slip_host[code].th[k];
+                t16[k] = slip_host[code].th[k];
             packed[size_t(v) * 5 + a] = make_uint4(uint32_t(cells[0]) | (uint32_t(cells[1]) << 16),
                                                     uint32_t(cells[2]) | (uint32_t(code) << 16) | (slip_host[code].members << 19),
                                                     t16[0] | (t16[1] << 16), uint32_t(code * sizeof(mapf::SlipRow)));

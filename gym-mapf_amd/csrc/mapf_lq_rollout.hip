@@ -23,6 +23,10 @@
 //     an action byte is extracted and clamped by one v_min_u32 with a byte select, a table address is
 //     cell * 96 + action * 16.
 //
+// COMPACT form for maps whose full table does not fit (64x64 maps: ~3300 free cells): the LDS table keeps only the first
+// 8 bytes of each 16-byte row (the three cells and the equality code; five columns), one block per CU owns up to 158 KB
+// of it, and the code's thresholds come from a second, dependent LDS read of the code's slip row.
+//
 // Scope: the fused rollout of FULL groups only (A = K * Q, Q a power of two <= 16), every block full, move table in
 // LDS -- the bench configurations and their neighbours.  Everything else (odd agent counts, ragged batches, tables
 // beyond the LDS budget, single steps) stays with mapf_lg_rollout.hip; launch_rollout_lg() picks.  Same stream,
@@ -204,10 +208,11 @@ __device__ __forceinline__ double packed_prob_product(const double (&q)[K]) {
 // RECORD: all five trajectory arrays are written every step; STREAM: actions come from memory, else from the
 // in-kernel policy.  Memory pipeline and store scheme as lg_rollout_kernel<DENSE>.
 constexpr uint32_t kSlipAt = 0, kOutcomeAt = sizeof(SlipRow) * 8, kMoveAt = kLdsReserve, kMoveCols = 6;
+constexpr uint32_t kCompactCols = 5, kCompactEntry = 8;   // COMPACT: cells + code only, no sixth column
 static_assert(kOutcomeAt + sizeof(OutcomeRow) * 16 <= kMoveAt, "LDS image: slip rows, outcome rows, then the move table");
 
-template <int Q, int K, bool RECORD, bool STREAM, bool SOC>
-__global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
+template <int Q, int K, bool RECORD, bool STREAM, bool SOC, bool COMPACT>
+__global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
     constexpr int P = K / 2;   // packed dwords per lane
     static_assert(K == 2 || K == 4, "two or four agents per lane");
     // the kernel's only LDS object, so it sits at LDS address 0 and every offset below is an instruction immediate
@@ -237,19 +242,23 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
     }
     {   // move table -> LDS with six columns per cell (0..4 = the actions, 5 = STAY again: where out-of-range action
         // bytes are clamped to), batches of four independent loads per thread
-        const uint32_t n_words = p.c.n_cells * kMoveCols;
+        // (COMPACT: five columns, the first 8 bytes of every row)
+        const uint32_t n_words = p.c.n_cells * (COMPACT ? kCompactCols : kMoveCols);
         for (uint32_t w0 = threadIdx.x; w0 < n_words; w0 += 4u * blockDim.x) {
             MoveEntry part[4];
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) {
                 const uint32_t w = min(w0 + k * blockDim.x, n_words - 1u);
                 const uint32_t cell = w / kMoveCols, col = w - cell * kMoveCols;
-                part[k] = p.mv[cell * 5u + (col == 5u ? 0u : col)];
+                part[k] = p.mv[COMPACT ? w : cell * 5u + (col == 5u ? 0u : col)];
             }
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) {
                 const uint32_t w = w0 + k * blockDim.x;
-                if (w < n_words) lds_mv[w] = part[k];
+                if (w < n_words) {
+                    if (COMPACT) reinterpret_cast<u32x2 *>(lds_mv)[w] = u32x2{part[k].x, part[k].y};
+                    else lds_mv[w] = part[k];
+                }
             }
         }
     }
@@ -385,7 +394,10 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
         for (int k = 0; k < K; ++k) cur[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu;
         if (STREAM) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) act[k] = min((raw >> (8 * k)) & 0xFFu, 5u);   // extract + clamp: one v_min_u32 (byte select)
+            for (int k = 0; k < K; ++k) {
+                const uint32_t byte = (raw >> (8 * k)) & 0xFFu;
+                act[k] = COMPACT ? (byte > 4u ? 0u : byte) : min(byte, 5u);   // six columns: extract + clamp is one v_min_u32 (byte select)
+            }
 #pragma unroll
             for (int k = 0; k < K; ++k) asm volatile("" : "+v"(act[k]));   // the wait for `raw` sits here
 #ifndef MAPF_EXP_NO_ACT_ADVANCE   // (experiment builds only: every step re-reads one row, i.e. the action stream hits in L2)
@@ -412,9 +424,11 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
 
         // --- my agents' table rows (cell * 96 + action * 16, the table's LDS offset is an immediate): requested first ...
         MoveEntry entry[K];
+        u32x2 cells_code[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            entry[k] = lds_entry_at(kMoveAt + (act[k] << 4) + __umul24(cur[k], kMoveCols * uint32_t(sizeof(MoveEntry))));
+            if (COMPACT) cells_code[k] = lds_at<u32x2>(kMoveAt + (act[k] << 3) + __umul24(cur[k], kCompactCols * kCompactEntry));
+            else entry[k] = lds_entry_at(kMoveAt + (act[k] << 4) + __umul24(cur[k], kMoveCols * uint32_t(sizeof(MoveEntry))));
         }
         STAMP(0);   // loop top: action fetch / policy, table read issue
         // --- ... then the previous step is finished while they are in flight
@@ -432,6 +446,17 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
             }
         }
         STAMP(1);   // previous step: probability chain, totals, trajectory stores
+        if (COMPACT) {   // the code's thresholds: a second LDS read that depends on the first; the row completes to a MoveEntry
+            u32x2 th[K];
+            uint32_t row_off[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                row_off[k] = ((cells_code[k].y >> 16) & 7u) * uint32_t(sizeof(SlipRow));
+                th[k] = lds_at<u32x2>(kSlipAt + uint32_t(offsetof(SlipRow, th)) + row_off[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < K; ++k) entry[k] = make_uint4(cells_code[k].x, cells_code[k].y, th[k].x | (th[k].y << 16), row_off[k]);
+        }
         // one slip-stream call per pair serves four steps
         const bool refresh = FIRST || W == 0 || (W < 0 && (t & 3u) == 0u);
         if (refresh && p.c.need_rng) {
@@ -495,7 +520,7 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const uint32_t goal_k = (k & 1) ? g[k / 2] >> 16 : g[k / 2] & 0xFFFFu;
-                mine += (cur[k] == goal_k && (act[k] == 0u || act[k] == 5u)) ? 1u : 0u;
+                mine += (cur[k] == goal_k && (act[k] == 0u || (!COMPACT && act[k] == 5u))) ? 1u : 0u;
             }
             const int stayed = int(group_reduce<Q, true>(mine, x));
             const double living = __dmul_rn(double(int(n_agents) - stayed), p.c.r_living);
@@ -593,17 +618,18 @@ __global__ void __launch_bounds__(512) lq_rollout_kernel(const RolloutArgs p, co
     }
 }
 
-template <int Q, int K, bool RECORD, bool STREAM>
+template <int Q, int K, bool RECORD, bool STREAM, bool COMPACT = false>
 hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream) {
-    auto kern = args.c.criteria != 0u ? lq_rollout_kernel<Q, K, RECORD, STREAM, true> : lq_rollout_kernel<Q, K, RECORD, STREAM, false>;
+    auto kern = args.c.criteria != 0u ? lq_rollout_kernel<Q, K, RECORD, STREAM, true, COMPACT> : lq_rollout_kernel<Q, K, RECORD, STREAM, false, COMPACT>;
     if (lds_bytes > 32 * 1024) {   // dynamic LDS beyond the default cap needs an explicit opt-in (per device: not cached)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            int(kLdsBytes - kLdsReserve));
         if (e != hipSuccess) return e;
     }
     const unsigned grid = unsigned(args.n_envs / (block / unsigned(Q)));
-    note_kernel("lq_rollout_kernel<Q=%d,K=%d,%s,%s,%s> block=%u (packed layout: %d agents per lane)", Q, K, RECORD ? "RECORD" : "TOTALS",
-                STREAM ? "STREAM" : "POLICY", args.c.criteria != 0u ? "SOC" : "MAKESPAN", block, K);
+    note_kernel("lq_rollout_kernel<Q=%d,K=%d,%s,%s,%s%s> block=%u (packed layout: %d agents per lane%s)", Q, K, RECORD ? "RECORD" : "TOTALS",
+                STREAM ? "STREAM" : "POLICY", args.c.criteria != 0u ? "SOC" : "MAKESPAN", COMPACT ? ",COMPACT" : "", block, K,
+                COMPACT ? ", 8-byte table rows" : "");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds_bytes, stream, args, A);
     return hipGetLastError();
 }
@@ -618,10 +644,24 @@ hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size
 #define MAPF_LQ_CAT3(a, b, c) a##b##_r##c
 #define MAPF_LQ_NAME(k, r) MAPF_LQ_CAT3(launch_rollout_lq_k, k, r)
 
-hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream) {
+hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream) {
     constexpr int K = MAPF_LQ_K;
     constexpr bool R = MAPF_LQ_RECORD != 0;
     const bool stream_actions = args.actions != nullptr;
+#if MAPF_LQ_K == 4
+    if (compact) {   // instantiated for the group sizes whose maps need it: 16, 32 and 64 agents
+        switch (Q) {
+#define X(QQ)                                                                                                        \
+    case QQ: return stream_actions ? launch_impl<QQ, K, R, true, true>(args, A, block, lds_bytes, stream)                  \
+                                   : launch_impl<QQ, K, R, false, true>(args, A, block, lds_bytes, stream);
+            X(4) X(8) X(16)
+#undef X
+            default: return hipErrorInvalidValue;
+        }
+    }
+#else
+    if (compact) return hipErrorInvalidValue;
+#endif
     switch (Q) {
 #define X(QQ)                                                                                                        \
     case QQ: return stream_actions ? launch_impl<QQ, K, R, true>(args, A, block, lds_bytes, stream)                        \
@@ -636,9 +676,9 @@ hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, const RolloutArgs &arg
 }
 
 #if MAPF_LQ_K == 4 && MAPF_LQ_RECORD == 1
-hipError_t launch_rollout_lq_k4_r0(int Q, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
-hipError_t launch_rollout_lq_k2_r1(int Q, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
-hipError_t launch_rollout_lq_k2_r0(int Q, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_rollout_lq_k4_r0(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_rollout_lq_k2_r1(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_rollout_lq_k2_r0(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
 
 // does the K-agents-per-lane form apply to this launch?  (full groups, power-of-two group size, full blocks)
 static bool layout_fits(int n_agents, int K, const RolloutArgs &args, size_t lds_bytes, unsigned *block_out, int *q_out) {
@@ -658,23 +698,38 @@ static bool layout_fits(int n_agents, int K, const RolloutArgs &args, size_t lds
 // true when a packed layout took the launch (*err = its status); false = not applicable, use the lane-group kernel
 bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err) {
     if (!tune.quad_lanes) return false;
-    const size_t lds_bytes = kMoveAt + size_t(args.c.n_cells) * kMoveCols * sizeof(MoveEntry);   // the kernel's whole LDS image
-    if (lds_bytes > tune.mv_lds_max_bytes) return false;
-    // Four agents per lane halve the waves: that form needs tune.quad_min_lanes lanes (default: enough to put two waves
-    // on every SIMD); below that the two-agents-per-lane form of the same kernel runs.
+    const bool record = args.rec_local != nullptr;
+    const uint32_t A = uint32_t(n_agents);
     unsigned block = 0;
     int Q = 0, K = 0;
-    if (layout_fits(n_agents, 4, args, lds_bytes, &block, &Q) && args.n_envs * uint64_t(Q) >= tune.quad_min_lanes) K = 4;
-    else if (layout_fits(n_agents, 2, args, lds_bytes, &block, &Q)) K = 2;
-    else return false;
-    const bool record = args.rec_local != nullptr;
+    bool compact = false;
+    size_t lds_bytes = kMoveAt + size_t(args.c.n_cells) * kMoveCols * sizeof(MoveEntry);   // the kernel's whole LDS image
+    if (lds_bytes <= tune.mv_lds_max_bytes) {
+        // Four agents per lane halve the waves: that form needs tune.quad_min_lanes lanes (default: enough to put two
+        // waves on every SIMD); below that the two-agents-per-lane form of the same kernel runs.
+        if (layout_fits(n_agents, 4, args, lds_bytes, &block, &Q) && args.n_envs * uint64_t(Q) >= tune.quad_min_lanes) K = 4;
+        else if (layout_fits(n_agents, 2, args, lds_bytes, &block, &Q)) K = 2;
+        else return false;
+    } else {
+        // the full table is too large: 8-byte rows, one block per CU (512 threads = two waves per SIMD; 1024 when the
+        // batch gives every CU a block of that size), four agents per lane, group sizes 4 / 8 / 16 only
+        lds_bytes = kMoveAt + size_t(args.c.n_cells) * kCompactCols * kCompactEntry;
+        if (tune.mv_lds_max_bytes == 0 || lds_bytes > kLdsBytes - kLdsReserve) return false;
+        if (!layout_fits(n_agents, 4, args, lds_bytes, &block, &Q) || Q < 4) return false;
+        int n_cu = 256, dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
+        block = 512u;
+        if (args.n_envs % (1024u / unsigned(Q)) == 0 && args.n_envs * uint64_t(Q) >= uint64_t(n_cu) * 1024u) block = 1024u;
+        if (args.n_envs % (block / unsigned(Q)) != 0) return false;
+        K = 4;
+        compact = true;
+    }
     if (record && !(args.rec_reward && args.rec_prob && args.rec_done && args.rec_collision)) {
         *err = hipErrorInvalidValue;
         return true;
     }
-    const uint32_t A = uint32_t(n_agents);
-    if (K == 4) *err = record ? launch_rollout_lq_k4_r1(Q, args, A, block, lds_bytes, stream) : launch_rollout_lq_k4_r0(Q, args, A, block, lds_bytes, stream);
-    else *err = record ? launch_rollout_lq_k2_r1(Q, args, A, block, lds_bytes, stream) : launch_rollout_lq_k2_r0(Q, args, A, block, lds_bytes, stream);
+    if (K == 4) *err = record ? launch_rollout_lq_k4_r1(Q, compact, args, A, block, lds_bytes, stream) : launch_rollout_lq_k4_r0(Q, compact, args, A, block, lds_bytes, stream);
+    else *err = record ? launch_rollout_lq_k2_r1(Q, compact, args, A, block, lds_bytes, stream) : launch_rollout_lq_k2_r0(Q, compact, args, A, block, lds_bytes, stream);
     return true;
 }
 #endif
