@@ -76,6 +76,15 @@ template <typename T>
 __device__ __forceinline__ T lds_at(uint32_t byte_address) {
     return *(const __attribute__((address_space(3))) T *)(uintptr_t(byte_address));
 }
+// half-word H of x times a wave-uniform factor: ONE v_mul_u32_u24 with a word select (the compiler prefers to extract
+// the half-word first and fold the multiply into a v_mad: one instruction more per agent)
+template <int H>
+__device__ __forceinline__ uint32_t half_times(uint32_t x, uint32_t factor) {
+    uint32_t r;
+    if (H == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(r) : "v"(x), "v"(factor));
+    else asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(r) : "v"(x), "v"(factor));
+    return r;
+}
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ MoveEntry lds_entry_at(uint32_t byte_address) {   // one ds_read_b128
     const u32x4 v = lds_at<u32x4>(byte_address);
@@ -425,10 +434,13 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
         // --- my agents' table rows (cell * 96 + action * 16, the table's LDS offset is an immediate): requested first ...
         MoveEntry entry[K];
         u32x2 cells_code[K];
+        uint32_t row_bytes = COMPACT ? kCompactCols * kCompactEntry : kMoveCols * uint32_t(sizeof(MoveEntry));
+        asm volatile("" : "+v"(row_bytes));   // (one register for the loop; as an SGPR operand the assembler rejects the SDWA form)
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (COMPACT) cells_code[k] = lds_at<u32x2>(kMoveAt + (act[k] << 3) + __umul24(cur[k], kCompactCols * kCompactEntry));
-            else entry[k] = lds_entry_at(kMoveAt + (act[k] << 4) + __umul24(cur[k], kMoveCols * uint32_t(sizeof(MoveEntry))));
+            const uint32_t cell_at = (k & 1) ? half_times<1>(c[k / 2], row_bytes) : half_times<0>(c[k / 2], row_bytes);
+            if (COMPACT) cells_code[k] = lds_at<u32x2>(kMoveAt + (act[k] << 3) + cell_at);
+            else entry[k] = lds_entry_at(kMoveAt + (act[k] << 4) + cell_at);
         }
         STAMP(0);   // loop top: action fetch / policy, table read issue
         // --- ... then the previous step is finished while they are in flight
@@ -510,9 +522,9 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
 
         // --- outcome: the row (status for both criteria, reward for Makespan) is only REQUESTED here; everything the
         // next step's table address depends on is derived from `code` without waiting for it
-        const uint32_t row_at = kOutcomeAt + code * uint32_t(sizeof(OutcomeRow));
-        const uint32_t row_status = lds_at<uint32_t>(row_at + uint32_t(offsetof(OutcomeRow, status)));
-        double reward = lds_at<double>(row_at + uint32_t(offsetof(OutcomeRow, reward)));
+        const u32x4 row = lds_at<u32x4>(kOutcomeAt + code * uint32_t(sizeof(OutcomeRow)));   // {reward lo, hi, status, pad}
+        const uint32_t row_status = row.z;
+        double reward = __hiloint2double(int(row.y), int(row.x));
         const bool was_terminal = code > 7u;
         if (SOC) {
             // _living_reward: mapf_env.py:436-446
@@ -686,10 +698,13 @@ static bool layout_fits(int n_agents, int K, const RolloutArgs &args, size_t lds
     const int Q = n_agents / K;
     if (Q > 16 || (Q & (Q - 1)) != 0 || (K == 2 && Q < 2)) return false;
     const size_t copies = kLdsBytes / lds_bytes;   // blocks per CU by LDS
-    const unsigned block = copies >= 4 ? 256u : 512u;
-    const uint64_t per_block = block / unsigned(Q);
+    unsigned block = copies >= 4 ? 256u : 512u;
+    // a small batch is spread over the CUs in smaller blocks (down to one wave): every block stages its own table copy,
+    // which is cheap next to a rollout's steps, and an idle CU is not
     const uint64_t lanes = args.n_envs * uint64_t(Q);
-    if (args.n_envs % per_block != 0 || lanes < 64 * 256) return false;
+    while (block > 64u && lanes < 256u * uint64_t(block)) block /= 2u;
+    const uint64_t per_block = block / unsigned(Q);
+    if (args.n_envs % per_block != 0 || lanes < 64 * 16) return false;
     *block_out = block;
     *q_out = Q;
     return true;
@@ -705,10 +720,11 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
     bool compact = false;
     size_t lds_bytes = kMoveAt + size_t(args.c.n_cells) * kMoveCols * sizeof(MoveEntry);   // the kernel's whole LDS image
     if (lds_bytes <= tune.mv_lds_max_bytes) {
-        // Four agents per lane halve the waves: that form needs tune.quad_min_lanes lanes (default: enough to put two
-        // waves on every SIMD); below that the two-agents-per-lane form of the same kernel runs.
-        if (layout_fits(n_agents, 4, args, lds_bytes, &block, &Q) && args.n_envs * uint64_t(Q) >= tune.quad_min_lanes) K = 4;
-        else if (layout_fits(n_agents, 2, args, lds_bytes, &block, &Q)) K = 2;
+        // Four agents per lane halve the waves: that form needs tune.quad_min_lanes lanes (default: enough to put one
+        // wave on every SIMD); below that the two-agents-per-lane form of the same kernel runs.
+        if (tune.force_k != 2 && layout_fits(n_agents, 4, args, lds_bytes, &block, &Q) &&
+            (tune.force_k == 4 || args.n_envs * uint64_t(Q) >= tune.quad_min_lanes)) K = 4;
+        else if (tune.force_k != 4 && layout_fits(n_agents, 2, args, lds_bytes, &block, &Q)) K = 2;
         else return false;
     } else {
         // the full table is too large: 8-byte rows, one block per CU (512 threads = two waves per SIMD; 1024 when the

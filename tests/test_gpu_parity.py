@@ -390,11 +390,11 @@ def _goal_scenario_tables(n_agents, n_envs, seed):
 
 
 @pytest.mark.parametrize('n_agents,n_envs,layout,env_vars', [
-    (4, 16384, 'lq_rollout_kernel<Q=1,K=4', {}), (4, 16512, 'lq_rollout_kernel<Q=2,K=2', {}),
-    (8, 8192, 'lq_rollout_kernel<Q=2,K=4', {}), (8, 16448, 'lq_rollout_kernel<Q=4,K=2', {}),
+    (4, 16384, 'lq_rollout_kernel<Q=1,K=4', {'MAPF_LQ_K': '4'}), (4, 16512, 'lq_rollout_kernel<Q=2,K=2', {'MAPF_LQ_K': '2'}),
+    (8, 8192, 'lq_rollout_kernel<Q=2,K=4', {'MAPF_LQ_K': '4'}), (8, 16448, 'lq_rollout_kernel<Q=4,K=2', {'MAPF_LQ_K': '2'}),
     (8, 16448, 'lg_rollout_kernel<L=4,FULL,MV_LDS', {'MAPF_QUAD_LANES': '0'}),
-    (16, 4096, 'lq_rollout_kernel<Q=4,K=4', {}), (16, 4128, 'lq_rollout_kernel<Q=8,K=2', {}),
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4', {}), (32, 1024, 'lq_rollout_kernel<Q=16,K=2', {}),
+    (16, 4096, 'lq_rollout_kernel<Q=4,K=4', {'MAPF_LQ_K': '4'}), (16, 4128, 'lq_rollout_kernel<Q=8,K=2', {'MAPF_LQ_K': '2'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4', {'MAPF_LQ_K': '4'}), (32, 1024, 'lq_rollout_kernel<Q=16,K=2', {'MAPF_LQ_K': '2'}),
     (32, 1024, 'lg_rollout_kernel<L=16,FULL,MV_GLOBAL', {'MAPF_MV_LDS_MAX_BYTES': '0'}),
     # (a full table "too large" for the LDS budget: the 8-byte-row form of the packed kernel, 512- and 1024-thread blocks)
     (16, 4096, 'lq_rollout_kernel<Q=4,K=4,RECORD,STREAM,MAKESPAN,COMPACT> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
