@@ -113,7 +113,10 @@ hipError_t launch_query_terminal(int n_agents, const uint16_t *state, const uint
 
 // lane-group family (mapf_lg_kernels.hip): any A up to 128, run-time A
 constexpr int kTpeMaxAgents = 16;         // thread-per-env step kernels are specialised for A = 1..16
-constexpr int kTpeRolloutMaxAgents = 6;   // ... their rollout form is dispatched only where it is spill-free
+#ifndef MAPF_TPE_ROLLOUT_MAX              // (tools/exp/tpe_spill_repro.sh builds a library that dispatches the spilling ones)
+#define MAPF_TPE_ROLLOUT_MAX 6
+#endif
+constexpr int kTpeRolloutMaxAgents = MAPF_TPE_ROLLOUT_MAX;   // ... their rollout form is dispatched only where it is spill-free
 // Layout choices of the fused rollout, fixed per handle at mapf_create (environment overrides are read there, so a
 // process can hold handles with different settings -- the tests do).
 struct RolloutTuning {

@@ -240,14 +240,14 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
     const uint32_t lane_cell = e * n_agents + uint32_t(K) * x.g;    // my first agent's element index
     const uint32_t fixed_cell = uint32_t(K) * x.g;                  // ... in a broadcast row
 
-    uint32_t c[P], g[P], st[P];
+    uint32_t c[P], g[P], start_c[P];
     {
         const Packed<P> cells = Packed<P>::load(at(p.state, lane_cell));
         const Packed<P> gl = Packed<P>::load(at(p.goal, p.goal_broadcast ? fixed_cell : lane_cell));
         Packed<P> sc{};
         if (p.auto_reset) sc = Packed<P>::load(at(p.start, p.start_broadcast ? fixed_cell : lane_cell));
 #pragma unroll
-        for (int i = 0; i < P; ++i) { c[i] = cells.v[i]; g[i] = gl.v[i]; st[i] = sc.v[i]; }
+        for (int i = 0; i < P; ++i) { c[i] = cells.v[i]; g[i] = gl.v[i]; start_c[i] = sc.v[i]; }
     }
     {   // move table -> LDS with six columns per cell (0..4 = the actions, 5 = STAY again: where out-of-range action
         // bytes are clamped to), batches of four independent loads per thread
@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
     stage_slip_table(p.slip, slip);   // ends with __syncthreads()
 
     uint32_t terminal = packed_is_terminal<Q, P>(x, c, g) ? 1u : 0u;
-    const uint32_t start_terminal = (p.auto_reset && packed_is_terminal<Q, P>(x, st, g)) ? 1u : 0u;
+    const uint32_t start_terminal = (p.auto_reset && packed_is_terminal<Q, P>(x, start_c, g)) ? 1u : 0u;
     // Every select of the reset logic compares the env's integer code against a wave-uniform constant:
     // (code ^ 4) > 0 <=> the step ended the episode (or the env was terminal already); with auto-reset off the
     // threshold is unreachable, so "reset" never fires and the state simply stays where the step left it.
@@ -560,7 +560,7 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
         const uint32_t ended = code ^ 4u;
         const bool back = ended > reset_above;                 // never with auto-reset off
 #pragma unroll
-        for (int i = 0; i < P; ++i) c[i] = back ? st[i] : n[i];
+        for (int i = 0; i < P; ++i) c[i] = back ? start_c[i] : n[i];
         terminal = back ? start_terminal : min(ended & 13u, 1u);
         STAMP(7);   // reset handling
     };

@@ -13,7 +13,7 @@ import bench  # noqa: E402
 from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv  # noqa: E402
 
 E, A, T = 65536, 8, 64
-grid, nbr, start, goal = bench.workload_tables(E, 0)
+grid, _, nbr, start, goal = bench.workload_tables(bench.CONFIGS['c3'], E, 0)
 env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=42,
                  start_local=start, goal_local=goal)
 acts = env.fill_random_actions(0, T)

@@ -20,13 +20,13 @@ from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv  # noqa: 
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-E, A = 65536, bench.N_AGENTS
-grid, nbr, start, goal = bench.workload_tables(E, 0)
+E, A = 65536, bench.CONFIGS['c3']['agents']
+grid, _, nbr, start, goal = bench.workload_tables(bench.CONFIGS['c3'], E, 0)
 bits = lambda x: np.ascontiguousarray(x).view(np.uint64)  # noqa: E731
 for crit, ocrit in ((OptimizationCriteria.Makespan, mo.MAKESPAN), (OptimizationCriteria.SoC, mo.SOC)):
-    env = VecMapfEnv(grid, A, None, None, bench.FAIL_PROB, bench.R_CLASH, bench.R_GOAL, bench.R_LIVING, crit, seed=bench.SEED,
+    env = VecMapfEnv(grid, A, None, None, bench.CONFIGS['c3']['fail_prob'], bench.R_CLASH, bench.R_GOAL, bench.R_LIVING, crit, seed=bench.SEED,
                      start_local=start, goal_local=goal)
-    co = c_oracle.COracle(nbr, A, start, goal, bench.FAIL_PROB, bench.R_CLASH, bench.R_GOAL, bench.R_LIVING, ocrit, seed=bench.SEED)
+    co = c_oracle.COracle(nbr, A, start, goal, bench.CONFIGS['c3']['fail_prob'], bench.R_CLASH, bench.R_GOAL, bench.R_LIVING, ocrit, seed=bench.SEED)
     acc, t0, done = None, time.time(), 0
     while done < steps:
         n = min(T, steps - done)

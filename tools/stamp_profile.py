@@ -24,7 +24,7 @@ if 'stamps' not in os.environ.get('MAPF_HIP_LIB', ''):
     raise SystemExit('set MAPF_HIP_LIB to the stamps build (see the docstring)')
 E, A, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 65536), 8, 64
 # envs per wave: 32 in the quad-lane layout (default), 16 in the pair layout (MAPF_QUAD_LANES=0)
-PER_WAVE = 16 if os.environ.get('MAPF_QUAD_LANES') == '0' else 32
+PER_WAVE = 16 if os.environ.get('MAPF_QUAD_LANES') == '0' or os.environ.get('MAPF_LQ_K') == '2' else 32
 print('layout: %s' % ('pair (2 agents per lane)' if PER_WAVE == 16 else 'quad (4 agents per lane)'))
 grid, _, nbr, start, goal = bench.workload_tables(bench.CONFIGS['c3'], E, 0)
 print('envs: %d' % E)
@@ -40,7 +40,7 @@ else:
              'sampling (table wait) + probability read', 'pair tests', 'flags + group reduce', 'outcome request',
              'reset handling']
 for acts, label in ((actions, 'streamed actions'), (None, 'in-kernel policy')):
-    for record in (True, False):
+    for record in (True,):   # (the stamps build instruments the recording kernels only)
         env.reset()
         env.rollout(T, actions=acts, auto_reset=True, record=record)
         res = env.rollout(T, actions=acts, auto_reset=True, record=record)
