@@ -119,6 +119,15 @@ __device__ __forceinline__ void pair_apply_same(uint32_t pk_prev, uint32_t pk_ne
     }
 }
 
+// value held by lane (g + S) mod Q of my group.  Groups of 2, 4 and 16 lanes rotate with one DPP move; a group of 8
+// would need two DPP moves and a select per value (a 16-lane row holds two groups), so it goes through the LDS
+// crossbar instead: one ds_bpermute_b32 per value, all of a round's values in flight together
+template <int Q, int S>
+__device__ __forceinline__ uint32_t packed_rot(uint32_t v, const LaneCtx<Q> &x) {
+    if constexpr (Q == 8) return uint32_t(__builtin_amdgcn_ds_bpermute(int((x.base + ((x.g + uint32_t(S)) & 7u)) << 2), int(v)));
+    else return group_rot<Q, S>(v, x);
+}
+
 // full rotations 1 .. Q/2-1: my pairs against every pair of group position g + S
 template <int Q, int P, int S, bool DUP, bool MOVES>
 struct PackedRounds {
@@ -127,8 +136,8 @@ struct PackedRounds {
         if constexpr (S <= Q / 2 - 1) {
 #pragma unroll
             for (int j = 0; j < P; ++j) {
-                const uint32_t oc = group_rot<Q, S>(c[j], x);
-                const uint32_t on = MOVES ? group_rot<Q, S>(n[j], x) : 0u;
+                const uint32_t oc = packed_rot<Q, S>(c[j], x);
+                const uint32_t on = MOVES ? packed_rot<Q, S>(n[j], x) : 0u;
 #pragma unroll
                 for (int i = 0; i < P; ++i) pair_apply_packed<DUP, MOVES>(c[i], n[i], oc, on, acc);
             }
@@ -169,8 +178,8 @@ __device__ __forceinline__ PairAcc<true> packed_pair_tests(const LaneCtx<Q> &x, 
         const bool lower = x.g < uint32_t(Q / 2);
 #pragma unroll
         for (int j = 0; j < P; ++j) {
-            const uint32_t oc = group_rot<Q, Q / 2>(lower ? csw[j] : c[j], x);
-            const uint32_t on = MOVES ? group_rot<Q, Q / 2>(lower ? nsw[j] : n[j], x) : 0u;
+            const uint32_t oc = packed_rot<Q, Q / 2>(lower ? csw[j] : c[j], x);
+            const uint32_t on = MOVES ? packed_rot<Q, Q / 2>(lower ? nsw[j] : n[j], x) : 0u;
 #pragma unroll
             for (int i = 0; i < P; ++i) pair_apply_same<DUP, MOVES>(c[i], n[i], oc, on, acc);
         }
