@@ -621,13 +621,13 @@ int mapf_fill_random_actions(mapf_handle_t h, uint8_t *actions, uint64_t t0, uin
     return MAPF_OK;
 }
 
-int mapf_transitions(mapf_handle_t h, uint64_t n_queries, const uint16_t *local, const uint8_t *actions,
-                     const uint32_t *env_index, uint32_t max_branches, uint32_t *out_count, uint16_t *out_next,
+int mapf_transitions_window(mapf_handle_t h, uint64_t n_queries, const uint16_t *local, const uint8_t *actions,
+                            const uint32_t *env_index, uint64_t first_branch, uint32_t max_branches, uint32_t *out_count, uint16_t *out_next,
                      double *out_prob, double *out_reward, uint8_t *out_done, uint8_t *out_collision) {
     if (int rc = check_handle(h)) return rc;
     if (!local || !actions) return fail(MAPF_EINVAL, "local / actions are null");
     if (max_branches == 0) return fail(MAPF_EINVAL, "max_branches must be >= 1");
-    if (h->A > uint32_t(mapf::kTransitionsMaxAgents)) return fail(MAPF_EUNSUPPORTED, "mapf_transitions supports n_agents <= 8 (3^A branches per query)");
+    if (h->A > uint32_t(mapf::kTransitionsMaxAgents)) return fail(MAPF_EUNSUPPORTED, "mapf_transitions supports n_agents <= 16 (3^A branches per query)");
     const size_t N = size_t(n_queries), NA = N * h->A, NM = N * max_branches;
     if (!h->device_ptrs) {
         for (size_t i = 0; i < NA; ++i) if (local[i] >= h->V) return fail(MAPF_EINVAL, "transitions: cell out of range");
@@ -635,7 +635,7 @@ int mapf_transitions(mapf_handle_t h, uint64_t n_queries, const uint16_t *local,
     }
     mapf::TransitionsArgs a{};
     a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.goal = h->goal; a.goal_broadcast = h->goal_broadcast;
-    a.n_queries = n_queries; a.max_branches = max_branches; a.n_agents = h->A;
+    a.n_queries = n_queries; a.max_branches = max_branches; a.n_agents = h->A; a.first_branch = first_branch;
     if (int rc = stage_in(h, h->q_local, local, NA, &a.local, "local")) return rc;
     if (int rc = stage_in(h, h->q_actions, actions, NA, &a.actions, "actions")) return rc;
     if (int rc = stage_in(h, h->q_env, env_index, N, &a.env_index, "env_index")) return rc;
@@ -654,6 +654,13 @@ int mapf_transitions(mapf_handle_t h, uint64_t n_queries, const uint16_t *local,
     if (int rc = fetch_out(h, a.out_collision, out_collision, NM)) return rc;
     if (!h->device_ptrs) HIP_TRY(hipStreamSynchronize(h->stream));
     return MAPF_OK;
+}
+
+int mapf_transitions(mapf_handle_t h, uint64_t n_queries, const uint16_t *local, const uint8_t *actions,
+                     const uint32_t *env_index, uint32_t max_branches, uint32_t *out_count, uint16_t *out_next,
+                     double *out_prob, double *out_reward, uint8_t *out_done, uint8_t *out_collision) {
+    return mapf_transitions_window(h, n_queries, local, actions, env_index, 0, max_branches, out_count, out_next, out_prob,
+                                   out_reward, out_done, out_collision);
 }
 
 int mapf_transition_rewards(mapf_handle_t h, uint64_t n_queries, const uint16_t *prev_local, const uint8_t *actions,

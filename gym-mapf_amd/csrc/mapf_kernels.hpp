@@ -92,10 +92,11 @@ struct TransitionsArgs {
     double *out_prob, *out_reward; // [N*M]
     uint8_t *out_done, *out_collision;
     uint64_t n_queries;
+    uint64_t first_branch;         // first branch of the returned window (0 = from the start)
     uint32_t max_branches, n_agents;
     bool goal_broadcast;
 };
-constexpr int kTransitionsMaxAgents = 8;    // 3^8 = 6561 branches per query; beyond that the enumeration is impractical
+constexpr int kTransitionsMaxAgents = 16;   // 3^16 = 43 M branches per query, returned in windows
 hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream);
 // calc_transition_reward_from_local_states for N (prev = args.local, args.actions, next) triples; fills
 // args.out_reward / out_done / out_collision [N] (max_branches, out_count, out_next, out_prob unused)

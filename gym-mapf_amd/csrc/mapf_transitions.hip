@@ -6,6 +6,8 @@
 // k_i = digit i of b in the mixed radix (n_0, ..., n_{A-1}).  prob is the left-to-right float64 product of the
 // selected probabilities (functools.reduce at :467); reward / done / collision come from the same rules as
 // step() (:225-235).  A terminal state has the single branch ((1.0, False), s, 0, True) (:455-456).
+// A call returns the WINDOW [first_branch, first_branch + max_branches) of every query's enumeration, so a caller
+// pages through the 3^A branches of a large team in pieces (A <= 16: at most 43 M branches per query).
 #include "mapf_kernels.hpp"
 #include "mapf_device.hpp"
 
@@ -17,7 +19,8 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
     stage_slip_table(p.slip, slip);
     const uint64_t gid = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const uint64_t q = gid / p.max_branches;
-    const uint32_t b = uint32_t(gid - q * p.max_branches);
+    const uint32_t slot = uint32_t(gid - q * p.max_branches);   // output row of the query's window
+    const uint64_t b = p.first_branch + slot;                    // branch index in the query's full enumeration
     if (q >= p.n_queries) return;
     const uint32_t A = p.n_agents;
     const uint64_t env = p.env_index ? p.env_index[q] : 0;
@@ -47,10 +50,10 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
         for (int j = i + 1; j < MAXA; ++j) dup_acc = min(dup_acc, prev[i] ^ prev[j]);
     const bool terminal = dup_acc == 0u || goal_acc == 0u;           // is_terminal: mapf_env.py:210-223
     if (terminal) count = 1;
-    if (b == 0 && p.out_count) p.out_count[q] = uint32_t(count > 0xFFFFFFFFull ? 0xFFFFFFFFull : count);
-    if (uint64_t(b) >= count) return;
+    if (slot == 0 && p.out_count) p.out_count[q] = uint32_t(count > 0xFFFFFFFFull ? 0xFFFFFFFFull : count);
+    if (b >= count) return;
 
-    const uint64_t o = q * p.max_branches + b;
+    const uint64_t o = q * p.max_branches + slot;
     if (terminal) {
         if (p.out_next) for (uint32_t i = 0; i < A; ++i) p.out_next[o * A + i] = uint16_t(prev[i]);
         if (p.out_prob) p.out_prob[o] = 1.0;
@@ -61,9 +64,9 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
     }
     // digits of b, last agent fastest
     uint32_t k[MAXA];
-    uint32_t rest = b;
+    uint64_t rest = b;
 #pragma unroll
-    for (int i = MAXA - 1; i >= 0; --i) { k[i] = rest % n[i]; rest /= n[i]; }
+    for (int i = MAXA - 1; i >= 0; --i) { k[i] = uint32_t(rest % n[i]); rest /= n[i]; }
 
     uint32_t next[MAXA];
     double prob = 1.0;
@@ -149,6 +152,7 @@ hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream) {
     const dim3 grid{unsigned(grid64)}, block{256};
     if (args.n_agents <= 4) hipLaunchKernelGGL(transitions_kernel<4>, grid, block, 0, stream, args);
     else if (args.n_agents <= 8) hipLaunchKernelGGL(transitions_kernel<8>, grid, block, 0, stream, args);
+    else if (args.n_agents <= 16) hipLaunchKernelGGL(transitions_kernel<16>, grid, block, 0, stream, args);
     else return hipErrorInvalidValue;
     return hipGetLastError();
 }

@@ -52,6 +52,8 @@ SIGNATURES = {
     'mapf_set_policy': (c_int, [c_void_p, c_int, c_void_p]),
     'mapf_transitions': (c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p]),
+    'mapf_transitions_window': (c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_void_p, c_void_p]),
     'mapf_transition_rewards': (c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mapf_query_terminal': (c_int, [c_void_p, c_void_p]),
     'mapf_get_state': (c_int, [c_void_p, c_void_p, POINTER(c_uint64)]),

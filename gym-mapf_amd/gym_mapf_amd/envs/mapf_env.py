@@ -267,14 +267,18 @@ class MapfEnv(_EnvBase):
         """All branches of taking joint action ``a`` in joint state ``s``, in the reference's order
         (mapf_env.py:448-478); enumerated by the ``mapf_transitions`` kernel."""
         n, V = self.n_agents, len(self.valid_locations)
-        local = integer_to_vector(s, [V] * n, n, lambda x: x)
-        digits = integer_to_vector(a, [len(ACTIONS)] * n, n, lambda x: x)
-        res = self._device().transitions(np.asarray([local], dtype=np.uint16), np.asarray([digits], dtype=np.uint8))
-        out = []
-        for b in range(int(res['count'][0])):
-            nxt = vector_to_integer(tuple(int(c) for c in res['next'][0, b]), [V] * n, lambda x: x)
-            out.append(((float(res['prob'][0, b]), bool(res['collision'][0, b])), nxt,
-                        float(res['reward'][0, b]), bool(res['done'][0, b])))
+        local = np.asarray([integer_to_vector(s, [V] * n, n, lambda x: x)], dtype=np.uint16)
+        digits = np.asarray([integer_to_vector(a, [len(ACTIONS)] * n, n, lambda x: x)], dtype=np.uint8)
+        window = min(3 ** n, 1 << 16)              # large teams: the 3^n branches are fetched window by window
+        out, first, count = [], 0, 1
+        while first < count:
+            res = self._device().transitions(local, digits, max_branches=window, first_branch=first)
+            count = int(res['count'][0])
+            for b in range(min(window, count - first)):
+                nxt = vector_to_integer(tuple(int(c) for c in res['next'][0, b]), [V] * n, lambda x: x)
+                out.append(((float(res['prob'][0, b]), bool(res['collision'][0, b])), nxt,
+                            float(res['reward'][0, b]), bool(res['done'][0, b])))
+            first += window
         return out
 
     def _locals_query(self, *rows):

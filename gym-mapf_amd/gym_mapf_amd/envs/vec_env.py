@@ -250,12 +250,13 @@ class VecMapfEnv:
         nat.check(self._lib.mapf_rollout(self._h, ctypes.byref(io)))
         return res
 
-    def transitions(self, local, actions, max_branches=None, env_index=None):
+    def transitions(self, local, actions, max_branches=None, env_index=None, first_branch=0):
         """``env.P[s][a]`` for N (state, joint action) queries (reference mapf_env.py:448-478): every branch of the
         joint slip distribution in the reference's order.  ``local`` uint16 [N, A], ``actions`` uint8 [N, A],
-        ``env_index`` uint32 [N] picks whose goals apply (default env 0).  Returns a dict: ``count`` uint32 [N] and,
-        padded to ``max_branches`` rows per query (default 3**A), ``next`` uint16 [N, M, A], ``prob`` / ``reward``
-        float64 [N, M], ``done`` / ``collision`` uint8 [N, M].  Rows >= count[q] are unspecified."""
+        ``env_index`` uint32 [N] picks whose goals apply (default env 0).  Returns a dict: ``count`` uint32 [N] (always
+        the full number of branches) and, for the window of ``max_branches`` branches (default 3**A) that starts at
+        ``first_branch``, ``next`` uint16 [N, M, A], ``prob`` / ``reward`` float64 [N, M], ``done`` / ``collision``
+        uint8 [N, M].  Rows whose branch index is >= count[q] are unspecified.  Up to 16 agents."""
         A = self.n_agents
         local = np.asarray(local) if not self.device_arrays else local
         N = int(local.shape[0])
@@ -266,9 +267,9 @@ class VecMapfEnv:
         res = {'count': self._empty((N,), np.uint32), 'next': self._empty((N, M, A), np.uint16),
                'prob': self._empty((N, M), np.float64), 'reward': self._empty((N, M), np.float64),
                'done': self._empty((N, M), np.uint8), 'collision': self._empty((N, M), np.uint8)}
-        nat.check(self._lib.mapf_transitions(
+        nat.check(self._lib.mapf_transitions_window(
             self._h, N, self._ptr(local, np.uint16, (N, A), 'local'), self._ptr(actions, np.uint8, (N, A), 'actions'),
-            self._ptr(env_index, np.uint32, (N,), 'env_index'), M, self._ptr(res['count'], np.uint32, (N,), 'count'),
+            self._ptr(env_index, np.uint32, (N,), 'env_index'), int(first_branch), M, self._ptr(res['count'], np.uint32, (N,), 'count'),
             self._ptr(res['next'], np.uint16, (N, M, A), 'next'), self._ptr(res['prob'], np.float64, (N, M), 'prob'),
             self._ptr(res['reward'], np.float64, (N, M), 'reward'), self._ptr(res['done'], np.uint8, (N, M), 'done'),
             self._ptr(res['collision'], np.uint8, (N, M), 'collision')))

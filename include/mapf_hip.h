@@ -173,12 +173,19 @@ int mapf_set_policy(mapf_handle_t h, int policy, const uint32_t *cell_rc);
  *   max_branches M: rows reserved per query (3^A always suffices); out_count u32[N] reports the true number
  *   out_next u16[N*M*A], out_prob f64[N*M], out_reward f64[N*M], out_done u8[N*M], out_collision u8[N*M]
  * Rows b >= out_count[q] are left untouched.  A terminal state yields one branch (prob 1.0, reward 0, done).
- * Supported for n_agents <= 8 (3^A branches per query; planners decompose larger problems with
- * get_local_view).  Any out_* may be NULL.
+ * Supported for n_agents <= 16 (3^A branches per query: up to 43 M -- page through them with
+ * mapf_transitions_window; planners decompose larger problems with get_local_view).  Any out_* may be NULL.
  */
 int mapf_transitions(mapf_handle_t h, uint64_t n_queries, const uint16_t *local, const uint8_t *actions,
                      const uint32_t *env_index, uint32_t max_branches, uint32_t *out_count, uint16_t *out_next,
                      double *out_prob, double *out_reward, uint8_t *out_done, uint8_t *out_collision);
+/* The same enumeration, one WINDOW at a time: row j of query q's outputs holds branch first_branch + j (rows whose
+ * branch index is >= out_count[q] are left untouched); out_count always reports the full branch count.  The reference
+ * builds the whole list at once (mapf_env.py:465-476); for more than ~8 agents that list does not fit anywhere. */
+int mapf_transitions_window(mapf_handle_t h, uint64_t n_queries, const uint16_t *local, const uint8_t *actions,
+                            const uint32_t *env_index, uint64_t first_branch, uint32_t max_branches, uint32_t *out_count,
+                            uint16_t *out_next, double *out_prob, double *out_reward, uint8_t *out_done,
+                            uint8_t *out_collision);
 
 /*
  * MapfEnv.calc_transition_reward_from_local_states (mapf_env.py:225-235, with _living_reward :436-446 and

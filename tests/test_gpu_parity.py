@@ -617,6 +617,54 @@ def test_transitions_random_queries_against_oracle(n_agents, criteria):
     env.close()
 
 
+def test_transitions_of_large_teams_come_in_windows():
+    """env.P for more than 8 agents (reference mapf_env.py:448-478 has no limit): the 3^A branches of a query are
+    fetched window by window (mapf_transitions_window); the concatenation equals the pinned Python oracle's
+    enumeration, whatever the window size, and MapfEnv.P pages through them by itself."""
+    from gym_mapf_amd.envs.mapf_env import MapfEnv
+    rs = np.random.RandomState(91)
+    lines = ['.....', '..@..', '.....', '.....']
+    grid = MapfGrid(lines)
+    valid = grid.tables()[0]
+    V, A = len(valid), 9
+    start = rs.choice(V, A, replace=False).astype(np.uint16)
+    goal = rs.choice(V, A, replace=False).astype(np.uint16)
+    env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.SoC, start_local=start, goal_local=goal)
+    orc = mo.OracleEnv(lines, A, [valid[c] for c in start], [valid[c] for c in goal], 0.2, -1000.0, 100.0, -1.0, mo.SOC)
+    acts = rs.randint(0, 5, size=(1, A)).astype(np.uint8)
+    exp = orc.transitions(tuple(int(c) for c in start), acts[0].tolist())
+    assert len(exp) > 2000                                   # several windows below
+    for window in (4096, 1000):
+        got, first = [], 0
+        while first < len(exp):
+            res = env.transitions(start.reshape(1, A), acts, max_branches=window, first_branch=first)
+            assert int(res['count'][0]) == len(exp)
+            k = min(window, len(exp) - first)
+            got += [(res['next'][0, b].tolist(), res['prob'][0, b], res['reward'][0, b], bool(res['done'][0, b]),
+                     bool(res['collision'][0, b])) for b in range(k)]
+            first += window
+        for (nxt, p, r, d, c), ((ep, ec), enxt, er, ed) in zip(got, exp):
+            assert nxt == list(enxt) and _bits(p) == _bits(ep) and _bits(r) == _bits(er) and (d, c) == (ed, ec)
+    env.close()
+    # 12 agents through the scalar API: MapfEnv.P pages by itself (window 65536 < 3^12 possible branches)
+    lines = ['......', '......', '......']
+    starts = tuple((r, c) for r in range(2) for c in range(6))
+    goals = tuple((2 - r, 5 - c) for r in range(2) for c in range(6))
+    menv = MapfEnv(MapfGrid(lines), 12, starts, goals, 0.1, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan)
+    orc = mo.OracleEnv(lines, 12, list(starts), list(goals), 0.1, -1000.0, 100.0, -1.0, mo.MAKESPAN)
+    digits = [2] * 11 + [0]
+    joint = sum(d * 5 ** i for i, d in enumerate(digits))
+    got = menv.P[menv.s][joint]
+    exp = orc.transitions(tuple(orc.start), digits)
+    assert len(got) == len(exp) > 65536
+    for k in (0, 1, 65535, 65536, 65537, len(exp) - 1):
+        ((p, c), s_next, r, d), ((ep, ec), enxt, er, ed) = got[k], exp[k]
+        assert _bits(p) == _bits(ep) and _bits(r) == _bits(er) and (d, c) == (ed, ec)
+        assert s_next == mo.encode_mixed_radix(enxt, orc.V)
+    assert abs(sum(t[0][0] for t in got) - 1.0) < 1e-9
+    menv.close()
+
+
 # ----------------------------------------------------------------------- edge cases of the boundary
 def test_empty_batch_and_single_cell_map():
     """E = 0 handles are legal no-ops; a 1-cell map with one agent is terminal from the start (start == goal)."""
