@@ -88,6 +88,7 @@ struct mapf_handle_s {
     // The thread-per-env rollout specialisations for A >= 8 need SGPR spills (the pointer-heavy argument block
     // plus A-wide unrolling); only spill-free kernels are dispatched, so those sizes use the lane-group rollout.
     bool lane_group_rollout = false;
+    bool start_terminal_any = true;   // is_terminal(start) for some env (looked up once at create)
     mapf::RolloutTuning tune;
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -370,7 +371,15 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
     if (n_start) CREATE_TRY(hipMemcpy(h->start, d->start, n_start * sizeof(uint16_t), hipMemcpyHostToDevice));
     if (n_goal) CREATE_TRY(hipMemcpy(h->goal, d->goal, n_goal * sizeof(uint16_t), hipMemcpyHostToDevice));
     CREATE_TRY(mapf::launch_reset(int(A), h->state, h->start, sb, nullptr, E, h->stream));
-    CREATE_TRY(hipStreamSynchronize(h->stream));
+    {   // is any env's start state terminal?  (the rollout kernels specialise on "no": state == start right now)
+        std::vector<uint8_t> flags(E ? E : 1, 0);
+        CREATE_TRY(h->s_term.reserve(E ? E : 1));
+        CREATE_TRY(mapf::launch_query_terminal(int(A), h->state, h->goal, gb, static_cast<uint8_t *>(h->s_term.ptr), E, h->stream));
+        if (E) CREATE_TRY(hipMemcpyAsync(flags.data(), h->s_term.ptr, E, hipMemcpyDeviceToHost, h->stream));
+        CREATE_TRY(hipStreamSynchronize(h->stream));
+        h->start_terminal_any = false;
+        for (uint64_t e = 0; e < E; ++e) h->start_terminal_any |= flags[e] != 0;
+    }
 #undef CREATE_TRY
     *out_handle = h;
     return MAPF_OK;
@@ -521,6 +530,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     a.start_broadcast = h->start_broadcast; a.goal_broadcast = h->goal_broadcast;
     a.auto_reset = io->step_flags & MAPF_STEP_AUTO_RESET;
     a.accumulate = io->accumulate != 0;
+    a.start_terminal_any = h->start_terminal_any;
     if (h->device_ptrs) {
         for (const void *p : {(const void *)io->actions, (const void *)io->out_returns, (const void *)io->out_episodes,
                               (const void *)io->out_collisions, (const void *)io->rec_local, (const void *)io->rec_reward,

@@ -72,6 +72,7 @@ struct RolloutArgs {
     uint64_t n_envs, env_id_offset, t;
     uint32_t n_steps;
     bool start_broadcast, goal_broadcast, auto_reset, accumulate;
+    bool start_terminal_any;       // some env's START state is terminal (two starts coincide / every start is its goal)
 };
 
 // Every launcher names the kernel instance (and block size) that took the launch; the C ABI keeps the name of a

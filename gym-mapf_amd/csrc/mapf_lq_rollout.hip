@@ -229,7 +229,10 @@ constexpr uint32_t kSlipAt = 0, kOutcomeAt = sizeof(SlipRow) * 8, kMoveAt = kLds
 constexpr uint32_t kCompactCols = 5, kCompactEntry = 8;   // COMPACT: cells + code only, no sixth column
 static_assert(kOutcomeAt + sizeof(OutcomeRow) * 16 <= kMoveAt, "LDS image: slip rows, outcome rows, then the move table");
 
-template <int Q, int K, bool RECORD, bool STREAM, bool SOC, bool COMPACT>
+// TERM = an env may be terminal when a step begins.  With auto-reset on and no env whose START state is itself
+// terminal (the handle knows: mapf_create looks) that cannot happen after the launch's first step -- a done env is back
+// on its start cells -- and the !TERM instance runs every later step without the was-terminal selects.
+template <int Q, int K, bool RECORD, bool STREAM, bool SOC, bool COMPACT, bool TERM>
 __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
     constexpr int P = K / 2;   // packed dwords per lane
     static_assert(K == 2 || K == 4, "two or four agents per lane");
@@ -403,9 +406,12 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
     // (word picked at run time, call refreshed when t is a multiple of four).  FIRST = the launch's first step: nothing
     // is pending yet and the slip call is refreshed whatever t is.  TAIL = the action rows run out within two steps, so
     // the prefetch address is clamped.  `raw` is the register that holds this step's action word.
+    uint32_t row_bytes = COMPACT ? kCompactCols * kCompactEntry : kMoveCols * uint32_t(sizeof(MoveEntry));
+    asm volatile("" : "+v"(row_bytes));   // (one register for the whole loop; as an SGPR operand the assembler rejects the SDWA form)
     auto one_step = [&](const uint32_t s, uint32_t &raw, auto w_tag, auto first_tag, auto tail_tag) __attribute__((always_inline)) {
         constexpr int W = decltype(w_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value, TAIL = decltype(tail_tag)::value;
+        constexpr bool MAYBE_TERMINAL = TERM || FIRST;   // (the launch's first step finds whatever state the last launch left)
         const uint64_t t = p.t + s;
         uint32_t cur[K], act[K];
 #pragma unroll
@@ -443,8 +449,6 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
         // --- my agents' table rows (cell * 96 + action * 16, the table's LDS offset is an immediate): requested first ...
         MoveEntry entry[K];
         u32x2 cells_code[K];
-        uint32_t row_bytes = COMPACT ? kCompactCols * kCompactEntry : kMoveCols * uint32_t(sizeof(MoveEntry));
-        asm volatile("" : "+v"(row_bytes));   // (one register for the loop; as an SGPR operand the assembler rejects the SDWA form)
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t cell_at = (k & 1) ? half_times<1>(c[k / 2], row_bytes) : half_times<0>(c[k / 2], row_bytes);
@@ -526,7 +530,7 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
         bits |= bits >> 16;
         uint32_t flags = (min(away, 1u) << 2) | bits;
         flags = group_reduce<Q, false>(flags, x);
-        const uint32_t code = (flags & 7u) | (terminal << 3);   // terminal is 0 / 1
+        const uint32_t code = MAYBE_TERMINAL ? (flags & 7u) | (terminal << 3) : (flags & 7u);   // terminal is 0 / 1
         STAMP(5);   // flags + group reduce
 
         // --- outcome: the row (status for both criteria, reward for Makespan) is only REQUESTED here; everything the
@@ -534,7 +538,7 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
         const u32x4 row = lds_at<u32x4>(kOutcomeAt + code * uint32_t(sizeof(OutcomeRow)));   // {reward lo, hi, status, pad}
         const uint32_t row_status = row.z;
         double reward = __hiloint2double(int(row.y), int(row.x));
-        const bool was_terminal = code > 7u;
+        const bool was_terminal = MAYBE_TERMINAL && code > 7u;
         if (SOC) {
             // _living_reward: mapf_env.py:436-446
             uint32_t mine = 0u;
@@ -570,7 +574,7 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
         const bool back = ended > reset_above;                 // never with auto-reset off
 #pragma unroll
         for (int i = 0; i < P; ++i) c[i] = back ? start_c[i] : n[i];
-        terminal = back ? start_terminal : min(ended & 13u, 1u);
+        if (MAYBE_TERMINAL) terminal = back ? start_terminal : min(ended & 13u, 1u);
         STAMP(7);   // reset handling
     };
     using Generic = std::integral_constant<int, -1>;
@@ -641,16 +645,20 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
 
 template <int Q, int K, bool RECORD, bool STREAM, bool COMPACT = false>
 hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream) {
-    auto kern = args.c.criteria != 0u ? lq_rollout_kernel<Q, K, RECORD, STREAM, true, COMPACT> : lq_rollout_kernel<Q, K, RECORD, STREAM, false, COMPACT>;
+    // (criteria, may-be-terminal): the instance without terminal handling exists for Makespan only
+    const bool term = !(args.auto_reset && !args.start_terminal_any);
+    auto kern = args.c.criteria != 0u ? lq_rollout_kernel<Q, K, RECORD, STREAM, true, COMPACT, true>
+                : term            ? lq_rollout_kernel<Q, K, RECORD, STREAM, false, COMPACT, true>
+                                  : lq_rollout_kernel<Q, K, RECORD, STREAM, false, COMPACT, false>;
     if (lds_bytes > 32 * 1024) {   // dynamic LDS beyond the default cap needs an explicit opt-in (per device: not cached)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                            int(kLdsBytes - kLdsReserve));
         if (e != hipSuccess) return e;
     }
     const unsigned grid = unsigned(args.n_envs / (block / unsigned(Q)));
-    note_kernel("lq_rollout_kernel<Q=%d,K=%d,%s,%s,%s%s> block=%u (packed layout: %d agents per lane%s)", Q, K, RECORD ? "RECORD" : "TOTALS",
-                STREAM ? "STREAM" : "POLICY", args.c.criteria != 0u ? "SOC" : "MAKESPAN", COMPACT ? ",COMPACT" : "", block, K,
-                COMPACT ? ", 8-byte table rows" : "");
+    note_kernel("lq_rollout_kernel<Q=%d,K=%d,%s,%s,%s%s%s> block=%u (packed layout: %d agents per lane%s)", Q, K, RECORD ? "RECORD" : "TOTALS",
+                STREAM ? "STREAM" : "POLICY", args.c.criteria != 0u ? "SOC" : "MAKESPAN", COMPACT ? ",COMPACT" : "",
+                (args.c.criteria == 0u && !term) ? ",NO_TERMINAL" : "", block, K, COMPACT ? ", 8-byte table rows" : "");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds_bytes, stream, args, A);
     return hipGetLastError();
 }

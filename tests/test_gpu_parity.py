@@ -397,9 +397,9 @@ def _goal_scenario_tables(n_agents, n_envs, seed):
     (32, 2048, 'lq_rollout_kernel<Q=8,K=4', {'MAPF_LQ_K': '4'}), (32, 1024, 'lq_rollout_kernel<Q=16,K=2', {'MAPF_LQ_K': '2'}),
     (32, 1024, 'lg_rollout_kernel<L=16,FULL,MV_GLOBAL', {'MAPF_MV_LDS_MAX_BYTES': '0'}),
     # (a full table "too large" for the LDS budget: the 8-byte-row form of the packed kernel, 512- and 1024-thread blocks)
-    (16, 4096, 'lq_rollout_kernel<Q=4,K=4,RECORD,STREAM,MAKESPAN,COMPACT> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
-    (64, 16384, 'lq_rollout_kernel<Q=16,K=4,RECORD,STREAM,MAKESPAN,COMPACT> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
+    (16, 4096, 'lq_rollout_kernel<Q=4,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
+    (64, 16384, 'lq_rollout_kernel<Q=16,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
     (8, 300, 'lg_rollout_kernel<L=4,FULL,MV_GLOBAL', {}), (5, 600, 'lg_rollout_kernel<L=4,RAGGED', {}),
     (8, 16417, 'lg_rollout_kernel<L=4,FULL,MV_LDS', {}), (6, 512, 'rollout_kernel<A=6>', {})])
 def test_goal_reaching_episodes_against_c_oracle(n_agents, n_envs, layout, env_vars, monkeypatch):
