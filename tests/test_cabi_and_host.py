@@ -124,7 +124,7 @@ def test_every_dispatchable_kernel_is_free_of_register_spills(tmp_path):
         assert proc.wait() == 0
         resources.update(_kernel_resources(out.read_text()))
     assert len(resources) >= 200
-    max_tpe_rollout = int(re.search(r'kTpeRolloutMaxAgents\s*=\s*(\d+)', open(os.path.join(CSRC, 'mapf_kernels.hpp')).read()).group(1))
+    max_tpe_rollout = int(re.search(r'#define MAPF_TPE_ROLLOUT_MAX\s+(\d+)', open(os.path.join(CSRC, 'mapf_kernels.hpp')).read()).group(1))
     checked = tpe_step = tpe_rollout = 0
     for name, (sgpr, vgpr, scratch) in resources.items():
         m = re.match(r'_ZN4mapf14rollout_kernelILi(\d+)E', name)
