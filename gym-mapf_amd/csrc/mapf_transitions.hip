@@ -13,7 +13,9 @@
 
 namespace mapf {
 
-template <int MAXA>
+// EXACT: the team has exactly MAXA agents (no ghost slots, no per-slot predicates: the 9..16-agent instances would
+// otherwise keep sixteen wave masks alive and spill scalar registers).
+template <int MAXA, bool EXACT = false>
 __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs p) {
     __shared__ SlipRow slip[8];
     stage_slip_table(p.slip, slip);
@@ -22,7 +24,7 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
     const uint32_t slot = uint32_t(gid - q * p.max_branches);   // output row of the query's window
     const uint64_t b = p.first_branch + slot;                    // branch index in the query's full enumeration
     if (q >= p.n_queries) return;
-    const uint32_t A = p.n_agents;
+    const uint32_t A = EXACT ? uint32_t(MAXA) : p.n_agents;
     const uint64_t env = p.env_index ? p.env_index[q] : 0;
     const uint16_t *goal_row = p.goal + (p.goal_broadcast ? 0 : env * A);
     const uint16_t *state_row = p.local + q * A;
@@ -34,7 +36,7 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
     uint64_t count = 1;
 #pragma unroll
     for (int i = 0; i < MAXA; ++i) {
-        const bool on = uint32_t(i) < A;
+        const bool on = EXACT || uint32_t(i) < A;
         prev[i] = on ? state_row[i] : 0x10000u + uint32_t(i);       // ghosts: unique, never equal to a real cell
         goal[i] = on ? goal_row[i] : prev[i];
         const uint32_t a = on ? act_row[i] : 0u;
@@ -74,7 +76,7 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
     uint32_t coll_acc = 0xFFFFFFFFu, goal_next_acc = 0u;
 #pragma unroll
     for (int i = 0; i < MAXA; ++i) {
-        const bool on = uint32_t(i) < A;
+        const bool on = EXACT || uint32_t(i) < A;
         const SlipRow &row = slip[entry_code(entry[i])];
         const uint32_t cell = entry_cell(entry[i], k[i]);
         next[i] = on ? cell : prev[i];
@@ -152,8 +154,12 @@ hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream) {
     const dim3 grid{unsigned(grid64)}, block{256};
     if (args.n_agents <= 4) hipLaunchKernelGGL(transitions_kernel<4>, grid, block, 0, stream, args);
     else if (args.n_agents <= 8) hipLaunchKernelGGL(transitions_kernel<8>, grid, block, 0, stream, args);
-    else if (args.n_agents <= 16) hipLaunchKernelGGL(transitions_kernel<16>, grid, block, 0, stream, args);
-    else return hipErrorInvalidValue;
+    else switch (args.n_agents) {
+#define X(N) case N: hipLaunchKernelGGL((transitions_kernel<N, true>), grid, block, 0, stream, args); break;
+        X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
+#undef X
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 
