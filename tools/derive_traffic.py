@@ -2,8 +2,8 @@
 lengths (--rollout-steps T1 and T2): per kernel instance and batch, HBM bytes per launch = fixed + per_env_step * T.
 
 usage: python tools/derive_traffic.py <label> <E> <A> <T1> <fetch1.csv> <write1.csv> <T2> <fetch2.csv> <write2.csv> [...]
-       (label = the kernel name the library reports for that batch: bench line `roofline.kernel`; a group of nine
-        arguments per configuration; the single-step kernel of each group is recorded too)
+       (label = "<rollout kernel>||<single-step kernel>" as the library reports them for that batch: bench line
+        `roofline.kernel` and `single_step_launches.kernel`; a group of nine arguments per configuration)
 
 hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per dispatch: the counters are KB per dispatch and gfx950 tallies
 128-byte read requests at 64 B (MI355X_MICROARCH.md, HBM / rocprofv3 section).  reset_kernel and fill_actions_kernel
@@ -48,6 +48,7 @@ def main():
     out = {"_how": __doc__.strip().split("\n\n")[2].replace("\n", " "), "kernels": [], "calibration": {}}
     while len(args) >= 9:
         label, E, A, T1, f1, w1, T2, f2, w2 = args[:9]
+        label, _, step_label = label.partition("||")
         args = args[9:]
         E, A, T1, T2 = int(E), int(A), int(T1), int(T2)
         F1, W1, F2, W2 = per_kernel(f1, "FETCH_SIZE"), per_kernel(w1, "WRITE_SIZE"), per_kernel(f2, "FETCH_SIZE"), per_kernel(w2, "WRITE_SIZE")
@@ -65,7 +66,7 @@ def main():
         if "step_kernel" in F1 and "step_kernel" in W1:
             name = F1["step_kernel"][2]
             out["kernels"].append({
-                "kernel": None, "instance": name.split("(mapf::")[0].replace("void ", "").strip(), "single_step_of": label,
+                "kernel": step_label or None, "instance": name.split("(mapf::")[0].replace("void ", "").strip(), "single_step_of": label,
                 "n_envs": E, "n_agents": A, "bytes_per_env_step_launch": round(hbm_bytes(F1, W1, "step_kernel"), 1), "fixed_bytes": 0.0,
                 "algorithmic_bytes_per_env_step_launch": alg,
                 "measured": {"1": {"FETCH_SIZE_KB": round(F1["step_kernel"][0], 2), "WRITE_SIZE_KB": round(W1["step_kernel"][0], 2),

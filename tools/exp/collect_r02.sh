@@ -1,9 +1,11 @@
 #!/bin/bash
 # side artefacts of round 2 (run on the GPU box; outputs under gpurun_out/side_r02/)
 out=$PWD/gpurun_out/side_r02; mkdir -p $out
-export MAPF_HIP_LIB=$PWD/gym-mapf_amd/gym_mapf_amd/lib/variants/libmapf_hip_stamps.so
-(python tools/stamp_profile.py 65536; MAPF_LQ_K=4 python tools/stamp_profile.py 32768) 2>&1 | grep -v amdgpu.ids > $out/r02_rollout_stamps.txt
-unset MAPF_HIP_LIB
+if [ -f $PWD/gym-mapf_amd/gym_mapf_amd/lib/variants/libmapf_hip_stamps.so ]; then   # (make stamps + copy it there first)
+  export MAPF_HIP_LIB=$PWD/gym-mapf_amd/gym_mapf_amd/lib/variants/libmapf_hip_stamps.so
+  (python tools/stamp_profile.py 65536; MAPF_LQ_K=4 python tools/stamp_profile.py 32768) 2>&1 | grep -v amdgpu.ids > $out/r02_rollout_stamps.txt
+  unset MAPF_HIP_LIB
+fi
 : > $out/r02_configs.txt
 for spec in "c3" "c4" "c4 --envs 32768" "c5" "c5 --envs 16384" "c2"; do
   python bench.py --config $spec --steps 20 --warmup 5 --no-cpu-baseline --no-scalar-env 2>/dev/null | python3 -c "

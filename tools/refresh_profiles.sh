@@ -25,7 +25,7 @@ for T in 256 128; do
   python3 tools/pmc_compact.py $P/fetch$T/*/*counter_collection.csv > "$out/${tag}_pmc_fetch_size_T$T.csv"
   python3 tools/pmc_compact.py $P/write$T/*/*counter_collection.csv > "$out/${tag}_pmc_write_size_T$T.csv"
 done
-label=$(python3 -c "import json,sys; print(json.load(open('$out/${tag}_bench_under_rocprof.json'))['roofline']['kernel'])")
+label=$(python3 -c "import json,sys; d=json.load(open('$out/${tag}_bench_under_rocprof.json')); print(d['roofline']['kernel'] + '||' + d['single_step_launches']['kernel'])")
 python3 tools/derive_traffic.py "$label" 65536 8 256 $P/fetch256/*/*counter_collection.csv $P/write256/*/*counter_collection.csv \
         128 $P/fetch128/*/*counter_collection.csv $P/write128/*/*counter_collection.csv > /dev/null
 cp profiles/traffic.json "$out/traffic.json"
