@@ -272,6 +272,11 @@ def main():
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         spawn_ranks(args.gpus)
 
+    # stdout carries ONE JSON line: whatever libraries print while they initialise (gloo's rank banner, ...) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -493,7 +498,10 @@ def main():
             line["scalar_env"] = scalar_env_rate()
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     env.close()
     if dist is not None:
         dist.barrier()
