@@ -203,6 +203,9 @@ bool build_slip_table(double fail_prob, mapf::SlipRow (&rows)[8], double (&cand_
                 row.th[k] = 65535u;
             }
         }
+        // th[2] is never compared against (a list's last threshold is 65535 by construction): it carries th[0] | th[1] << 16,
+        // the word MoveEntry::z holds, for kernels that keep only the cells of a row in LDS (mapf_lq_rollout.hip COMPACT)
+        row.th[2] = row.th[0] | (row.th[1] << 16);
         any_multi |= n > 1;
     }
     return any_multi;

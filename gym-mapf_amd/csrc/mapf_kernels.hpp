@@ -23,7 +23,8 @@ using MoveEntry = uint4;
 struct SlipRow {
     double q[3];                   // merged probabilities, list order
     uint32_t th[3];                // top 16 bits of the thresholds, saturated to 65535 (65535 past the list end too): the
-                                   // fast path of slip_move_hi; MoveEntry::z carries th[0], th[1] of the entry's code
+                                   // fast path of slip_move_hi; MoveEntry::z carries th[0], th[1] of the entry's code;
+                                   // th[2] = th[0] | th[1] << 16 (that same word, for the COMPACT rollout form)
     uint32_t n;                    // list length, 1..3
     uint64_t thr[3];               // ceil(cum[k] * 2^53): cum[k] > u  <=>  mant(u) < thr[k]; 0 past the list end
     double cum[3];                 // running float64 sums (for caller-supplied uniforms); -inf past the list end

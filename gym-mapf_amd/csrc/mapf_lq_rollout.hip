@@ -277,7 +277,8 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
             for (uint32_t k = 0; k < 4u; ++k) {
                 const uint32_t w = w0 + k * blockDim.x;
                 if (w < n_words) {
-                    if (COMPACT) reinterpret_cast<u32x2 *>(lds_mv)[w] = u32x2{part[k].x, part[k].y};
+                    // COMPACT rows: {c0 | c1 << 16, c2 | byte offset of the code's slip row << 16}
+                    if (COMPACT) reinterpret_cast<u32x2 *>(lds_mv)[w] = u32x2{part[k].x, (part[k].y & 0xFFFFu) | (part[k].w << 16)};
                     else lds_mv[w] = part[k];
                 }
             }
@@ -472,15 +473,14 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
         }
         STAMP(1);   // previous step: probability chain, totals, trajectory stores
         if (COMPACT) {   // the code's thresholds: a second LDS read that depends on the first; the row completes to a MoveEntry
-            u32x2 th[K];
-            uint32_t row_off[K];
+            uint32_t row_off[K], th[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                row_off[k] = ((cells_code[k].y >> 16) & 7u) * uint32_t(sizeof(SlipRow));
-                th[k] = lds_at<u32x2>(kSlipAt + uint32_t(offsetof(SlipRow, th)) + row_off[k]);
+                row_off[k] = cells_code[k].y >> 16;
+                th[k] = lds_at<uint32_t>(kSlipAt + uint32_t(offsetof(SlipRow, th)) + 8u + row_off[k]);   // th[0] | th[1] << 16
             }
 #pragma unroll
-            for (int k = 0; k < K; ++k) entry[k] = make_uint4(cells_code[k].x, cells_code[k].y, th[k].x | (th[k].y << 16), row_off[k]);
+            for (int k = 0; k < K; ++k) entry[k] = make_uint4(cells_code[k].x, cells_code[k].y, th[k], row_off[k]);
         }
         // one slip-stream call per pair serves four steps
         const bool refresh = FIRST || W == 0 || (W < 0 && (t & 3u) == 0u);
@@ -511,8 +511,11 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
             // a top-16-bit tie somewhere in the wave: redo with all 53 bits
             uint32_t nx[K];
 #pragma unroll
-            for (int k = 0; k < K; ++k)
-                slip_move<false>(slip, entry[k], refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi[k]), 0.0, nx[k], q[k]);
+            for (int k = 0; k < K; ++k) {
+                MoveEntry full = entry[k];
+                if (COMPACT) full.y = (full.y & 0xFFFFu) | ((full.w / uint32_t(sizeof(SlipRow))) << 16);   // the code, where entry_code() looks
+                slip_move<false>(slip, full, refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi[k]), 0.0, nx[k], q[k]);
+            }
 #pragma unroll
             for (int i = 0; i < P; ++i) n[i] = nx[2 * i] | (nx[2 * i + 1] << 16);
         }
