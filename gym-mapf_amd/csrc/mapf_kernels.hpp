@@ -132,7 +132,7 @@ struct RolloutTuning {
 RolloutTuning default_rollout_tuning(int device);
 hipError_t launch_step_lg(int n_agents, const StepArgs &args, hipStream_t stream);
 hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream);
-// quad-lane layout of the fused rollout (mapf_lq_rollout.hip): true when it took the launch (*err = its status)
+// packed layout of the fused rollout (2 or 4 agents per lane, mapf_lq_rollout.hip): true when it took the launch (*err = its status)
 bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err);
 int lg_group_size(int n_agents);
 

@@ -104,7 +104,7 @@ def _kernel_resources(asm_text):
 def test_every_dispatchable_kernel_is_free_of_register_spills(tmp_path):
     """No code object the launchers can reach may spill registers: a spilling thread-per-env rollout kernel is the
     one place a wrong result was ever observed on the GPU (compiler notes), and spills cost time.  Covers
-    the lane-group and quad-lane families, the transition kernels AND the thread-per-env family (mapf_kernels.hip,
+    the lane-group and packed-layout families, the transition kernels AND the thread-per-env family (mapf_kernels.hip,
     compiled once per agent-count group like the Makefile does); of the latter's rollout kernels only those
     launch_rollout_g* dispatches (A <= kTpeRolloutMaxAgents) are held to it -- the others are never launched."""
     jobs = []

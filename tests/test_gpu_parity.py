@@ -266,7 +266,7 @@ def test_results_do_not_depend_on_how_envs_are_sharded():
     (64, 1024), (64, 512),                       # quad Q = 16; pair L = 32 (LDS)
     (128, 256)])                                 # pair L = 64
 def test_recorded_rollout_of_full_groups_against_c_oracle(n_agents, n_envs):
-    """Full groups whose env count fills every block run the predicate-free rollout kernels -- the quad-lane
+    """Full groups whose env count fills every block run the predicate-free rollout kernels -- the packed
     layout (four agents per lane) where A = 4Q and the batch fills its blocks, else the pair layout (LDS move
     table for the larger batches, global table for the smaller): every recorded step -- cells, reward, prob,
     done, collision -- against the C oracle stepped with the same actions, streamed and policy-generated,
@@ -343,7 +343,7 @@ def test_dense_rollout_split_launches_accumulate_and_single_steps(n_agents, n_en
                                                     (8, 8192, 'auto'), (8, 16448, 'auto'), (16, 4096, 'auto'), (7, 1000, 'auto')])
 def test_greedy_policy_rollout_against_c_oracle(n_agents, n_envs, kernel):
     """mapf_set_policy(MAPF_POLICY_GREEDY): the fused rollout with the on-device greedy policy (thread-per-env,
-    pair and quad-lane kernels) records exactly the trajectory the C oracle produces when it is stepped with the
+    lane-group and packed-layout kernels) records exactly the trajectory the C oracle produces when it is stepped with the
     greedy actions of its own restatement; switching back to the random policy restores the policy stream."""
     rs = np.random.RandomState(700 + n_agents)
     lines = [''.join('@' if rs.rand() < 0.15 else '.' for _ in range(20)) for _ in range(20)]

@@ -5,7 +5,7 @@ episode counters, so this build's outputs are not valid results) and prints medi
 
     make -C gym-mapf_amd/csrc stamps
     MAPF_HIP_LIB=gym-mapf_amd/csrc/build/libmapf_hip_stamps.so python tools/stamp_profile.py [envs]
-    (MAPF_QUAD_LANES=0 in the environment profiles the pair layout instead of the quad-lane one)
+    (MAPF_LQ_K=2 profiles the packed layout with two agents per lane, MAPF_QUAD_LANES=0 the lane-group kernel)
 
 Stamps serialise the segments (a fence on each side), so read the SHARES, not the total (cdna_hip_programming.md
 section 7, in-kernel stamps).
@@ -23,7 +23,7 @@ from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv  # noqa: 
 if 'stamps' not in os.environ.get('MAPF_HIP_LIB', ''):
     raise SystemExit('set MAPF_HIP_LIB to the stamps build (see the docstring)')
 E, A, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 65536), 8, 64
-# envs per wave: 32 in the quad-lane layout (default), 16 in the pair layout (MAPF_QUAD_LANES=0)
+# envs per wave: 32 with four agents per lane (default), 16 with two
 PER_WAVE = 16 if os.environ.get('MAPF_QUAD_LANES') == '0' or os.environ.get('MAPF_LQ_K') == '2' else 32
 print('layout: %s' % ('pair (2 agents per lane)' if PER_WAVE == 16 else 'quad (4 agents per lane)'))
 grid, _, nbr, start, goal = bench.workload_tables(bench.CONFIGS['c3'], E, 0)
