@@ -355,8 +355,8 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
     // "Pending" = what is left of step s-1 when step s begins: its probability chain, its totals and its trajectory
     // stores.  They are finished at the top of step s, right after step s's table reads have been issued, so the
     // chain of dependent float64 multiplies runs while those reads are in flight, and the outcome row / probability
-    // reads of step s-1 (requested in step s-1, consumed only here) never stall anything.  Step 0 finishes a dummy:
-    // reward -0.0 leaves the running return unchanged bit for bit, the stores hit row 0 and are overwritten by step 1.
+    // reads of step s-1 (requested in step s-1, consumed only here) never stall anything.  (The launch's first step has
+    // nothing pending and skips this.)
     double pq[K], p_reward = -0.0;
 #pragma unroll
     for (int i = 0; i < K; ++i) pq[i] = 0.0;
@@ -405,8 +405,8 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
 
     // One step.  W = which word of the slip calls this step uses (t & 3) when that is a compile-time fact, -1 = generic
     // (word picked at run time, call refreshed when t is a multiple of four).  FIRST = the launch's first step: nothing
-    // is pending yet and the slip call is refreshed whatever t is.  TAIL = the action rows run out within two steps, so
-    // the prefetch address is clamped.  `raw` is the register that holds this step's action word.
+    // is pending yet and the slip call is refreshed whatever t is.  TAIL = the action rows may run out within kAhead
+    // steps, so the prefetch address is clamped.  `raw` is the register that holds this step's action word.
     uint32_t row_bytes = COMPACT ? kCompactCols * kCompactEntry : kMoveCols * uint32_t(sizeof(MoveEntry));
     asm volatile("" : "+v"(row_bytes));   // (one register for the whole loop; as an SGPR operand the assembler rejects the SDWA form)
     auto one_step = [&](const uint32_t s, uint32_t &raw, auto w_tag, auto first_tag, auto tail_tag) __attribute__((always_inline)) {
