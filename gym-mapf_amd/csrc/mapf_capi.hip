@@ -470,7 +470,7 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
             if (out_done) a.out_done = reinterpret_cast<uint8_t *>(dp + o_done);
             if (out_collision) a.out_collision = reinterpret_cast<uint8_t *>(dp + o_coll);
             if (out_was_terminal) a.out_was_terminal = reinterpret_cast<uint8_t *>(dp + o_term);
-            HIP_TRY(h->lane_group ? mapf::launch_step_lg(int(h->A), a, h->stream) : mapf::launch_step(int(h->A), a, h->stream));
+            HIP_TRY(h->lane_group ? mapf::launch_step_lg(int(h->A), a, h->tune, h->stream) : mapf::launch_step(int(h->A), a, h->stream));
             if (h->last_step_kernel != g_noted_kernel) h->last_step_kernel = g_noted_kernel;
             h->t += 1;
             HIP_TRY(hipStreamSynchronize(h->stream));
@@ -491,7 +491,7 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     if (int rc = stage_out(h, h->s_done, out_done, E, &a.out_done, "out_done")) return rc;
     if (int rc = stage_out(h, h->s_coll, out_collision, E, &a.out_collision, "out_collision")) return rc;
     if (int rc = stage_out(h, h->s_term, out_was_terminal, E, &a.out_was_terminal, "out_was_terminal")) return rc;
-    HIP_TRY(h->lane_group ? mapf::launch_step_lg(int(h->A), a, h->stream) : mapf::launch_step(int(h->A), a, h->stream));
+    HIP_TRY(h->lane_group ? mapf::launch_step_lg(int(h->A), a, h->tune, h->stream) : mapf::launch_step(int(h->A), a, h->stream));
     if (h->last_step_kernel != g_noted_kernel) h->last_step_kernel = g_noted_kernel;
     h->t += 1;
     if (!h->device_ptrs) {

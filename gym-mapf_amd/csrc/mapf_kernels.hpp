@@ -130,7 +130,9 @@ struct RolloutTuning {
     size_t mv_lds_max_bytes = 0;     // largest move table staged into LDS (MAPF_MV_LDS_MAX_BYTES; default: two blocks per CU)
 };
 RolloutTuning default_rollout_tuning(int device);
-hipError_t launch_step_lg(int n_agents, const StepArgs &args, hipStream_t stream);
+hipError_t launch_step_lg(int n_agents, const StepArgs &args, const RolloutTuning &tune, hipStream_t stream);
+// packed layout of the single step (mapf_lq_step.hip): true when it took the launch (*err = its status)
+bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err);
 hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream);
 // packed layout of the fused rollout (2 or 4 agents per lane, mapf_lq_rollout.hip): true when it took the launch (*err = its status)
 bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err);

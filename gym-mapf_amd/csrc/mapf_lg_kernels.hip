@@ -143,8 +143,10 @@ int lg_group_size(int n_agents) {
     return L;
 }
 
-hipError_t launch_step_lg(int n_agents, const StepArgs &args, hipStream_t stream) {
+hipError_t launch_step_lg(int n_agents, const StepArgs &args, const RolloutTuning &tune, hipStream_t stream) {
     if (args.n_envs == 0) return hipSuccess;
+    hipError_t packed_status;
+    if (try_launch_step_lq(n_agents, args, tune, stream, &packed_status)) return packed_status;
     const int L = lg_group_size(n_agents);
     const bool full = n_agents == 2 * L;
     unsigned grid, block;

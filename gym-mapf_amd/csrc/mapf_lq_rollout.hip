@@ -31,7 +31,7 @@
 // LDS -- the bench configurations and their neighbours.  Everything else (odd agent counts, ragged batches, tables
 // beyond the LDS budget, single steps) stays with mapf_lg_rollout.hip; launch_rollout_lg() picks.  Same stream,
 // same arithmetic, same outputs: the parity tests run all layouts against the oracle.
-#include "mapf_lg.hpp"
+#include "mapf_lq.hpp"
 
 #include <cstdlib>
 #include <type_traits>
@@ -42,186 +42,6 @@ namespace {
 
 constexpr size_t kLdsBytes = 160 * 1024, kLdsReserve = 1024;
 static_assert(sizeof(SlipRow) * 8 + sizeof(OutcomeRow) * 16 <= kLdsReserve, "static LDS of the rollout kernel");
-
-using gf64 = __attribute__((address_space(1))) double *;
-using gu32 = __attribute__((address_space(1))) uint32_t *;
-using gu16 = __attribute__((address_space(1))) uint16_t *;
-using gu8 = __attribute__((address_space(1))) uint8_t *;
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
-// P packed dwords (2P cells) of a lane, moved as one global access
-template <int P> struct Packed;
-template <> struct Packed<1> {
-    uint32_t v[1];
-    static __device__ __forceinline__ Packed load(const void *p) { return Packed{{*reinterpret_cast<const uint32_t *>(p)}}; }
-    __device__ __forceinline__ void store(void *p) const { *reinterpret_cast<uint32_t *>(p) = v[0]; }
-    __device__ __forceinline__ void store_global(gu16 p) const { *(gu32)p = v[0]; }
-};
-template <> struct Packed<2> {
-    uint32_t v[2];
-    static __device__ __forceinline__ Packed load(const void *p) {
-        const u32x2 w = *reinterpret_cast<const u32x2 *>(p);
-        return Packed{{w.x, w.y}};
-    }
-    __device__ __forceinline__ void store(void *p) const { *reinterpret_cast<u32x2 *>(p) = u32x2{v[0], v[1]}; }
-    __device__ __forceinline__ void store_global(gu16 p) const {
-        *(__attribute__((address_space(1))) u32x2 *)p = u32x2{v[0], v[1]};
-    }
-};
-
-// The kernel's LDS image starts at LDS address 0 (it is the kernel's only LDS object; checked once at kernel entry), so
-// an LDS location is named by its BYTE ADDRESS: plain integer arithmetic ending in one v_lshl_add_u32, the constant
-// part of the address folded into the ds instruction's offset field.
-template <typename T>
-__device__ __forceinline__ T lds_at(uint32_t byte_address) {
-    return *(const __attribute__((address_space(3))) T *)(uintptr_t(byte_address));
-}
-// half-word H of x times a wave-uniform factor: ONE v_mul_u32_u24 with a word select (the compiler prefers to extract
-// the half-word first and fold the multiply into a v_mad: one instruction more per agent)
-template <int H>
-__device__ __forceinline__ uint32_t half_times(uint32_t x, uint32_t factor) {
-    uint32_t r;
-    if (H == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(r) : "v"(x), "v"(factor));
-    else asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(r) : "v"(x), "v"(factor));
-    return r;
-}
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ MoveEntry lds_entry_at(uint32_t byte_address) {   // one ds_read_b128
-    const u32x4 v = lds_at<u32x4>(byte_address);
-    return make_uint4(v.x, v.y, v.z, v.w);
-}
-
-// sampled list slot of one agent from the top 16 bits of its uniform (see slip_move_hi): idx, its probability, and
-// the tie distance (0 <=> hi equals a threshold -> exact path)
-__device__ __forceinline__ uint32_t sample_slot(uint32_t slip_at, const MoveEntry &entry, uint32_t hi, double &q,
-                                                uint32_t &tie_dist) {
-    // (slot = how many of the first two thresholds hi has passed: see slip_move_hi in mapf_device.hpp)
-    const uint32_t t0 = entry.z & 0xFFFFu, t1 = entry.z >> 16;
-    const uint32_t d0 = hi - t0, d1 = hi - t1, d2 = hi - 0xFFFFu;
-    tie_dist = min(d0, min(d1, d2));
-    const uint32_t idx = 2u - (d0 >> 31) - (d1 >> 31);
-    q = lds_at<double>(slip_at + (idx << 3) + entry_row_offset(entry));
-    return idx;
-}
-// list slot idx of an entry, zero-extended: one v_perm_b32
-__device__ __forceinline__ uint32_t cell_lo(const MoveEntry &entry, uint32_t idx) {
-    return __builtin_amdgcn_perm(entry.y, entry.x, 0x0C0C0100u + idx * 0x0202u);
-}
-
-// "same half-word" tests only: my pair against a pair that arrives straight or half-swapped (half rotation)
-template <bool DUP, bool MOVES>
-__device__ __forceinline__ void pair_apply_same(uint32_t pk_prev, uint32_t pk_next, uint32_t o_prev, uint32_t o_next,
-                                                PairAcc<true> &acc) {
-    if (DUP) acc.dup = pk_min_u16(acc.dup, pk_prev ^ o_prev);
-    if (MOVES) {
-        acc.vertex = pk_min_u16(acc.vertex, pk_next ^ o_next);
-        acc.swap = pk_min_u16(acc.swap, (pk_next ^ o_prev) | (pk_prev ^ o_next));
-    }
-}
-
-// value held by lane (g + S) mod Q of my group.  Groups of 2, 4 and 16 lanes rotate with one DPP move; a group of 8
-// would need two DPP moves and a select per value (a 16-lane row holds two groups), so it goes through the LDS
-// crossbar instead: one ds_bpermute_b32 per value, all of a round's values in flight together
-template <int Q, int S>
-__device__ __forceinline__ uint32_t packed_rot(uint32_t v, const LaneCtx<Q> &x) {
-    if constexpr (Q == 8) return uint32_t(__builtin_amdgcn_ds_bpermute(int((x.base + ((x.g + uint32_t(S)) & 7u)) << 2), int(v)));
-    else return group_rot<Q, S>(v, x);
-}
-
-// full rotations 1 .. Q/2-1: my pairs against every pair of group position g + S
-template <int Q, int P, int S, bool DUP, bool MOVES>
-struct PackedRounds {
-    static __device__ __forceinline__ void run(const LaneCtx<Q> &x, const uint32_t (&c)[P], const uint32_t (&n)[P],
-                                               PairAcc<true> &acc) {
-        if constexpr (S <= Q / 2 - 1) {
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                const uint32_t oc = packed_rot<Q, S>(c[j], x);
-                const uint32_t on = MOVES ? packed_rot<Q, S>(n[j], x) : 0u;
-#pragma unroll
-                for (int i = 0; i < P; ++i) pair_apply_packed<DUP, MOVES>(c[i], n[i], oc, on, acc);
-            }
-            PackedRounds<Q, P, S + 1, DUP, MOVES>::run(x, c, n, acc);
-        }
-    }
-};
-
-// all agent pairs of the env.  c: my packed current cells (agents K*g .. K*g+K-1, two per dword), n: next cells.
-template <int Q, int P, bool DUP, bool MOVES>
-__device__ __forceinline__ PairAcc<true> packed_pair_tests(const LaneCtx<Q> &x, const uint32_t (&c)[P], const uint32_t (&n)[P]) {
-    PairAcc<true> acc;
-    uint32_t csw[P], nsw[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        csw[i] = swap_halves(c[i]);
-        nsw[i] = MOVES ? swap_halves(n[i]) : 0u;
-    }
-    // inside each pair (both half-words carry the same test) ...
-#pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const uint32_t d = c[i] ^ csw[i], v = n[i] ^ nsw[i], w = (n[i] ^ csw[i]) | (c[i] ^ nsw[i]);
-        if (DUP) acc.dup = i == 0 ? d : pk_min_u16(acc.dup, d);
-        if (MOVES) {
-            acc.vertex = i == 0 ? v : pk_min_u16(acc.vertex, v);
-            acc.swap = i == 0 ? w : pk_min_u16(acc.swap, w);
-        }
-    }
-    // ... then pair against pair inside the lane
-#pragma unroll
-    for (int i = 0; i < P; ++i)
-#pragma unroll
-        for (int j = i + 1; j < P; ++j) pair_apply_packed<DUP, MOVES>(c[i], n[i], c[j], n[j], acc);
-    if constexpr (Q >= 2) {
-        PackedRounds<Q, P, 1, DUP, MOVES>::run(x, c, n, acc);
-        // half rotation: lane g meets lane g + Q/2 from both sides, so the two lanes split the agent pairs --
-        // lower-half lanes offer their pairs half-swapped; whoever receives runs only the same-half-word tests
-        const bool lower = x.g < uint32_t(Q / 2);
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const uint32_t oc = packed_rot<Q, Q / 2>(lower ? csw[j] : c[j], x);
-            const uint32_t on = MOVES ? packed_rot<Q, Q / 2>(lower ? nsw[j] : n[j], x) : 0u;
-#pragma unroll
-            for (int i = 0; i < P; ++i) pair_apply_same<DUP, MOVES>(c[i], n[i], oc, on, acc);
-        }
-    }
-    return acc;
-}
-
-// non-zero <=> one of the two half-words of a is zero (the classic "has a zero byte" test on 16-bit fields): the only
-// bits that can be set are 15 and 31
-__device__ __forceinline__ uint32_t zero_half(uint32_t a) {
-    return (a - 0x00010001u) & ~a & 0x80008000u;
-}
-
-// MapfEnv.is_terminal (mapf_env.py:210-223) of the group's env, in every lane
-template <int Q, int P>
-__device__ __forceinline__ bool packed_is_terminal(const LaneCtx<Q> &x, const uint32_t (&c)[P], const uint32_t (&g)[P]) {
-    const uint32_t none[P] = {};
-    const PairAcc<true> acc = packed_pair_tests<Q, P, true, false>(x, c, none);
-    bool off_goal = false;
-#pragma unroll
-    for (int i = 0; i < P; ++i) off_goal |= c[i] != g[i];
-    const uint32_t flags = group_reduce<Q, false>((PairAcc<true>::hit(acc.dup) ? 1u : 0u) | (off_goal ? 2u : 0u), x);
-    return (flags & 1u) != 0u || (flags & 2u) == 0u;
-}
-
-// ordered product over agents 0..A-1: every lane continues the product handed over by the lane before it (see
-// prob_product in mapf_lg.hpp); the total ends in lane Q-1
-template <int Q, int K>
-__device__ __forceinline__ double packed_prob_product(const double (&q)[K]) {
-    double run = q[0];
-#pragma unroll
-    for (int i = 1; i < K; ++i) run = __dmul_rn(run, q[i]);
-#pragma unroll
-    for (int k = 1; k < Q; ++k) {
-        const uint32_t lo = from_prev_lane<Q>(uint32_t(__double2loint(run)));
-        const uint32_t hi = from_prev_lane<Q>(uint32_t(__double2hiint(run)));
-        run = __hiloint2double(int(hi), int(lo));
-#pragma unroll
-        for (int i = 0; i < K; ++i) run = __dmul_rn(run, q[i]);
-    }
-    return run;
-}
 
 // RECORD: all five trajectory arrays are written every step; STREAM: actions come from memory, else from the
 // in-kernel policy.  Memory pipeline and store scheme as lg_rollout_kernel<DENSE>.

@@ -1,0 +1,167 @@
+// Packed-layout single step: one MapfEnv.step() of every env per launch (mapf_step with device-drawn uniforms), K = 2 or
+// 4 agents per lane, Q = A/K lanes per env -- the lane layout of mapf_lq_rollout.hip applied to the one-launch-per-step
+// path, for full groups and batches that fill their blocks; everything else (caller-supplied uniforms, odd agent
+// counts, ragged batches) stays with lg_step_kernel (mapf_lg_kernels.hip), whose semantics this kernel reproduces
+// line by line.
+//
+// A single step is launch- and latency-bound (three dependent round trips: state/actions -> table row -> stores), so
+// nothing is staged into LDS: the 16-byte table rows are gathered from global memory (L2-resident), the sampled
+// probability is rebuilt from the slot's members (no read of the slip rows on the common path), the reward is
+// computed in registers.  What the packed layout buys is fewer waves and fewer replicated per-env instructions -- it
+// shows at large batches (profiles/r02_single_step_scaling.txt).
+#include "mapf_lq.hpp"
+
+namespace mapf {
+
+namespace {
+
+template <int Q, int K>
+__global__ void __launch_bounds__(256) lq_step_kernel(const StepArgs p, const uint32_t n_agents) {
+    constexpr int P = K / 2;
+    LaneCtx<Q> x;
+    x.lane = threadIdx.x & 63u;
+    x.g = x.lane & uint32_t(Q - 1);
+    x.base = x.lane & ~uint32_t(Q - 1);
+    x.e = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * uint32_t(64 / Q) + x.lane / uint32_t(Q);
+    x.v0 = x.v1 = true;
+    const uint32_t e = x.e;
+    const uint32_t lane_cell = e * n_agents + uint32_t(K) * x.g;    // my first agent's element index
+    const uint32_t fixed_cell = uint32_t(K) * x.g;                  // ... in a broadcast row
+    const uint64_t env_id = p.env_id_offset + e, t = p.t;
+
+    uint32_t c[P], g[P];
+    {
+        const Packed<P> cells = Packed<P>::load(at(p.state, lane_cell));
+        const Packed<P> gl = Packed<P>::load(at(p.goal, p.goal_broadcast ? fixed_cell : lane_cell));
+#pragma unroll
+        for (int i = 0; i < P; ++i) { c[i] = cells.v[i]; g[i] = gl.v[i]; }
+    }
+    const uint32_t raw = K == 4 ? *reinterpret_cast<const uint32_t *>(at(p.actions, lane_cell))
+                                : uint32_t(*reinterpret_cast<const uint16_t *>(at(p.actions, lane_cell)));
+    // the slip call of my pair(s) for steps 4h .. 4h+3 (one call per pair per step: a single step cannot amortise it)
+    Words4 rng[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) rng[i] = Words4{0u, 0u, 0u, 0u};
+    if (p.c.need_rng) {
+        if constexpr (P == 2) slip_words_x2(p.c, env_id, t >> 2, 2u * x.g, 2u * x.g + 1u, rng[0], rng[1]);
+        else rng[0] = slip_words(p.c, env_id, t >> 2, x.g, 0u, 0u);
+    }
+
+    uint32_t cur[K], act[K], hi[K];
+    MoveEntry entry[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        cur[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu;
+        const uint32_t byte = (raw >> (8 * k)) & 0xFFu;
+        act[k] = byte > 4u ? 0u : byte;
+        entry[k] = move_entry<true>(p.mv, p.c.n_cells, cur[k], act[k]);
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const uint32_t word = step_word(rng[i], t);
+        hi[2 * i] = word & 0xFFFFu;
+        hi[2 * i + 1] = word >> 16;
+    }
+    double q[K];
+    uint32_t nx[K], tie_all = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        uint32_t tie;
+        slip_move_hi_members(p.c, entry[k], hi[k], nx[k], q[k], tie);
+        tie_all = min(tie_all, tie);
+    }
+    if (__builtin_expect(__any(tie_all == 0u && p.c.need_rng), 0)) {
+        // a top-16-bit tie somewhere in the wave: redo with all 53 bits (the slip rows are read from global memory here)
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+            slip_move<false>(p.slip, entry[k], refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi[k]), 0.0, nx[k], q[k]);
+    }
+    uint32_t n[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) n[i] = nx[2 * i] | (nx[2 * i + 1] << 16);
+
+    // is_terminal(prev) and the collision tests in one pass over the agent pairs; per-env facts OR-reduced over the group
+    const PairAcc<true> acc = packed_pair_tests<Q, P, true, true>(x, c, n);
+    uint32_t away_next = 0u, away_prev = 0u;
+#pragma unroll
+    for (int i = 0; i < P; ++i) { away_next |= n[i] ^ g[i]; away_prev |= c[i] ^ g[i]; }
+    uint32_t flags = (PairAcc<true>::hit(acc.vertex) ? 1u : 0u) | (PairAcc<true>::hit(acc.swap) ? 2u : 0u) | (away_next ? 4u : 0u) |
+                     (PairAcc<true>::hit(acc.dup) ? 8u : 0u) | (away_prev ? 16u : 0u);
+    flags = group_reduce<Q, false>(flags, x);
+    const bool was_terminal = (flags & 8u) != 0u || (flags & 16u) == 0u;     // mapf_env.py:210-223
+    const uint32_t f = flags & 7u;
+
+    // total_prob: left-to-right product over agents 0..A-1 (mapf_env.py:257); the total ends in the group's last lane
+    const double prob = packed_prob_product<Q, K>(q);
+
+    // _living_reward (mapf_env.py:436-446), calc_transition_reward_from_local_states (:225-235: collision before goal)
+    double living = p.c.r_living;
+    if (p.c.criteria == 1u) {
+        uint32_t mine = 0u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const uint32_t goal_k = (k & 1) ? g[k / 2] >> 16 : g[k / 2] & 0xFFFFu;
+            mine += (cur[k] == goal_k && act[k] == 0u) ? 1u : 0u;
+        }
+        const int stayed = int(group_reduce<Q, true>(mine, x));
+        living = __dmul_rn(double(int(n_agents) - stayed), p.c.r_living);
+    }
+    const bool coll = (f & 3u) != 0u, goal_next = (f & 4u) == 0u;
+    const double r = coll ? __dadd_rn(p.c.r_clash, living) : (goal_next ? __dadd_rn(p.c.r_goal, living) : living);
+    const double reward = was_terminal ? 0.0 : r;                  // mapf_env.py:239-240 -- (s, 0, True, {"prob": 0})
+    const bool done = coll || goal_next || was_terminal;
+    if (was_terminal) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) n[i] = c[i];
+    }
+
+    Packed<P> out;
+#pragma unroll
+    for (int i = 0; i < P; ++i) out.v[i] = n[i];
+    if (p.out_local) out.store(at(p.out_local, lane_cell));
+    if (x.g == uint32_t(Q - 1) && p.out_prob) *at(p.out_prob, e) = was_terminal ? 0.0 : prob;
+    if (x.g == 0u) {
+        if (p.out_reward) *at(p.out_reward, e) = reward;
+        if (p.out_done) *at(p.out_done, e) = done ? 1 : 0;
+        if (p.out_collision) *at(p.out_collision, e) = (coll && !was_terminal) ? 1 : 0;
+        if (p.out_was_terminal) *at(p.out_was_terminal, e) = was_terminal ? 1 : 0;
+    }
+    if (p.auto_reset && done) {                                    // MapfEnv.reset(): start cells, no reseed
+        Packed<P>::load(at(p.start, p.start_broadcast ? fixed_cell : lane_cell)).store(at(p.state, lane_cell));
+    } else if (!was_terminal) {
+        out.store(at(p.state, lane_cell));
+    }
+}
+
+}  // namespace
+
+// true when the packed layout took the launch (*err = its status); false = not applicable, use lg_step_kernel
+bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err) {
+    if (!tune.quad_lanes || args.uniforms != nullptr) return false;
+    int K = 0;
+    if (tune.force_k != 2 && n_agents % 4 == 0) K = 4;
+    else if (tune.force_k != 4 && n_agents % 2 == 0 && n_agents >= 4) K = 2;
+    else return false;
+    const int Q = n_agents / K;
+    if (Q > 16 || (Q & (Q - 1)) != 0) return false;
+    const uint64_t lanes = args.n_envs * uint64_t(Q);
+    unsigned block = 256u;
+    while (block > 64u && lanes < 256u * uint64_t(block)) block /= 2u;   // small batches: spread over the CUs
+    const uint64_t per_block = block / unsigned(Q);
+    if (args.n_envs == 0 || args.n_envs % per_block != 0) return false;
+    const unsigned grid = unsigned(args.n_envs / per_block);
+    const uint32_t A = uint32_t(n_agents);
+    note_kernel("lq_step_kernel<Q=%d,K=%d> block=%u (packed layout: %d agents per lane)", Q, K, block, K);
+#define MAPF_LQ_STEP(QQ, KK)                                                                                   \
+    if (Q == QQ && K == KK) {                                                                                  \
+        hipLaunchKernelGGL((lq_step_kernel<QQ, KK>), dim3(grid), dim3(block), 0, stream, args, A);             \
+        *err = hipGetLastError();                                                                              \
+        return true;                                                                                           \
+    }
+    MAPF_LQ_STEP(1, 4) MAPF_LQ_STEP(2, 4) MAPF_LQ_STEP(4, 4) MAPF_LQ_STEP(8, 4) MAPF_LQ_STEP(16, 4)
+    MAPF_LQ_STEP(2, 2) MAPF_LQ_STEP(4, 2) MAPF_LQ_STEP(8, 2) MAPF_LQ_STEP(16, 2)
+#undef MAPF_LQ_STEP
+    return false;
+}
+
+}  // namespace mapf

@@ -110,7 +110,7 @@ def test_every_dispatchable_kernel_is_free_of_register_spills(tmp_path):
     jobs = []
     flags = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-I' + os.path.join(ROOT, 'include'),
              '-S', '--cuda-device-only']
-    for unit in ('mapf_lg_kernels', 'mapf_lg_rollout', 'mapf_transitions'):
+    for unit in ('mapf_lg_kernels', 'mapf_lg_rollout', 'mapf_lq_step', 'mapf_transitions'):
         jobs.append((unit, [], tmp_path / (unit + '.s')))
     for k in (4, 2):                                              # packed-layout rollout: one object per (K, RECORD)
         for r in (1, 0):
