@@ -239,7 +239,7 @@ extern "C" {
 
 const char *mapf_last_error(void) { return g_last_error.c_str(); }
 
-const char *mapf_version(void) { return "mapf_hip 0.1.0 (abi 1, gfx950)"; }
+const char *mapf_version(void) { return "mapf_hip 0.2.0 (abi 2, gfx950)"; }
 
 int mapf_device_count(int *out_count) {
     if (!out_count) return fail(MAPF_EINVAL, "out_count is null");

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MAPF_ABI_VERSION 1
+#define MAPF_ABI_VERSION 2
 
 /* status codes */
 #define MAPF_OK            0
