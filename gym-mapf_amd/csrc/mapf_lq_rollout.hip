@@ -270,11 +270,15 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
         // --- my agents' table rows (cell * 96 + action * 16, the table's LDS offset is an immediate): requested first ...
         MoveEntry entry[K];
         u32x2 cells_code[K];
+        uint32_t cell_at[K];   // (all the word-select multiplies first: back to back with their users each one costs an s_nop)
+#pragma unroll
+        for (int k = 0; k < K; ++k) cell_at[k] = (k & 1) ? half_times<1>(c[k / 2], row_bytes) : half_times<0>(c[k / 2], row_bytes);
+#pragma unroll
+        for (int k = 0; k < K; ++k) asm volatile("" : "+v"(cell_at[k]));
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            const uint32_t cell_at = (k & 1) ? half_times<1>(c[k / 2], row_bytes) : half_times<0>(c[k / 2], row_bytes);
-            if (COMPACT) cells_code[k] = lds_at<u32x2>(kMoveAt + (act[k] << 3) + cell_at);
-            else entry[k] = lds_entry_at(kMoveAt + (act[k] << 4) + cell_at);
+            if (COMPACT) cells_code[k] = lds_at<u32x2>(kMoveAt + (act[k] << 3) + cell_at[k]);
+            else entry[k] = lds_entry_at(kMoveAt + (act[k] << 4) + cell_at[k]);
         }
         STAMP(0);   // loop top: action fetch / policy, table read issue
         // --- ... then the previous step is finished while they are in flight
