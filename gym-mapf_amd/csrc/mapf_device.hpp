@@ -80,6 +80,14 @@ __device__ __forceinline__ void store_row(T *base, uint64_t row, const Row<T, N>
     *reinterpret_cast<Row<T, N> *>(base + row * N) = r;
 }
 
+// end-of-step signal of a ONE-WAVE launch (StepArgs::done_flag): every store of the wave is older than this release
+__device__ __forceinline__ void signal_step_done(uint32_t *flag, uint32_t seq) {
+    if (flag) {
+        __threadfence_system();
+        if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ------------------------------------------------------------------ one env step
 template <int A>
 struct StepResult {

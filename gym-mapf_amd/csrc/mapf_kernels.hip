@@ -68,6 +68,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs p) {
     } else if (!res.was_terminal) {
         store_row<uint16_t, A>(p.state, e, nx);
     }
+    signal_step_done(p.done_flag, p.done_seq);
 }
 
 template <int A>

@@ -54,6 +54,8 @@ struct StepArgs {
     double *out_reward, *out_prob;
     uint8_t *out_done, *out_collision, *out_was_terminal;
     uint64_t n_envs, env_id_offset, t;
+    uint32_t *done_flag;           // one-wave launches only (else null): host-visible word that receives done_seq
+    uint32_t done_seq;             //   after every output of the step has been written (system-scope release)
     bool start_broadcast, goal_broadcast, auto_reset;
 };
 

@@ -50,6 +50,7 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
     } else if (!o.was_terminal) {
         store_cells(p.state, e, n_agents, x.g, x.v0, x.v1, next0, next1);
     }
+    signal_step_done(p.done_flag, p.done_seq);
 }
 
 // ------------------------------------------------------- run-time-A helper kernels

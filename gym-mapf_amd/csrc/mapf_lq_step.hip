@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(256) lq_step_kernel(const StepArgs p, const ui
     } else if (!was_terminal) {
         out.store(at(p.state, lane_cell));
     }
+    signal_step_done(p.done_flag, p.done_seq);
 }
 
 }  // namespace
