@@ -393,8 +393,10 @@ def main():
         for k in range(n_timed):
             enqueue(n_warm + k)
         gpu_ms = env.timer_end()
+        torch.cuda.synchronize()
+        env.sync()
+        wall = time.perf_counter() - t0                   # this rank's K steps, device idle again; MAX over ranks below
         barrier()
-        wall = time.perf_counter() - t0
         if dist is not None:
             tmax = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -352,10 +352,17 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
 #pragma unroll
         for (int i = 1; i < P; ++i) away |= n[i] ^ g[i];
         asm volatile("" : "+v"(away));   // stays an integer: as a compare it would travel through scalar masks
-        // zero_half() leaves bits 15 / 31: vertex -> bits 0 / 16, swap -> bits 1 / 17; both halves folded onto bits 0, 1
-        uint32_t bits = (zero_half(acc.vertex) >> 15) | (zero_half(acc.swap) >> 14);
-        bits |= bits >> 16;
-        uint32_t flags = (min(away, 1u) << 2) | bits;
+        uint32_t flags;
+        if constexpr (!MAYBE_TERMINAL) {
+            // every finished episode is reset, so a vertex collision and a swap need not be told apart (same reward,
+            // same status, and is_terminal of the outcome is never asked): one zero test over both minima -> bit 0
+            flags = (min(away, 1u) << 2) | min(zero_half(pk_min_u16(acc.vertex, acc.swap)), 1u);
+        } else {
+            // zero_half() leaves bits 15 / 31: vertex -> bits 0 / 16, swap -> bits 1 / 17; both halves folded onto bits 0, 1
+            uint32_t bits = (zero_half(acc.vertex) >> 15) | (zero_half(acc.swap) >> 14);
+            bits |= bits >> 16;
+            flags = (min(away, 1u) << 2) | bits;
+        }
         flags = group_reduce<Q, false>(flags, x);
         const uint32_t code = MAYBE_TERMINAL ? (flags & 7u) | (terminal << 3) : (flags & 7u);   // terminal is 0 / 1
         STAMP(5);   // flags + group reduce
