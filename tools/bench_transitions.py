@@ -42,8 +42,9 @@ if __name__ == '__main__':
     local = np.stack([s0.ravel(), s1.ravel()], 1).astype(np.uint16)
     acts = np.stack([a0.ravel(), a1.ravel()], 1).astype(np.uint8)
     run('empty-8-8, 2 agents: all (s, a) pairs', 'empty-8-8', 1, 2, local, acts, 9)
+    run('empty-8-8, 2 agents: all (s, a) pairs x 32', 'empty-8-8', 1, 2, np.tile(local, (32, 1)), np.tile(acts, (32, 1)), 9)
     rs = np.random.RandomState(0)
-    for A, M, N in ((4, 81, 200000), (8, 6561, 2000)):
+    for A, M, N in ((4, 81, 200000), (4, 81, 2000000), (8, 6561, 2000), (8, 6561, 20000)):
         local = np.stack([rs.choice(682, A, replace=False) for _ in range(N)]).astype(np.uint16)
         acts = rs.randint(0, 5, size=(N, A)).astype(np.uint8)
         run('room-32-32-4, %d agents: random queries' % A, 'room-32-32-4', 6, A, local, acts, M)
