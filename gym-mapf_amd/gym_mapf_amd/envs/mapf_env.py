@@ -183,6 +183,7 @@ class MapfEnv(_EnvBase):
         self.observation_space = _make_discrete(self.nS)
 
         self.P = _TransitionModel(self)
+        self._transitions_memo = {}
         self._vec = None        # one-env VecMapfEnv, created on first use (needs the GPU)
         self._single = None     # one-agent helper env for single_agent_movements
         self._terminal = None   # is_terminal(self.s) if known
@@ -263,9 +264,20 @@ class MapfEnv(_EnvBase):
         self._terminal = done and (len(set(local)) < n or local == self._goal_local)
         return state, float(out['reward'][0]), done, {"prob": float(out['prob'][0]), "collision": collision}
 
+    def _partial_get_transitions(self, s):
+        """``env.P[s]`` (reference :481-483)."""
+        return _TransitionsOfState(self, s)
+
     def _get_transitions(self, s, a):
         """All branches of taking joint action ``a`` in joint state ``s``, in the reference's order
-        (mapf_env.py:448-478); enumerated by the ``mapf_transitions`` kernel."""
+        (mapf_env.py:448-478); enumerated by the ``mapf_transitions`` kernel.  Memoised per (s, a) like the
+        reference's ``functools.lru_cache(maxsize=None)`` (planners sweep the same pairs many times)."""
+        hit = self._transitions_memo.get((s, a))
+        if hit is None:
+            hit = self._transitions_memo[(s, a)] = self._enumerate_transitions(s, a)
+        return hit
+
+    def _enumerate_transitions(self, s, a):
         n, V = self.n_agents, len(self.valid_locations)
         local = np.asarray([integer_to_vector(s, [V] * n, n, lambda x: x)], dtype=np.uint16)
         digits = np.asarray([integer_to_vector(a, [len(ACTIONS)] * n, n, lambda x: x)], dtype=np.uint8)

@@ -303,6 +303,18 @@ def test_similar_transitions_probability_summed():          # mapf_env_tests.py:
 
 
 @pytest.mark.gpu
+def test_transition_lists_are_memoised_like_the_reference():    # mapf_env.py:448 lru_cache, :481-483
+    env = MapfEnv(MapfGrid(['..', '..']), 2, ((0, 0), (1, 1)), ((1, 1), (0, 0)), 0.1, REWARD_OF_CLASH, REWARD_OF_GOAL,
+                  REWARD_OF_LIVING, OptimizationCriteria.Makespan)
+    a = vector_action_to_integer((RIGHT, LEFT))
+    first = env.P[env.s][a]
+    assert env.P[env.s][a] is first                          # the same list object, not a second enumeration
+    assert env._partial_get_transitions(env.s)[a] is first
+    assert env._get_transitions(env.s, a) is first
+    assert abs(sum(p for ((p, _), _, _, _) in first) - 1.0) < 1e-12
+
+
+@pytest.mark.gpu
 def test_is_terminal_and_single_agent_movements_match_reference():      # mapf_env.py:210-223, :163-184
     import numpy as np
     from conftest import load_json, load_trajectory_set
