@@ -305,6 +305,9 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
 
     mapf::SlipRow slip_host[8];
     h->c.need_rng = build_slip_table(d->fail_prob, slip_host, h->c.p_cand) ? 1u : 0u;
+    h->c.top_tie = 0u;
+    for (unsigned code = 0; code < 8; ++code)
+        if (slip_host[code].n == 3 && slip_host[code].thr[2] < (uint64_t(1) << 53)) h->c.top_tie = 1u;   // (shorter lists compare against their last threshold, 65535)
     // the single-step kernels rebuild a merged probability from its members instead of reading the row: the ordered
     // sum ((m ? p_m : 0) + (r ? p_r : 0)) + (l ? p_l : 0) must reproduce the table bit for bit
     for (unsigned code = 0; code < 8; ++code)

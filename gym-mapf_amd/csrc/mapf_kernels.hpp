@@ -36,6 +36,7 @@ struct EnvConsts {
     double r_clash, r_goal, r_living;
     double p_cand[3];              // probabilities of the three candidates: intended move, right slip, left slip
     uint32_t need_rng;             // 0 when every slip list has one entry (e.g. fail_prob == 0)
+    uint32_t top_tie;              // 1 when some list's last cumulative sum rounds below 1.0 (a uniform can lie past it)
     uint32_t criteria;             // 0 Makespan, 1 SoC
     uint32_t n_cells;              // V
     uint32_t seed_lo, seed_hi;     // slip-stream Philox key

@@ -56,21 +56,34 @@ __device__ __forceinline__ MoveEntry lds_entry_at(uint32_t byte_address) {   // 
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
-// sampled list slot of one agent from the top 16 bits of its uniform (see slip_move_hi): idx, its probability, and
-// the tie distance (0 <=> hi equals a threshold -> exact path)
-__device__ __forceinline__ uint32_t sample_slot(uint32_t slip_at, const MoveEntry &entry, uint32_t hi, double &q,
-                                                uint32_t &tie_dist) {
-    // (slot = how many of the first two thresholds hi has passed: see slip_move_hi in mapf_device.hpp)
-    const uint32_t t0 = entry.z & 0xFFFFu, t1 = entry.z >> 16;
-    const uint32_t d0 = hi - t0, d1 = hi - t1, d2 = hi - 0xFFFFu;
-    tie_dist = min(d0, min(d1, d2));
-    const uint32_t idx = 2u - (d0 >> 31) - (d1 >> 31);
-    q = lds_at<double>(slip_at + (idx << 3) + entry_row_offset(entry));
-    return idx;
+// ---- packed slot sampling of the fused rollout: both threshold compares of an agent in one packed subtract.
+// The 16-bit uniform and the entry's two thresholds are biased by 0x8000 (unsigned order -> signed order), so that a
+// SATURATING signed 16-bit subtract keeps the sign of the true difference and is zero exactly on a tie:
+//   d = sat(h - t) per half-word;  d < 0 <=> hi < th_k (slot not passed);  d == 0 <=> tie (exact 53-bit redo)
+// sign = d >> 15 is 0 / -1 per half; slot = 2 + sign0 + sign1 turns into the probability's LDS address and into the
+// v_perm selector of the slot's cell by one dot product each (v_dot2_i32_i16 with (8, 8) resp. (0x0202, 0x0202)).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+constexpr uint32_t kHalfBias = 0x80008000u;
+__device__ __forceinline__ uint32_t pk_sub_sat_i16(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
 }
-// list slot idx of an entry, zero-extended: one v_perm_b32
-__device__ __forceinline__ uint32_t cell_lo(const MoveEntry &entry, uint32_t idx) {
-    return __builtin_amdgcn_perm(entry.y, entry.x, 0x0C0C0100u + idx * 0x0202u);
+__device__ __forceinline__ uint32_t pk_sign_i16(uint32_t a) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(s16x2, a) >> 15); }
+// a.lo * b.lo + a.hi * b.hi + c (signed halves), all three operands in vector registers: the two-operand form the
+// compiler prefers accumulates into its destination, which would cost a v_mov of `c` per use
+__device__ __forceinline__ uint32_t dot2_i16(uint32_t a, uint32_t b, uint32_t c) {
+    uint32_t r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// one agent: `h` = its biased uniform in both half-words, `entry.z` = its biased thresholds.  Returns the packed
+// difference (tie <=> a zero half); the slot's probability address (relative to the slip rows) and cell selector go out
+__device__ __forceinline__ uint32_t sample_slot_packed(const MoveEntry &entry, uint32_t h, uint32_t eights, uint32_t steps,
+                                                       uint32_t sel_base, uint32_t &q_at, uint32_t &cell) {
+    const uint32_t d = pk_sub_sat_i16(h, entry.z);
+    const uint32_t sign = pk_sign_i16(d);
+    q_at = dot2_i16(sign, eights, entry_row_offset(entry));       // row + 8 * (sign0 + sign1); slot 2's address is 16 further
+    cell = __builtin_amdgcn_perm(entry.y, entry.x, dot2_i16(sign, steps, sel_base));
+    return d;
 }
 
 // "same half-word" tests only: my pair against a pair that arrives straight or half-swapped (half rotation)

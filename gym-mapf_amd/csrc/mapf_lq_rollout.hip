@@ -18,6 +18,10 @@
 //   * keeps the auto-reset / terminal bookkeeping as one integer code = vertex | swap << 1 | off_goal << 2 |
 //     was_terminal << 3 per env that indexes the LDS outcome table and, compared against wave-uniform constants,
 //     drives every select;
+//   * samples an agent's list slot with packed 16-bit arithmetic (sample_slot_packed in mapf_lq.hpp): both threshold
+//     compares are one saturating v_pk_sub_i16 of bias-shifted operands, and the slot's probability address and cell
+//     selector each come out of one v_dot2_i32_i16 of the sign halves -- the kernel is bound by vector-instruction issue
+//     (SQ_ACTIVE_INST_VALU ~ 98 % of the SIMD's cycles at two waves per SIMD), so instructions are what is saved;
 //   * owns the whole LDS image (slip rows at 0, outcome rows at 768, move table at 1024), so every LDS address is a
 //     register plus an immediate offset, and stages the move table with SIX columns per cell (column 5 = STAY again):
 //     an action byte is extracted and clamped by one v_min_u32 with a byte select, a table address is
@@ -53,7 +57,7 @@ static_assert(kOutcomeAt + sizeof(OutcomeRow) * 16 <= kMoveAt, "LDS image: slip 
 // terminal (the handle knows: mapf_create looks) that cannot happen after the launch's first step -- a done env is back
 // on its start cells -- and the !TERM instance runs every later step without the was-terminal selects.
 template <int Q, int K, bool RECORD, bool STREAM, bool SOC, bool COMPACT, bool TERM>
-__global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
+__global__ void __launch_bounds__(1024) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
     constexpr int P = K / 2;   // packed dwords per lane
     static_assert(K == 2 || K == 4, "two or four agents per lane");
     // the kernel's only LDS object, so it sits at LDS address 0 and every offset below is an instruction immediate
@@ -99,13 +103,17 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
                 if (w < n_words) {
                     // COMPACT rows: {c0 | c1 << 16, c2 | byte offset of the code's slip row << 16}
                     if (COMPACT) reinterpret_cast<u32x2 *>(lds_mv)[w] = u32x2{part[k].x, (part[k].y & 0xFFFFu) | (part[k].w << 16)};
-                    else lds_mv[w] = part[k];
+                    else lds_mv[w] = make_uint4(part[k].x, part[k].y, part[k].z ^ kHalfBias, part[k].w);   // thresholds: see sample_slot_packed
                 }
             }
         }
     }
     stage_outcome_table(p.c, outcome);
     stage_slip_table(p.slip, slip);   // ends with __syncthreads()
+    if (COMPACT) {   // the thresholds come from the slip rows' packed word: biased like the full table's
+        if (threadIdx.x < 8u) slip[threadIdx.x].th[2] ^= kHalfBias;
+        __syncthreads();
+    }
 
     uint32_t terminal = packed_is_terminal<Q, P>(x, c, g) ? 1u : 0u;
     const uint32_t start_terminal = (p.auto_reset && packed_is_terminal<Q, P>(x, start_c, g)) ? 1u : 0u;
@@ -227,6 +235,8 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
     // (word picked at run time, call refreshed when t is a multiple of four).  FIRST = the launch's first step: nothing
     // is pending yet and the slip call is refreshed whatever t is.  TAIL = the action rows may run out within kAhead
     // steps, so the prefetch address is clamped.  `raw` is the register that holds this step's action word.
+    uint32_t pk_eights = 0x00080008u, pk_steps = 0x02020202u, sel_base = 0x0C0C0504u;   // sample_slot_packed's constants,
+    asm volatile("" : "+v"(pk_eights), "+v"(pk_steps), "+v"(sel_base));                   // one vector register each
     uint32_t row_bytes = COMPACT ? kCompactCols * kCompactEntry : kMoveCols * uint32_t(sizeof(MoveEntry));
     asm volatile("" : "+v"(row_bytes));   // (one register for the whole loop; as an SGPR operand the assembler rejects the SDWA form)
     auto one_step = [&](const uint32_t s, uint32_t &raw, auto w_tag, auto first_tag, auto tail_tag) __attribute__((always_inline)) {
@@ -313,32 +323,32 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
             else rng[0] = slip_words(p.c, env_id, t >> 2, x.g, 0u, 0u);
         }
         STAMP(2);   // slip Philox (1 step in 4)
-        uint32_t hi[K];
+        double q[K];
+        uint32_t n[P], word[P], tie_all = 0u;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
-            const uint32_t word = W == 0 ? rng[i].w0 : W == 1 ? rng[i].w1 : W == 2 ? rng[i].w2 : W == 3 ? rng[i].w3 : step_word(rng[i], t);
-            hi[2 * i] = word & 0xFFFFu;
-            hi[2 * i + 1] = word >> 16;
+            word[i] = W == 0 ? rng[i].w0 : W == 1 ? rng[i].w1 : W == 2 ? rng[i].w2 : W == 3 ? rng[i].w3 : step_word(rng[i], t);
+            const uint32_t biased = word[i] ^ kHalfBias;             // low half: agent 2i's uniform, high half: agent 2i+1's
+            uint32_t q_at[2], cell[2];
+            const uint32_t d_even = sample_slot_packed(entry[2 * i], __builtin_amdgcn_perm(biased, biased, 0x01000100u), pk_eights, pk_steps,
+                                                       sel_base, q_at[0], cell[0]);
+            const uint32_t d_odd = sample_slot_packed(entry[2 * i + 1], __builtin_amdgcn_perm(biased, biased, 0x03020302u), pk_eights, pk_steps,
+                                                      sel_base, q_at[1], cell[1]);
+            q[2 * i] = lds_at<double>(kSlipAt + 16u + q_at[0]);
+            q[2 * i + 1] = lds_at<double>(kSlipAt + 16u + q_at[1]);
+            n[i] = cell[0] | (cell[1] << 16);
+            tie_all = i == 0 ? pk_min_u16(d_even, d_odd) : pk_min_u16(tie_all, pk_min_u16(d_even, d_odd));
         }
-        double q[K];
-        uint32_t idx[K], tie[K];
-#pragma unroll
-        for (int k = 0; k < K; ++k) idx[k] = sample_slot(kSlipAt, entry[k], hi[k], q[k], tie[k]);
-        uint32_t n[P];
-#pragma unroll
-        for (int i = 0; i < P; ++i) n[i] = cell_lo(entry[2 * i], idx[2 * i]) | (cell_lo(entry[2 * i + 1], idx[2 * i + 1]) << 16);
-        uint32_t tie_all = tie[0];
-#pragma unroll
-        for (int k = 1; k < K; ++k) tie_all = min(tie_all, tie[k]);
         // (without slip the words stay zero and every threshold is 65535: no tie can fire, so need_rng is not asked here)
-        if (__builtin_expect(__any(tie_all == 0u), 0)) {
+        if (__builtin_expect(__any(zero_half(tie_all) != 0u), 0)) {
             // a top-16-bit tie somewhere in the wave: redo with all 53 bits
             uint32_t nx[K];
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 MoveEntry full = entry[k];
                 if (COMPACT) full.y = (full.y & 0xFFFFu) | ((full.w / uint32_t(sizeof(SlipRow))) << 16);   // the code, where entry_code() looks
-                slip_move<false>(slip, full, refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi[k]), 0.0, nx[k], q[k]);
+                const uint32_t hi = (k & 1) ? word[k / 2] >> 16 : word[k / 2] & 0xFFFFu;
+                slip_move<false>(slip, full, refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi), 0.0, nx[k], q[k]);
             }
 #pragma unroll
             for (int i = 0; i < P; ++i) n[i] = nx[2 * i] | (nx[2 * i + 1] << 16);
@@ -352,27 +362,33 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
 #pragma unroll
         for (int i = 1; i < P; ++i) away |= n[i] ^ g[i];
         asm volatile("" : "+v"(away));   // stays an integer: as a compare it would travel through scalar masks
-        uint32_t flags;
+        // code16 = code * 16 (the byte offset of the code's outcome row), code = vertex | swap << 1 | off_goal << 2 | was_terminal << 3
+        uint32_t code16;
         if constexpr (!MAYBE_TERMINAL) {
             // every finished episode is reset, so a vertex collision and a swap need not be told apart (same reward,
-            // same status, and is_terminal of the outcome is never asked): one zero test over both minima -> bit 0
-            flags = (min(away, 1u) << 2) | min(zero_half(pk_min_u16(acc.vertex, acc.swap)), 1u);
+            // same status, and is_terminal of the outcome is never asked): one zero test over both minima -> bit 0.
+            // Both facts are clamped by a v_min (written out: the optimiser turns min(x, 1) into compare + select).
+            const uint32_t hit = zero_half(pk_min_u16(acc.vertex, acc.swap));   // 0, or bits 15 / 31
+            uint32_t off_goal, coll16;
+            asm("v_min_u32 %0, 1, %1" : "=v"(off_goal) : "v"(away));
+            asm("v_min_u32 %0, 16, %1" : "=v"(coll16) : "v"(hit));
+            code16 = group_reduce<Q, false>((off_goal << 6) | coll16, x);
         } else {
             // zero_half() leaves bits 15 / 31: vertex -> bits 0 / 16, swap -> bits 1 / 17; both halves folded onto bits 0, 1
             uint32_t bits = (zero_half(acc.vertex) >> 15) | (zero_half(acc.swap) >> 14);
             bits |= bits >> 16;
-            flags = (min(away, 1u) << 2) | bits;
+            const uint32_t flags = group_reduce<Q, false>((min(away, 1u) << 2) | bits, x);
+            code16 = ((flags & 7u) | (terminal << 3)) << 4;   // terminal is 0 / 1
         }
-        flags = group_reduce<Q, false>(flags, x);
-        const uint32_t code = MAYBE_TERMINAL ? (flags & 7u) | (terminal << 3) : (flags & 7u);   // terminal is 0 / 1
         STAMP(5);   // flags + group reduce
 
         // --- outcome: the row (status for both criteria, reward for Makespan) is only REQUESTED here; everything the
         // next step's table address depends on is derived from `code` without waiting for it
-        const u32x4 row = lds_at<u32x4>(kOutcomeAt + code * uint32_t(sizeof(OutcomeRow)));   // {reward lo, hi, status, pad}
+        static_assert(sizeof(OutcomeRow) == 16, "code16 addresses the outcome rows");
+        const u32x4 row = lds_at<u32x4>(kOutcomeAt + code16);   // {reward lo, hi, status, pad}
         const uint32_t row_status = row.z;
         double reward = __hiloint2double(int(row.y), int(row.x));
-        const bool was_terminal = MAYBE_TERMINAL && code > 7u;
+        const bool was_terminal = MAYBE_TERMINAL && code16 > 7u * 16u;
         if (SOC) {
             // _living_reward: mapf_env.py:436-446
             uint32_t mine = 0u;
@@ -383,7 +399,7 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
             }
             const int stayed = int(group_reduce<Q, true>(mine, x));
             const double living = __dmul_rn(double(int(n_agents) - stayed), p.c.r_living);
-            const uint32_t f = code & 7u;
+            const uint32_t f = (code16 >> 4) & 7u;
             const bool coll = (f & 3u) != 0u, goal_next = (f & 4u) == 0u;
             const double r = coll ? __dadd_rn(p.c.r_clash, living) : (goal_next ? __dadd_rn(p.c.r_goal, living) : living);
             reward = was_terminal ? 0.0 : r;
@@ -404,11 +420,11 @@ __global__ void __launch_bounds__(COMPACT ? 1024 : 512) lq_rollout_kernel(const 
         // MapfEnv.reset(): start cells, no reseed.  Every code except "off goal, no collision, not terminal" (= 4) ends
         // the episode; the returned state is terminal after a vertex collision or on goal (mapf_env.py:210-223), a swap
         // alone is not: bits 0 (vertex), 2 (flipped: on goal) and 3 (was terminal) of code ^ 4
-        const uint32_t ended = code ^ 4u;
+        const uint32_t ended = code16 ^ (4u * 16u);
         const bool back = ended > reset_above;                 // never with auto-reset off
 #pragma unroll
         for (int i = 0; i < P; ++i) c[i] = back ? start_c[i] : n[i];
-        if (MAYBE_TERMINAL) terminal = back ? start_terminal : min(ended & 13u, 1u);
+        if (MAYBE_TERMINAL) terminal = back ? start_terminal : min(ended & (13u * 16u), 1u);
         STAMP(7);   // reset handling
     };
     using Generic = std::integral_constant<int, -1>;
@@ -554,6 +570,9 @@ static bool layout_fits(int n_agents, int K, const RolloutArgs &args, size_t lds
     // which is cheap next to a rollout's steps, and an idle CU is not
     const uint64_t lanes = args.n_envs * uint64_t(Q);
     while (block > 64u && lanes < 256u * uint64_t(block)) block /= 2u;
+    // one table copy per CU and a batch that gives every CU 1024 lanes: sixteen waves share that copy (four per SIMD
+    // instead of two: +4 % at 131072 envs x 8 agents)
+    if (copies == 1 && lanes >= 256u * 1024u && args.n_envs % (1024u / unsigned(Q)) == 0) block = 1024u;
     const uint64_t per_block = block / unsigned(Q);
     if (args.n_envs % per_block != 0 || lanes < 64 * 16) return false;
     *block_out = block;
@@ -563,7 +582,9 @@ static bool layout_fits(int n_agents, int K, const RolloutArgs &args, size_t lds
 
 // true when a packed layout took the launch (*err = its status); false = not applicable, use the lane-group kernel
 bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err) {
-    if (!tune.quad_lanes) return false;
+    // top_tie: a three-entry list whose last cumulative sum rounds below 1.0 needs a third compare per agent (hi = 65535);
+    // the packed sampling does two, so such a table (none arises from fail_prob / 2 splits) stays with the lane-group kernel
+    if (!tune.quad_lanes || args.c.top_tie) return false;
     const bool record = args.rec_local != nullptr;
     const uint32_t A = uint32_t(n_agents);
     unsigned block = 0;
