@@ -421,7 +421,8 @@ __global__ void __launch_bounds__(1024) lq_rollout_kernel(const RolloutArgs p, c
         // the episode; the returned state is terminal after a vertex collision or on goal (mapf_env.py:210-223), a swap
         // alone is not: bits 0 (vertex), 2 (flipped: on goal) and 3 (was terminal) of code ^ 4
         const uint32_t ended = code16 ^ (4u * 16u);
-        const bool back = ended > reset_above;                 // never with auto-reset off
+        // (the instance without terminal handling only runs with auto-reset on: one compare against the code itself)
+        const bool back = MAYBE_TERMINAL ? ended > reset_above : code16 != 4u * 16u;   // never with auto-reset off
 #pragma unroll
         for (int i = 0; i < P; ++i) c[i] = back ? start_c[i] : n[i];
         if (MAYBE_TERMINAL) terminal = back ? start_terminal : min(ended & (13u * 16u), 1u);
