@@ -571,9 +571,6 @@ static bool layout_fits(int n_agents, int K, const RolloutArgs &args, size_t lds
     // which is cheap next to a rollout's steps, and an idle CU is not
     const uint64_t lanes = args.n_envs * uint64_t(Q);
     while (block > 64u && lanes < 256u * uint64_t(block)) block /= 2u;
-    // one table copy per CU and a batch that gives every CU 1024 lanes: sixteen waves share that copy (four per SIMD
-    // instead of two: +4 % at 131072 envs x 8 agents)
-    if (copies == 1 && lanes >= 256u * 1024u && args.n_envs % (1024u / unsigned(Q)) == 0) block = 1024u;
     const uint64_t per_block = block / unsigned(Q);
     if (args.n_envs % per_block != 0 || lanes < 64 * 16) return false;
     *block_out = block;
