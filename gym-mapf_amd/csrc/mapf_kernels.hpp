@@ -129,7 +129,9 @@ struct RolloutTuning {
     bool quad_lanes = true;          // MAPF_QUAD_LANES=0 forces the pair layout
     uint64_t quad_min_lanes = 0;     // four agents per lane need at least this many lanes (MAPF_QUAD_MIN_LANES; default: one
                                      // wave on every SIMD of the device); below that two agents per lane
-    int force_k = 0;                 // MAPF_LQ_K=2|4 pins the agents per lane of the packed layout (tests)
+    uint64_t oct_min_lanes = 0;      // eight agents per lane need at least this many lanes (MAPF_OCT_MIN_LANES; default:
+                                     //   two waves on every SIMD)
+    int force_k = 0;                 // MAPF_LQ_K=2|4|8 pins the agents per lane of the packed layout (tests)
     size_t mv_lds_max_bytes = 0;     // largest move table staged into LDS (MAPF_MV_LDS_MAX_BYTES; default: two blocks per CU)
 };
 RolloutTuning default_rollout_tuning(int device);

@@ -251,6 +251,8 @@ RolloutTuning default_rollout_tuning(int device) {
     t.quad_min_lanes = uint64_t(n_cu) * 4u * 64u;        // CUs x SIMDs x lanes
     if (const char *e = getenv("MAPF_LQ_K")) t.force_k = atoi(e);
     if (const char *e = getenv("MAPF_QUAD_MIN_LANES")) t.quad_min_lanes = uint64_t(strtoull(e, nullptr, 10));
+    t.oct_min_lanes = uint64_t(n_cu) * 4u * 64u * 2u;    // (eight agents per lane: see try_launch_rollout_lq)
+    if (const char *e = getenv("MAPF_OCT_MIN_LANES")) t.oct_min_lanes = uint64_t(strtoull(e, nullptr, 10));
     t.mv_lds_max_bytes = (kLdsBytes - kLdsReserve) / 2;
     if (const char *e = getenv("MAPF_MV_LDS_MAX_BYTES")) t.mv_lds_max_bytes = size_t(strtoull(e, nullptr, 10));
     return t;

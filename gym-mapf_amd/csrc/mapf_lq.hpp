@@ -1,5 +1,5 @@
 // Device helpers shared by the packed-layout kernels (mapf_lq_rollout.hip: fused rollout, mapf_lq_step.hip: single
-// step): K = 2 or 4 agents per lane as P = K/2 packed 2 x u16 registers, Q = A/K lanes per env.
+// step): K = 2, 4 or 8 agents per lane as P = K/2 packed 2 x u16 registers, Q = A/K lanes per env.
 #pragma once
 #include "mapf_lg.hpp"
 
@@ -21,6 +21,18 @@ template <> struct Packed<1> {
     static __device__ __forceinline__ Packed load(const void *p) { return Packed{{*reinterpret_cast<const uint32_t *>(p)}}; }
     __device__ __forceinline__ void store(void *p) const { *reinterpret_cast<uint32_t *>(p) = v[0]; }
     __device__ __forceinline__ void store_global(gu16 p) const { *(gu32)p = v[0]; }
+};
+template <> struct Packed<4> {
+    uint32_t v[4];
+    static __device__ __forceinline__ Packed load(const void *p) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(p);
+        return Packed{{w.x, w.y, w.z, w.w}};
+    }
+    __device__ __forceinline__ void store(void *p) const { *reinterpret_cast<uint4 *>(p) = make_uint4(v[0], v[1], v[2], v[3]); }
+    __device__ __forceinline__ void store_global(gu16 p) const {
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        *(__attribute__((address_space(1))) u32x4_ *)p = u32x4_{v[0], v[1], v[2], v[3]};
+    }
 };
 template <> struct Packed<2> {
     uint32_t v[2];

@@ -1,4 +1,4 @@
-// Packed-lane rollout kernel: K = 2 or 4 agents per lane (one or two packed cell pairs), Q = A/K lanes per env.
+// Packed-lane rollout kernel: K = 2, 4 or 8 agents per lane (one, two or four packed cell pairs), Q = A/K lanes per env.
 //
 // Why a second lane layout beside mapf_lg.hpp's: there everything that is per ENV -- flag reduction, outcome lookup,
 // totals, reset handling, the hand-over steps of the probability product -- is replicated over the L = A/2 lanes of a
@@ -57,9 +57,9 @@ static_assert(kOutcomeAt + sizeof(OutcomeRow) * 16 <= kMoveAt, "LDS image: slip 
 // terminal (the handle knows: mapf_create looks) that cannot happen after the launch's first step -- a done env is back
 // on its start cells -- and the !TERM instance runs every later step without the was-terminal selects.
 template <int Q, int K, bool RECORD, bool STREAM, bool SOC, bool COMPACT, bool TERM>
-__global__ void __launch_bounds__(1024) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
+__global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
     constexpr int P = K / 2;   // packed dwords per lane
-    static_assert(K == 2 || K == 4, "two or four agents per lane");
+    static_assert(K == 2 || K == 4 || K == 8, "two, four or eight agents per lane");
     // the kernel's only LDS object, so it sits at LDS address 0 and every offset below is an instruction immediate
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_image[];
     SlipRow *slip = reinterpret_cast<SlipRow *>(lds_image + kSlipAt);
@@ -161,12 +161,14 @@ __global__ void __launch_bounds__(1024) lq_rollout_kernel(const RolloutArgs p, c
     // A step consumes the register that holds its row and reloads THAT register with row s+kAhead, so in the unrolled
     // part of the loop the registers simply take turns (rotating a register through a move would be a use, i.e. a
     // wait); a single step outside it uses raw[0] and shifts the others down afterwards.
-    constexpr uint32_t kAhead = K == 4 ? 4 : 8;
+    constexpr uint32_t kAhead = K == 2 ? 8 : 4;
+    using RawWord = std::conditional_t<K == 8, uint64_t, uint32_t>;   // one action byte per agent of the lane
     const uint32_t last_row = p.n_steps ? p.n_steps - 1u : 0u;
     auto load_raw = [&]() __attribute__((always_inline)) {
-        return K == 4 ? *reinterpret_cast<const uint32_t *>(act_lane) : uint32_t(*reinterpret_cast<const uint16_t *>(act_lane));
+        if constexpr (K == 8) return *reinterpret_cast<const uint64_t *>(act_lane);
+        else return K == 4 ? *reinterpret_cast<const uint32_t *>(act_lane) : uint32_t(*reinterpret_cast<const uint16_t *>(act_lane));
     };
-    uint32_t raw[kAhead] = {};
+    RawWord raw[kAhead] = {};
     if (STREAM && p.n_steps > 0) {
         raw[0] = load_raw();
 #pragma unroll
@@ -239,7 +241,7 @@ __global__ void __launch_bounds__(1024) lq_rollout_kernel(const RolloutArgs p, c
     asm volatile("" : "+v"(pk_eights), "+v"(pk_steps), "+v"(sel_base));                   // one vector register each
     uint32_t row_bytes = COMPACT ? kCompactCols * kCompactEntry : kMoveCols * uint32_t(sizeof(MoveEntry));
     asm volatile("" : "+v"(row_bytes));   // (one register for the whole loop; as an SGPR operand the assembler rejects the SDWA form)
-    auto one_step = [&](const uint32_t s, uint32_t &raw, auto w_tag, auto first_tag, auto tail_tag) __attribute__((always_inline)) {
+    auto one_step = [&](const uint32_t s, RawWord &raw, auto w_tag, auto first_tag, auto tail_tag) __attribute__((always_inline)) {
         constexpr int W = decltype(w_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value, TAIL = decltype(tail_tag)::value;
         constexpr bool MAYBE_TERMINAL = TERM || FIRST;   // (the launch's first step finds whatever state the last launch left)
@@ -250,7 +252,7 @@ __global__ void __launch_bounds__(1024) lq_rollout_kernel(const RolloutArgs p, c
         if (STREAM) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                const uint32_t byte = (raw >> (8 * k)) & 0xFFu;
+                const uint32_t byte = uint32_t(raw >> (8 * k)) & 0xFFu;
                 act[k] = COMPACT ? (byte > 4u ? 0u : byte) : min(byte, 5u);   // six columns: extract + clamp is one v_min_u32 (byte select)
             }
 #pragma unroll
@@ -263,17 +265,28 @@ __global__ void __launch_bounds__(1024) lq_rollout_kernel(const RolloutArgs p, c
 #pragma unroll
             for (int k = 0; k < K; ++k) act[k] = greedy_action(p.policy_cells, p.c.n_cells, cur[k], goal_rc[k]);
         } else {   // policy stream: one Philox call covers agents 4j .. 4j+3
-            uint32_t w[4];
-            const uint32_t quad = K == 4 ? x.g : x.g >> 1;
-            const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | (quad << 24);
-            philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, p.c.pol_lo, p.c.pol_hi, w);
-            if (K == 4) {
+            if constexpr (K == 8) {
 #pragma unroll
-                for (int k = 0; k < K; ++k) act[k] = __umulhi(w[k], 5u);
+                for (int j = 0; j < 2; ++j) {
+                    uint32_t w[4];
+                    const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | ((2u * x.g + uint32_t(j)) << 24);
+                    philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, p.c.pol_lo, p.c.pol_hi, w);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) act[4 * j + k] = __umulhi(w[k], 5u);
+                }
             } else {
-                const bool upper = (x.g & 1u) != 0u;
-                act[0] = __umulhi(upper ? w[2] : w[0], 5u);
-                act[1] = __umulhi(upper ? w[3] : w[1], 5u);
+                uint32_t w[4];
+                const uint32_t quad = K == 4 ? x.g : x.g >> 1;
+                const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | (quad << 24);
+                philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, p.c.pol_lo, p.c.pol_hi, w);
+                if (K == 4) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) act[k] = __umulhi(w[k], 5u);
+                } else {
+                    const bool upper = (x.g & 1u) != 0u;
+                    act[0] = __umulhi(upper ? w[2] : w[0], 5u);
+                    act[1] = __umulhi(upper ? w[3] : w[1], 5u);
+                }
             }
         }
 
@@ -319,7 +332,10 @@ __global__ void __launch_bounds__(1024) lq_rollout_kernel(const RolloutArgs p, c
         // one slip-stream call per pair serves four steps
         const bool refresh = FIRST || W == 0 || (W < 0 && (t & 3u) == 0u);
         if (refresh && p.c.need_rng) {
-            if constexpr (P == 2) slip_words_x2(p.c, env_id, t >> 2, 2u * x.g, 2u * x.g + 1u, rng[0], rng[1]);
+            if constexpr (P == 4) {
+                slip_words_x2(p.c, env_id, t >> 2, 4u * x.g, 4u * x.g + 1u, rng[0], rng[1]);
+                slip_words_x2(p.c, env_id, t >> 2, 4u * x.g + 2u, 4u * x.g + 3u, rng[2], rng[3]);
+            } else if constexpr (P == 2) slip_words_x2(p.c, env_id, t >> 2, 2u * x.g, 2u * x.g + 1u, rng[0], rng[1]);
             else rng[0] = slip_words(p.c, env_id, t >> 2, x.g, 0u, 0u);
         }
         STAMP(2);   // slip Philox (1 step in 4)
@@ -436,7 +452,7 @@ __global__ void __launch_bounds__(1024) lq_rollout_kernel(const RolloutArgs p, c
     using Yes = std::true_type;
     using No = std::false_type;
     auto shift_raw = [&]() __attribute__((always_inline)) {   // after a single step: raw[0] was reloaded with row s + kAhead
-        const uint32_t newest = raw[0];
+        const RawWord newest = raw[0];
 #pragma unroll
         for (uint32_t j = 0; j + 1 < kAhead; ++j) raw[j] = raw[j + 1];
         raw[kAhead - 1] = newest;
@@ -516,10 +532,10 @@ hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size
 
 }  // namespace
 
-// This file is compiled once per (agents per lane, recording) pair -- -DMAPF_LQ_K=4|2 -DMAPF_LQ_RECORD=1|0 -- so that
-// its 72 kernel instances build in parallel; each object exports one launcher, the K=4 / RECORD=1 object also the router.
+// This file is compiled once per (agents per lane, recording) pair -- -DMAPF_LQ_K=8|4|2 -DMAPF_LQ_RECORD=1|0 -- so that
+// its kernel instances build in parallel; each object exports one launcher, the K=4 / RECORD=1 object also the router.
 #if !defined(MAPF_LQ_K) || !defined(MAPF_LQ_RECORD)
-#error "compile with -DMAPF_LQ_K=4|2 -DMAPF_LQ_RECORD=1|0"
+#error "compile with -DMAPF_LQ_K=8|4|2 -DMAPF_LQ_RECORD=1|0"
 #endif
 #define MAPF_LQ_CAT3(a, b, c) a##b##_r##c
 #define MAPF_LQ_NAME(k, r) MAPF_LQ_CAT3(launch_rollout_lq_k, k, r)
@@ -528,6 +544,23 @@ hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, bool compact, const Ro
     constexpr int K = MAPF_LQ_K;
     constexpr bool R = MAPF_LQ_RECORD != 0;
     const bool stream_actions = args.actions != nullptr;
+#if MAPF_LQ_K == 8
+    // eight agents per lane: 8, 16 and 32 agents (Q = 1, 2, 4); 8-byte table rows for the 32-agent maps only
+    if (compact) {
+        if (Q != 4) return hipErrorInvalidValue;
+        return stream_actions ? launch_impl<4, K, R, true, true>(args, A, block, lds_bytes, stream)
+                              : launch_impl<4, K, R, false, true>(args, A, block, lds_bytes, stream);
+    }
+    switch (Q) {
+#define X(QQ)                                                                                                        \
+    case QQ: return stream_actions ? launch_impl<QQ, K, R, true>(args, A, block, lds_bytes, stream)                        \
+                                   : launch_impl<QQ, K, R, false>(args, A, block, lds_bytes, stream);
+        X(1) X(2) X(4)
+#undef X
+        default: return hipErrorInvalidValue;
+    }
+}
+#else
 #if MAPF_LQ_K == 4
     if (compact) {   // instantiated for the group sizes whose maps need it: 16, 32 and 64 agents
         switch (Q) {
@@ -554,8 +587,11 @@ hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, bool compact, const Ro
         default: return hipErrorInvalidValue;
     }
 }
+#endif
 
 #if MAPF_LQ_K == 4 && MAPF_LQ_RECORD == 1
+hipError_t launch_rollout_lq_k8_r1(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_rollout_lq_k8_r0(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_rollout_lq_k4_r0(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_rollout_lq_k2_r1(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
 hipError_t launch_rollout_lq_k2_r0(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
@@ -564,7 +600,7 @@ hipError_t launch_rollout_lq_k2_r0(int Q, bool compact, const RolloutArgs &args,
 static bool layout_fits(int n_agents, int K, const RolloutArgs &args, size_t lds_bytes, unsigned *block_out, int *q_out) {
     if (n_agents < K || n_agents % K != 0) return false;
     const int Q = n_agents / K;
-    if (Q > 16 || (Q & (Q - 1)) != 0 || (K == 2 && Q < 2)) return false;
+    if (Q > 16 || (Q & (Q - 1)) != 0 || (K == 2 && Q < 2) || (K == 8 && Q > 4)) return false;
     const size_t copies = kLdsBytes / lds_bytes;   // blocks per CU by LDS
     unsigned block = copies >= 4 ? 256u : 512u;
     // a small batch is spread over the CUs in smaller blocks (down to one wave): every block stages its own table copy,
@@ -592,29 +628,41 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
     if (lds_bytes <= tune.mv_lds_max_bytes) {
         // Four agents per lane halve the waves: that form needs tune.quad_min_lanes lanes (default: enough to put one
         // wave on every SIMD); below that the two-agents-per-lane form of the same kernel runs.
-        if (tune.force_k != 2 && layout_fits(n_agents, 4, args, lds_bytes, &block, &Q) &&
-            (tune.force_k == 4 || args.n_envs * uint64_t(Q) >= tune.quad_min_lanes)) K = 4;
-        else if (tune.force_k != 4 && layout_fits(n_agents, 2, args, lds_bytes, &block, &Q)) K = 2;
+        // Eight agents per lane halve them again (at 8 agents nothing crosses lanes any more): worth it from two waves
+        // per SIMD of THAT form on, i.e. 131072 envs at 8 agents.
+        if ((tune.force_k == 0 || tune.force_k == 8) && layout_fits(n_agents, 8, args, lds_bytes, &block, &Q) &&
+            (tune.force_k == 8 || args.n_envs * uint64_t(Q) >= tune.oct_min_lanes) && block <= 512u) K = 8;
+        else if (tune.force_k != 2 && tune.force_k != 8 && layout_fits(n_agents, 4, args, lds_bytes, &block, &Q) &&
+                 (tune.force_k == 4 || args.n_envs * uint64_t(Q) >= tune.quad_min_lanes)) K = 4;
+        else if (tune.force_k != 4 && tune.force_k != 8 && layout_fits(n_agents, 2, args, lds_bytes, &block, &Q)) K = 2;
         else return false;
     } else {
         // the full table is too large: 8-byte rows, one block per CU (512 threads = two waves per SIMD; 1024 when the
         // batch gives every CU a block of that size), four agents per lane, group sizes 4 / 8 / 16 only
         lds_bytes = kMoveAt + size_t(args.c.n_cells) * kCompactCols * kCompactEntry;
         if (tune.mv_lds_max_bytes == 0 || lds_bytes > kLdsBytes - kLdsReserve) return false;
-        if (!layout_fits(n_agents, 4, args, lds_bytes, &block, &Q) || Q < 4) return false;
         int n_cu = 256, dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
-        block = 512u;
-        if (args.n_envs % (1024u / unsigned(Q)) == 0 && args.n_envs * uint64_t(Q) >= uint64_t(n_cu) * 1024u) block = 1024u;
-        if (args.n_envs % (block / unsigned(Q)) != 0) return false;
-        K = 4;
+        // 32 agents: eight per lane (Q = 4, one 512-thread block per CU) once the batch gives every CU two such blocks' worth
+        if ((tune.force_k == 0 || tune.force_k == 8) && n_agents == 32 && layout_fits(n_agents, 8, args, lds_bytes, &block, &Q) &&
+            args.n_envs % (512u / 4u) == 0 && (tune.force_k == 8 || args.n_envs * 4u >= tune.oct_min_lanes)) {
+            block = 512u;
+            K = 8;
+        } else {
+            if (tune.force_k == 8 || !layout_fits(n_agents, 4, args, lds_bytes, &block, &Q) || Q < 4) return false;
+            block = 512u;
+            if (args.n_envs % (1024u / unsigned(Q)) == 0 && args.n_envs * uint64_t(Q) >= uint64_t(n_cu) * 1024u) block = 1024u;
+            if (args.n_envs % (block / unsigned(Q)) != 0) return false;
+            K = 4;
+        }
         compact = true;
     }
     if (record && !(args.rec_reward && args.rec_prob && args.rec_done && args.rec_collision)) {
         *err = hipErrorInvalidValue;
         return true;
     }
-    if (K == 4) *err = record ? launch_rollout_lq_k4_r1(Q, compact, args, A, block, lds_bytes, stream) : launch_rollout_lq_k4_r0(Q, compact, args, A, block, lds_bytes, stream);
+    if (K == 8) *err = record ? launch_rollout_lq_k8_r1(Q, compact, args, A, block, lds_bytes, stream) : launch_rollout_lq_k8_r0(Q, compact, args, A, block, lds_bytes, stream);
+    else if (K == 4) *err = record ? launch_rollout_lq_k4_r1(Q, compact, args, A, block, lds_bytes, stream) : launch_rollout_lq_k4_r0(Q, compact, args, A, block, lds_bytes, stream);
     else *err = record ? launch_rollout_lq_k2_r1(Q, compact, args, A, block, lds_bytes, stream) : launch_rollout_lq_k2_r0(Q, compact, args, A, block, lds_bytes, stream);
     return true;
 }

@@ -112,7 +112,7 @@ def test_every_dispatchable_kernel_is_free_of_register_spills(tmp_path):
              '-S', '--cuda-device-only']
     for unit in ('mapf_lg_kernels', 'mapf_lg_rollout', 'mapf_lq_step', 'mapf_transitions'):
         jobs.append((unit, [], tmp_path / (unit + '.s')))
-    for k in (4, 2):                                              # packed-layout rollout: one object per (K, RECORD)
+    for k in (8, 4, 2):                                           # packed-layout rollout: one object per (K, RECORD)
         for r in (1, 0):
             jobs.append(('mapf_lq_rollout', ['-DMAPF_LQ_K=%d' % k, '-DMAPF_LQ_RECORD=%d' % r], tmp_path / ('mapf_lq_k%d_r%d.s' % (k, r))))
     for g in range(4):

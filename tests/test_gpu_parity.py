@@ -308,6 +308,22 @@ def test_recorded_rollout_of_full_groups_against_c_oracle(n_agents, n_envs):
         env.close()
 
 
+@pytest.mark.parametrize('n_agents,n_envs', [(8, 8192), (16, 4096), (32, 2048)])
+def test_recorded_rollout_with_eight_agents_per_lane(n_agents, n_envs, monkeypatch):
+    """The same passes with the packed layout pinned to eight agents per lane (its default range starts at two waves
+    per SIMD, i.e. 131072 envs of 8 agents), and a split rollout starting at a step index that is not a multiple of 4."""
+    monkeypatch.setenv('MAPF_LQ_K', '8')
+    test_recorded_rollout_of_full_groups_against_c_oracle(n_agents, n_envs)
+    if n_agents <= 16:
+        test_dense_rollout_split_launches_accumulate_and_single_steps(n_agents, n_envs)
+    grid = MapfGrid(['....', '....', '....', '....', '....', '....', '....', '....'])
+    env = VecMapfEnv(grid, n_agents, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=1, n_envs=n_envs,
+                     start_local=np.arange(n_agents, dtype=np.uint16), goal_local=np.arange(n_agents, dtype=np.uint16)[::-1].copy())
+    env.rollout(5, auto_reset=True)
+    assert 'K=8' in env.last_kernel('rollout'), env.last_kernel('rollout')
+    env.close()
+
+
 @pytest.mark.parametrize('n_agents,n_envs', [(4, 16384), (8, 8192), (8, 16448), (16, 4096)])
 def test_dense_rollout_split_launches_accumulate_and_single_steps(n_agents, n_envs):
     """Quad-lane and pair layouts: a rollout split into launches of 1, 4 and 7 steps that accumulate into the same
@@ -396,6 +412,10 @@ def _goal_scenario_tables(n_agents, n_envs, seed):
     (16, 4096, 'lq_rollout_kernel<Q=4,K=4', {'MAPF_LQ_K': '4'}), (16, 4128, 'lq_rollout_kernel<Q=8,K=2', {'MAPF_LQ_K': '2'}),
     (32, 2048, 'lq_rollout_kernel<Q=8,K=4', {'MAPF_LQ_K': '4'}), (32, 1024, 'lq_rollout_kernel<Q=16,K=2', {'MAPF_LQ_K': '2'}),
     (32, 1024, 'lg_rollout_kernel<L=16,FULL,MV_GLOBAL', {'MAPF_MV_LDS_MAX_BYTES': '0'}),
+    # eight agents per lane (the default only for batches of two waves per SIMD and more)
+    (8, 8192, 'lq_rollout_kernel<Q=1,K=8', {'MAPF_LQ_K': '8'}), (16, 4096, 'lq_rollout_kernel<Q=2,K=8', {'MAPF_LQ_K': '8'}),
+    (32, 2048, 'lq_rollout_kernel<Q=4,K=8', {'MAPF_LQ_K': '8'}),
+    (32, 2048, 'lq_rollout_kernel<Q=4,K=8,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_LQ_K': '8'}),
     # (a full table "too large" for the LDS budget: the 8-byte-row form of the packed kernel, 512- and 1024-thread blocks)
     (16, 4096, 'lq_rollout_kernel<Q=4,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
     (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
@@ -530,6 +550,20 @@ def test_config4_share_32768_envs_under_default_dispatch(monkeypatch):
     grid, _, nbr, start, goal = bench.workload_tables(bench.CONFIGS['c4'], count, offset)
     assert _full_size_check(grid, nbr, 8, start, goal, 0.2, OptimizationCriteria.Makespan, mo.MAKESPAN, 6, 40,
                             env_id_offset=offset) > 0
+
+
+def test_double_bench_batch_runs_eight_agents_per_lane_by_default(monkeypatch):
+    """131072 room-32-32-4 envs of 8 agents -- twice the bench batch, half of BASELINE configs[3] on one GPU: from two
+    waves per SIMD on, the library's default choice is the eight-agents-per-lane form of the packed rollout."""
+    import bench
+    monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    grid, _, nbr, start, goal = bench.workload_tables(bench.CONFIGS['c4'], 131072, 0)
+    assert _full_size_check(grid, nbr, 8, start, goal, 0.2, OptimizationCriteria.Makespan, mo.MAKESPAN, 2, 24) > 0
+    env = VecMapfEnv(grid, 8, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=42, start_local=start,
+                     goal_local=goal)
+    env.rollout(4, auto_reset=True, record=True)
+    assert 'lq_rollout_kernel<Q=1,K=8,RECORD' in env.last_kernel('rollout'), env.last_kernel('rollout')
+    env.close()
 
 
 def test_config5_bench_tables_16384_envs_under_default_dispatch(monkeypatch):
