@@ -323,7 +323,7 @@ constexpr uint32_t kTerminalStatus = 0x10001u;   // a step from a terminal state
 // function of f): rows 0..7 = f, rows 8..15 = "the state was terminal" (mapf_env.py:239-240: reward 0, done).
 struct OutcomeRow {
     double reward;
-    uint32_t status, pad;
+    uint32_t status, pad;   // pad: done | collision << 16 (the packed rollout sums it and stores its bytes)
 };
 static_assert(sizeof(OutcomeRow) == 16, "read as one 16-byte LDS word");
 __device__ __forceinline__ void stage_outcome_table(const EnvConsts &c, OutcomeRow *lds) {   // before a __syncthreads()
@@ -333,7 +333,7 @@ __device__ __forceinline__ void stage_outcome_table(const EnvConsts &c, OutcomeR
         const double r = (st & 0x100u) ? __dadd_rn(c.r_clash, c.r_living) : ((st & 1u) ? __dadd_rn(c.r_goal, c.r_living) : c.r_living);
         lds[i].reward = i < 8u ? r : 0.0;
         lds[i].status = i < 8u ? st : kTerminalStatus;
-        lds[i].pad = 0u;
+        lds[i].pad = (lds[i].status & 1u) | ((lds[i].status & 0x100u) << 8);   // done | collision << 16: summed as two 16-bit counts
     }
 }
 

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     // per-lane pointers into the step rows; they advance by wave-uniform strides
     const uint64_t step_rows = n_envs, step_cells = uint64_t(n_envs) * n_agents;
     const bool odd = (x.g & 1u) != 0u;
-    const uint32_t flag_shift = (x.g & 1u) * 8u;
+    const uint32_t flag_shift = (x.g & 1u) * 16u;
     gf64 wide_lane = nullptr, prob_lane = nullptr;
     gu8 narrow_lane = nullptr, coll_lane = nullptr;
     gu16 rec_lane = nullptr;
@@ -190,7 +190,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     double pq[K], p_reward = -0.0;
 #pragma unroll
     for (int i = 0; i < K; ++i) pq[i] = 0.0;
-    uint32_t p_cells[P], p_status = 0u;
+    uint32_t p_cells[P], p_status = 0u, counts = 0u;   // p_status: done | collision << 16 of the pending step; counts: their sums
 #pragma unroll
     for (int i = 0; i < P; ++i) p_cells[i] = 0u;
 
@@ -208,8 +208,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
             for (int i = 0; i < K; ++i) asm volatile("" : "+v"(pq[i]));
         }
         ret = __dadd_rn(ret, p_reward);
-        episodes += p_status & 0xFFu;                          // byte 0 done, byte 1 collision
-        collisions += (p_status >> 8) & 0xFFu;
+        counts += p_status;                                    // two 16-bit counts (a launch has at most 65535 steps)
         if (RECORD) {
             const double prob = packed_prob_product<Q, K>(pq);   // total in the last lane
             Packed<P> out;
@@ -220,7 +219,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
             *narrow_lane = uint8_t(Q > 1 ? p_status >> flag_shift : p_status);
             if (Q == 1) {
                 *prob_lane = prob;
-                *coll_lane = uint8_t(p_status >> 8);
+                *coll_lane = uint8_t(p_status >> 16);
             }
         }
     };
@@ -402,7 +401,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         // next step's table address depends on is derived from `code` without waiting for it
         static_assert(sizeof(OutcomeRow) == 16, "code16 addresses the outcome rows");
         const u32x4 row = lds_at<u32x4>(kOutcomeAt + code16);   // {reward lo, hi, status, pad}
-        const uint32_t row_status = row.z;
+        const uint32_t row_status = row.w;                     // done | collision << 16
         double reward = __hiloint2double(int(row.y), int(row.x));
         const bool was_terminal = MAYBE_TERMINAL && code16 > 7u * 16u;
         if (SOC) {
@@ -505,8 +504,8 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     }
     if (leader) {
         if (ret_p) *ret_p = ret;
-        if (epi_p) *epi_p = episodes;
-        if (col_p) *col_p = collisions;
+        if (epi_p) *epi_p = episodes + (counts & 0xFFFFu);
+        if (col_p) *col_p = collisions + (counts >> 16);
     }
 }
 
@@ -618,7 +617,7 @@ static bool layout_fits(int n_agents, int K, const RolloutArgs &args, size_t lds
 bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err) {
     // top_tie: a three-entry list whose last cumulative sum rounds below 1.0 needs a third compare per agent (hi = 65535);
     // the packed sampling does two, so such a table (none arises from fail_prob / 2 splits) stays with the lane-group kernel
-    if (!tune.quad_lanes || args.c.top_tie) return false;
+    if (!tune.quad_lanes || args.c.top_tie || args.n_steps > 65535u) return false;   // (per-launch counts are 16-bit)
     const bool record = args.rec_local != nullptr;
     const uint32_t A = uint32_t(n_agents);
     unsigned block = 0;
