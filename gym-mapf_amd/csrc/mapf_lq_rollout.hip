@@ -339,34 +339,36 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         }
         STAMP(2);   // slip Philox (1 step in 4)
         double q[K];
-        uint32_t n[P], word[P], tie_all = 0u;
+        uint32_t n[P], word[P], d[K], tie_all = 0u;
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             word[i] = W == 0 ? rng[i].w0 : W == 1 ? rng[i].w1 : W == 2 ? rng[i].w2 : W == 3 ? rng[i].w3 : step_word(rng[i], t);
             const uint32_t biased = word[i] ^ kHalfBias;             // low half: agent 2i's uniform, high half: agent 2i+1's
             uint32_t q_at[2], cell[2];
-            const uint32_t d_even = sample_slot_packed(entry[2 * i], __builtin_amdgcn_perm(biased, biased, 0x01000100u), pk_eights, pk_steps,
-                                                       sel_base, q_at[0], cell[0]);
-            const uint32_t d_odd = sample_slot_packed(entry[2 * i + 1], __builtin_amdgcn_perm(biased, biased, 0x03020302u), pk_eights, pk_steps,
-                                                      sel_base, q_at[1], cell[1]);
+            d[2 * i] = sample_slot_packed(entry[2 * i], __builtin_amdgcn_perm(biased, biased, 0x01000100u), pk_eights, pk_steps,
+                                          sel_base, q_at[0], cell[0]);
+            d[2 * i + 1] = sample_slot_packed(entry[2 * i + 1], __builtin_amdgcn_perm(biased, biased, 0x03020302u), pk_eights, pk_steps,
+                                              sel_base, q_at[1], cell[1]);
             q[2 * i] = lds_at<double>(kSlipAt + 16u + q_at[0]);
             q[2 * i + 1] = lds_at<double>(kSlipAt + 16u + q_at[1]);
             n[i] = cell[0] | (cell[1] << 16);
-            tie_all = i == 0 ? pk_min_u16(d_even, d_odd) : pk_min_u16(tie_all, pk_min_u16(d_even, d_odd));
+            tie_all = i == 0 ? pk_min_u16(d[0], d[1]) : pk_min_u16(tie_all, pk_min_u16(d[2 * i], d[2 * i + 1]));
         }
         // (without slip the words stay zero and every threshold is 65535: no tie can fire, so need_rng is not asked here)
         if (__builtin_expect(__any(zero_half(tie_all) != 0u), 0)) {
-            // a top-16-bit tie somewhere in the wave: redo with all 53 bits
-            uint32_t nx[K];
+            // a top-16-bit tie somewhere in the wave: the agents that tie (in any lane: the test is wave-uniform) are redone
+            // with all 53 bits -- for the lanes that did not tie the exact path repeats what the fast path found
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                MoveEntry full = entry[k];
-                if (COMPACT) full.y = (full.y & 0xFFFFu) | ((full.w / uint32_t(sizeof(SlipRow))) << 16);   // the code, where entry_code() looks
-                const uint32_t hi = (k & 1) ? word[k / 2] >> 16 : word[k / 2] & 0xFFFFu;
-                slip_move<false>(slip, full, refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi), 0.0, nx[k], q[k]);
+                if (__any(zero_half(d[k]) != 0u)) {
+                    MoveEntry full = entry[k];
+                    if (COMPACT) full.y = (full.y & 0xFFFFu) | ((full.w / uint32_t(sizeof(SlipRow))) << 16);   // the code, where entry_code() looks
+                    const uint32_t hi = (k & 1) ? word[k / 2] >> 16 : word[k / 2] & 0xFFFFu;
+                    uint32_t nx;
+                    slip_move<false>(slip, full, refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi), 0.0, nx, q[k]);
+                    n[k / 2] = (k & 1) ? (n[k / 2] & 0xFFFFu) | (nx << 16) : (n[k / 2] & 0xFFFF0000u) | nx;
+                }
             }
-#pragma unroll
-            for (int i = 0; i < P; ++i) n[i] = nx[2 * i] | (nx[2 * i + 1] << 16);
         }
         STAMP(3);   // sampling (table wait, thresholds, probability read issue)
 
