@@ -3,7 +3,7 @@
 streamed action ring, totals and final state against the C oracle after every launch, the full recorded trajectory
 of the last launch step by step.  Not part of the test suite (about a minute of single-core oracle time per 1000 steps).
 
-    python tools/soak_parity.py [steps=2048] [T=256]
+    python tools/soak_parity.py [steps=2048] [T=256] [config=c3] [envs=the config's per-GPU batch]
 """
 import os
 import sys
@@ -20,13 +20,14 @@ from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv  # noqa: 
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-E, A = 65536, bench.CONFIGS['c3']['agents']
-grid, _, nbr, start, goal = bench.workload_tables(bench.CONFIGS['c3'], E, 0)
+CFG = bench.CONFIGS[sys.argv[3] if len(sys.argv) > 3 else 'c3']
+E, A = int(sys.argv[4]) if len(sys.argv) > 4 else CFG['envs'], CFG['agents']
+grid, _, nbr, start, goal = bench.workload_tables(CFG, E, 0)
 bits = lambda x: np.ascontiguousarray(x).view(np.uint64)  # noqa: E731
 for crit, ocrit in ((OptimizationCriteria.Makespan, mo.MAKESPAN), (OptimizationCriteria.SoC, mo.SOC)):
-    env = VecMapfEnv(grid, A, None, None, bench.CONFIGS['c3']['fail_prob'], bench.R_CLASH, bench.R_GOAL, bench.R_LIVING, crit, seed=bench.SEED,
+    env = VecMapfEnv(grid, A, None, None, CFG['fail_prob'], bench.R_CLASH, bench.R_GOAL, bench.R_LIVING, crit, seed=bench.SEED,
                      start_local=start, goal_local=goal)
-    co = c_oracle.COracle(nbr, A, start, goal, bench.CONFIGS['c3']['fail_prob'], bench.R_CLASH, bench.R_GOAL, bench.R_LIVING, ocrit, seed=bench.SEED)
+    co = c_oracle.COracle(nbr, A, start, goal, CFG['fail_prob'], bench.R_CLASH, bench.R_GOAL, bench.R_LIVING, ocrit, seed=bench.SEED)
     acc, t0, done = None, time.time(), 0
     while done < steps:
         n = min(T, steps - done)
@@ -46,5 +47,6 @@ for crit, ocrit in ((OptimizationCriteria.Makespan, mo.MAKESPAN), (OptimizationC
         assert np.array_equal(env.get_state()[0], co.state), done
         done += n
         print('%s: %d steps ok (%.0f s)' % (crit.name, done, time.time() - t0), flush=True)
+    print('    kernel: %s' % env.last_kernel('rollout'), flush=True)
     env.close()
 print('soak parity ok: %d steps x %d envs x %d agents, both criteria' % (steps, E, A))
