@@ -140,6 +140,21 @@ def integer_action_to_vector(a, n_agents):
     return integer_to_vector(a, [len(ACTIONS)] * n_agents, n_agents, lambda n: ACTIONS[n])
 
 
+def empty_indices():
+    """Fresh per-cell bookkeeping record (reference :36-37; kept for code that imports it)."""
+    return {'prev': [], 'next': []}
+
+
+def function_to_get_item_of_object(func):
+    """An object whose ``obj[item]`` is ``func(item)`` (reference :105-112; ``env.P`` is built this way there)."""
+
+    class _Indexable:
+        def __getitem__(self, item):
+            return func(item)
+
+    return _Indexable()
+
+
 class _TransitionsOfState:
     """``env.P[s]``: indexing with a joint action gives the reference's transition list."""
 
@@ -417,6 +432,22 @@ class MapfEnv(_EnvBase):
                     token = ACTION_TO_CHAR[integer_action_to_vector(joint, self.n_agents)[agent]]
                 print(token, end=' ')
         print('')
+
+    def _single_location_predecessors(self, loc):
+        """Free cells from which the one-agent location ``loc`` (a 1-tuple ``((row, col),)``, as the reference passes
+        it) is entered by one noise-free action, in the reference's order: via UP, DOWN, RIGHT, LEFT, STAY
+        (reference :414-425; duplicates are kept, as there)."""
+        back = ((DOWN,), (UP,), (LEFT,), (RIGHT,), (STAY,))       # the move that undoes each arriving action
+        cells = [execute_action(self.grid, loc, undo) for undo in back]
+        return [c for c in cells if self.grid[c[0]] is EmptyCell]
+
+    def _multiple_locations_predecessors(self, locs):
+        """Every combination of the agents' single-location predecessors, first agent varying fastest
+        (reference :427-434)."""
+        head = self._single_location_predecessors((locs[0],))
+        if len(locs) == 1:
+            return head
+        return [first + rest for rest in self._multiple_locations_predecessors(locs[1:]) for first in head]
 
     def predecessors(self, s: int):
         """States from which ``s`` can be entered in one noise-free joint move: per agent the cells reached from its

@@ -60,6 +60,17 @@ def test_predecessors_match_reference():                    # mapf_env.py:373-37
     expected = {env.locations_to_state((a, b)) for a in ((0, 2), (1, 1), (1, 3), (2, 2), (1, 2))
                 for b in ((2, 2), (2, 0), (1, 1), (2, 1))}
     assert env.predecessors(env.s) == expected and len(expected) == 20
+    # the list-valued helpers the reference builds predecessors() from (:414-434): same states, its enumeration order
+    combos = env._multiple_locations_predecessors(env.state_to_locations(env.s))
+    assert {env.locations_to_state(c) for c in combos} == expected and len(combos) == 25       # (stay + bounce: duplicates kept)
+    assert env._single_location_predecessors(((1, 2),)) == [((2, 2),), ((0, 2),), ((1, 1),), ((1, 3),), ((1, 2),)]   # one-agent states, as there
+    assert combos[0] == ((2, 2), (2, 1)) and combos[1] == ((0, 2), (2, 1))                      # first agent fastest
+    for case in G['predecessors']:
+        env = MapfEnv(MapfGrid(case['lines']), len(case['starts']), tuple(map(tuple, case['starts'])),
+                      tuple(map(tuple, case['goals'])), 0, -1000.0, 100.0, -1, MK)
+        for q in case['queries']:
+            locs = env.state_to_locations(int(q['s']))
+            assert {env.locations_to_state(c) for c in env._multiple_locations_predecessors(locs)} == env.predecessors(int(q['s']))
 
 
 def test_render_with_policy_matches_reference_text():       # mapf_env.py:324-356 (render itself: GPU test file)
