@@ -23,10 +23,19 @@ launch = T = 256 fused MapfEnv.step() calls of every env (`config.env_steps_per_
 its outputs (next cells, reward, done, collision, prob) to HBM.  K steps = K launches back to back on the env's
 HIP stream between barrier + synchronize on both sides; `value` = all ranks' agent-steps / max-over-ranks wall
 time of that region.  Rank 0 prints ONE JSON line.  Keys beyond the contract:
+  value / ms_per_step   MEDIAN over --repeats timed blocks of exactly K steps each (every block bracketed by barrier +
+                synchronize on both sides, max over ranks); `repeats` lists every block.  `value_cold` = the first 25
+                launches after >= 1 s of idle device, timed the same way before any warm-up (clocks not yet ramped)
   roofline      dominant kernel (the fused rollout; `kernel` = what the library reports it dispatched): algorithmic
                 bytes / HIP-event time per launch; `traffic` = HBM bytes per launch from the committed PMC passes
-                (profiles/traffic.json: per-step + fixed part), `traffic_frac` = that / the same time / peak
-  single_step_launches   the same env-steps as one mapf_step launch each (launch-latency bound at this size)
+                (profiles/traffic.json: per-step + fixed part), `traffic_frac` = that / the same time / peak;
+                `valu_frac` = VALU wave-instructions per launch (committed SQ pass, profiles/valu.json) x 4 cycles /
+                (SIMDs x live launch time x the shader clock that pass measured): the share of the chip's vector-issue
+                slots the kernel fills -- the resource that binds it, printed beside the HBM figure
+  single_step_launches   the same env-steps as one mapf_step launch each, recorded ONCE into a hipGraph (64 nodes; the
+                step index lives in device memory, so every replay draws fresh numbers) and replayed; the next
+                observation is read from the handle's state view (cells written once); `plain_launches` = the same
+                calls issued one by one from the host (host-enqueue bound)
   scalar_env    the reference's own regime (configs[0]: empty-8-8, 2 agents, slip 0, ONE env): MapfEnv.step()
                 calls per second through the drop-in class, beside the reference's build-container figure
   cpu_baseline  the pure-Python restatement of the reference (oracle/, kind "port") timed on this box's host
@@ -222,9 +231,25 @@ def scalar_env_rate(budget_s=2.0):
     return out
 
 
-def spawn_ranks(n):
+def measured_valu(kernel, n_envs, n_agents):
+    """(VALU wave-instructions per env-step launch-step, shader clock in Hz, SIMDs) of `kernel` at this batch from the
+    committed SQ counter pass (profiles/valu.json, written by tools/sq_summary.py --json), or None."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'valu.json')) as f:
+            entries = json.load(f)['kernels']
+    except (OSError, KeyError, ValueError):
+        return None
+    for entry in entries:
+        if entry.get('kernel') == kernel and entry.get('n_envs') == n_envs and entry.get('n_agents') == n_agents:
+            return entry['valu_insts_per_env_step'], entry['shader_clock_hz'], entry['simds']
+    return None
+
+
+def spawn_ranks(n, deadline_s):
     """`python bench.py --gpus N` with no launcher: start one child per GPU (before this process makes any GPU
-    call -- it makes none at all), wait for them, and exit with the first failure's code.  Rank 0 prints the line."""
+    call -- it makes none at all), wait for them, and exit with the first failure's code.  Rank 0 prints the line.
+    A rank that has not finished `deadline_s` seconds after the start (stuck in a collective, a hung device) takes
+    every rank down with it: exit code 124."""
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
@@ -236,6 +261,7 @@ def spawn_ranks(n):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     pending = list(procs)
+    t_end = time.monotonic() + deadline_s
     while pending:
         for p in list(pending):
             code = p.poll()
@@ -246,6 +272,17 @@ def spawn_ranks(n):
                 rc = code
                 for q in pending:      # a dead rank would leave the others waiting in a collective
                     q.terminate()
+        if pending and time.monotonic() > t_end:
+            sys.stderr.write('bench.py: %d rank(s) still running after %.0f s -- terminating all ranks\n' % (len(pending), deadline_s))
+            for q in pending:
+                q.terminate()
+            t_kill = time.monotonic() + 10.0
+            while any(q.poll() is None for q in pending) and time.monotonic() < t_kill:
+                time.sleep(0.1)
+            for q in pending:
+                if q.poll() is None:
+                    q.kill()
+            raise SystemExit(124)
         time.sleep(0.05)
     raise SystemExit(rc)
 
@@ -267,10 +304,13 @@ def main():
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' + --share-device rehearses the N > 1 path on a one-GPU box")
     ap.add_argument('--share-device', action='store_true', help='every rank uses cuda:0 (rehearsal only)')
+    ap.add_argument('--repeats', type=int, default=5, help='timed blocks of --steps steps each; value = their median')
+    ap.add_argument('--rank-timeout', type=float, default=900.0,
+                    help='self-launched ranks (--gpus N without a launcher) are all terminated after this many seconds')
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        spawn_ranks(args.gpus)
+        spawn_ranks(args.gpus, args.rank_timeout)
 
     # stdout carries ONE JSON line: whatever libraries print while they initialise (gloo's rank banner, ...) goes to stderr
     sys.stdout.flush()
@@ -373,35 +413,56 @@ def main():
     from gym_mapf_amd import _native as nat
     bpas = bytes_per_agent_step(A)
 
-    def timed(enqueue, n_warm, n_timed):
-        """barrier + sync, n_timed enqueues bracketed by HIP events on the env's stream, barrier + sync;
-        returns (max-over-ranks wall seconds, HIP-event milliseconds of this rank).  Before the warm-up steps the same
-        launches run untimed for --preroll-ms: after an idle period the device needs ~25 ms of work to reach the clocks
-        it sustains (profiles/r02_launch_series.txt: the first 25 launches run 15 % slower than the 100th)."""
-        t_end = time.perf_counter() + args.preroll_ms * 1e-3
-        k = 0
-        while time.perf_counter() < t_end:
-            for _ in range(8):
-                enqueue(k)
-                k += 1
-            env.sync()
-        for k in range(n_warm):
-            enqueue(k)
+    def block(enqueue, first, n):
+        """One timed block: barrier + sync, n enqueues bracketed by HIP events on the env's stream, sync + barrier;
+        returns (max-over-ranks wall seconds, HIP-event milliseconds of this rank)."""
         barrier()
         env.timer_begin()
         t0 = time.perf_counter()
-        for k in range(n_timed):
-            enqueue(n_warm + k)
+        for k in range(n):
+            enqueue(first + k)
         gpu_ms = env.timer_end()
         torch.cuda.synchronize()
         env.sync()
-        wall = time.perf_counter() - t0                   # this rank's K steps, device idle again; MAX over ranks below
+        wall = time.perf_counter() - t0                   # this rank's n steps, device idle again; MAX over ranks below
         barrier()
         if dist is not None:
             tmax = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             wall = float(tmax.item())
         return wall, gpu_ms
+
+    def timed(enqueue, n_warm, n_timed, repeats, cold=0):
+        """`repeats` timed blocks of exactly n_timed enqueues each (see block()); returns (list of (wall s, gpu ms), the
+        cold block or None).  cold > 0: before anything else the device idles for a second and the first `cold`
+        enqueues are timed as a block of their own -- what a caller sees who does not keep the device busy.  Then the
+        same launches run untimed for --preroll-ms (after an idle period the device needs ~25 ms of work to reach the
+        clocks it sustains, profiles/r02_launch_series.txt), then the n_warm warm-up steps, then the blocks."""
+        cold_block = None
+        k = 0
+        if cold:
+            env.sync()
+            time.sleep(1.0)
+            cold_block = block(enqueue, 0, cold)
+            k = cold
+        t_end = time.perf_counter() + args.preroll_ms * 1e-3
+        while time.perf_counter() < t_end:
+            for _ in range(8):
+                enqueue(k)
+                k += 1
+            env.sync()
+        for _ in range(n_warm):
+            enqueue(k)
+            k += 1
+        blocks = []
+        for _ in range(max(1, repeats)):
+            blocks.append(block(enqueue, k, n_timed))
+            k += n_timed
+        return blocks, cold_block
+
+    def median_block(blocks):
+        order = sorted(range(len(blocks)), key=lambda i: blocks[i][0])
+        return blocks[order[(len(blocks) - 1) // 2]]        # a measured block (lower median), not an average of two
 
     # ---- headline leg: K passes, each ONE fused mapf_rollout launch of T env-steps.  Every env-step's outputs
     # (next cells, reward, done, collision, prob) are written to HBM, actions are streamed from the ring.
@@ -426,46 +487,64 @@ def main():
         nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(ios[k % n_slots])))
 
     env.reset()
-    wall, gpu_ms = timed(enqueue_rollout, W, K)
+    n_cold = 25
+    ro_blocks, ro_cold = timed(enqueue_rollout, W, K, args.repeats, cold=n_cold)
+    wall, gpu_ms = median_block(ro_blocks)
     rollout_kernel = env.last_kernel('rollout')
     agent_steps = float(K) * T * total_envs * A
     value = agent_steps / wall
     ro_launch_ms = gpu_ms / K
     ro_bytes = float(T) * E * A * bpas                              # algorithmic bytes of one launch of this rank
     ro_achieved = ro_bytes / (ro_launch_ms * 1e-3) / 1e9
+    gather_info = None
     if dist is not None:
         # the one collective of the path: gather per-env episode returns
         env.sync()
         counts = [sharding.split_evenly(cfg['envs'], r, world)[1] for r in range(world)] if scaling == 'strong' else [E] * world
-        assert len(set(counts)) == 1, 'gather_returns needs equal shards (pad the remainder before gathering)'
-        gathered = sharding.gather_returns(acc['returns'] if coll_dev == 'cuda' else acc['returns'].cpu())
+        gathered = sharding.gather_returns(acc['returns'] if coll_dev == 'cuda' else acc['returns'].cpu(), counts=counts)
         torch.cuda.synchronize()
         assert gathered.numel() == total_envs, (gathered.numel(), total_envs)
+        gather_info = {"backend": args.dist_backend, "elements": int(gathered.numel()), "shards": counts,
+                       "collective": "all_gather_into_tensor" if coll_dev == 'cuda' else "all_gather"}
 
     # ---- second leg: env-steps as single-step mapf_step launches (one kernel launch per env-step)
     single = None
     if not args.no_side_legs:
+        # recorded once, replayed: 64 mapf_step nodes; the step writes its cells once (the next observation is the
+        # handle's state view) and every other output to HBM
+        n_nodes = min(64, ring)
         out = None
-        calls = []
-        for r in range(ring):
-            call, out = env.prepare_step(actions[r], auto_reset=True, out=out)
-            calls.append(call)
         env.reset()
-        K1 = 2000
-        wall1, gpu_ms1 = timed(lambda k: calls[k % ring](), 200, K1)
+        env.graph_begin()
+        for r in range(n_nodes):
+            call, out = env.prepare_step(actions[r], auto_reset=True, out=out, write_local=False)
+            call()
+        graph = env.graph_end()
+        K1 = 32                                                      # replays per timed block = 2048 env-steps
+        g_blocks, _ = timed(lambda k: graph.launch(1), 4, K1, min(args.repeats, 3))
+        wall1, gpu_ms1 = median_block(g_blocks)
         step_kernel = env.last_kernel('step')
-        step_ms = gpu_ms1 / K1
+        n_steps1 = K1 * n_nodes
+        step_ms = gpu_ms1 / n_steps1
+        graph.close()
+        # the same calls issued one by one from the host
+        calls = [env.prepare_step(actions[r], auto_reset=True, out=out, write_local=False)[0] for r in range(ring)]
+        p_blocks, _ = timed(lambda k: calls[k % ring](), 200, 2000, 1)
         launch_bytes = E * A * bpas
         st_traffic = measured_traffic(step_kernel, E, A, 1)
-        single = {"value": float(K1) * total_envs * A / wall1, "unit": "agent-steps/s", "launches": K1,
-                  "ms_per_launch": wall1 * 1e3 / K1, "kernel": step_kernel,
+        single = {"value": float(n_steps1) * total_envs * A / wall1, "unit": "agent-steps/s", "launches": n_steps1,
+                  "ms_per_launch": wall1 * 1e3 / n_steps1, "kernel": step_kernel,
+                  "how": "%d mapf_step calls recorded into one hipGraph, %d replays per block; out_local = NULL (state view)" % (n_nodes, K1),
                   "roofline": {"bound": "hbm", "achieved": launch_bytes / (step_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
                                "unit": "GB/s", "frac": launch_bytes / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "traffic": st_traffic,
                                "traffic_frac": (st_traffic / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if st_traffic else None,
-                               "bytes_per_launch": launch_bytes, "ms_per_launch_hip_events": step_ms}}
+                               "bytes_per_launch": launch_bytes, "ms_per_launch_hip_events": step_ms},
+                  "plain_launches": {"value": 2000.0 * total_envs * A / p_blocks[0][0], "unit": "agent-steps/s",
+                                     "ms_per_launch": p_blocks[0][0] * 1e3 / 2000, "ms_per_launch_hip_events": p_blocks[0][1] / 2000}}
 
     ro_traffic = measured_traffic(rollout_kernel, E, A, T)          # PMC bytes per launch (profiles/)
+    ro_valu = measured_valu(rollout_kernel, E, A)                   # SQ pass: VALU wave-instructions per env-step
     if rank == 0:
         line = {
             "metric": "agent-steps/sec (batched MapfEnv.step)", "value": value, "unit": "agent-steps/s",
@@ -483,10 +562,16 @@ def main():
                        "preroll_ms": args.preroll_ms,
                        "parallelism": "env-sharded x%d" % world},
             "value_hip_events": float(T) * total_envs * A / (ro_launch_ms * 1e-3),
+            "value_cold": (float(n_cold) * T * total_envs * A / ro_cold[0]) if ro_cold else None,
+            "repeats": {"n": len(ro_blocks), "steps_per_block": K, "value_of": "median block",
+                        "values": [agent_steps / b[0] for b in ro_blocks],
+                        "ms_per_step": [b[0] * 1e3 / K for b in ro_blocks]},
             "roofline": {"bound": "hbm", "achieved": ro_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ro_achieved / HBM_PEAK_GBS,
                          "traffic": ro_traffic,
                          "traffic_frac": (ro_traffic / (ro_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ro_traffic else None,
+                         "valu_frac": (ro_valu[0] * T * 4.0 / (ro_valu[2] * ro_launch_ms * 1e-3 * ro_valu[1])) if ro_valu else None,
+                         "valu_insts_per_launch": (ro_valu[0] * T) if ro_valu else None,
                          "kernel": rollout_kernel, "bytes_per_launch": ro_bytes,
                          "ms_per_launch_hip_events": ro_launch_ms,
                          "note": "achieved = algorithmic bytes (5 + 18/A per agent-step, SURVEY.md 8(d)) per launch / HIP-event "
@@ -494,6 +579,8 @@ def main():
                                  "in registers, so it moves fewer bytes than the per-step contract credits)"},
             "parity": parity,
         }
+        if gather_info is not None:
+            line["gather"] = gather_info
         if single is not None:
             line["single_step_launches"] = single
         if world == 1 and not args.no_side_legs and not args.no_scalar_env:

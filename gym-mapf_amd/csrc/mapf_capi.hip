@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -102,6 +103,23 @@ struct mapf_handle_s {
     DeviceBuf x_local, x_reward, x_prob, x_done, x_coll;   // stand-ins for trajectory arrays the caller left out
     DeviceBuf q_local, q_actions, q_env, q_count, q_next, q_prob, q_reward, q_done, q_coll, q_next_in;   // mapf_transitions staging
     PinnedBlock pinned;               // zero-copy staging of tiny host-mode steps
+    // scenario table (StepArgs::scen): built at create when the batch has <= 256 distinct (start row, goal row) pairs
+    uint8_t *scen = nullptr;
+    uint16_t *scen_rows = nullptr;
+    uint32_t n_scen = 0;
+    // recording into a hipGraph (mapf_graph_begin .. mapf_graph_end): recorded launches take their step index from
+    // *t_dev + their offset inside the recording; t_dev_value = what *t_dev holds once the stream has drained
+    uint64_t *t_dev = nullptr;
+    uint64_t t_dev_value = 0, cap_steps = 0;
+    bool capturing = false;
+    int live_graphs = 0;
+};
+
+struct mapf_graph_s {
+    mapf_handle_t owner = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t steps = 0;               // env-steps one replay advances the handle by
 };
 
 namespace {
@@ -110,6 +128,13 @@ int check_handle(mapf_handle_t h) {
     if (!h) return fail(MAPF_EINVAL, "null handle");
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    return MAPF_OK;
+}
+
+// entry points that wait for the stream, move the step index from the host side or free what a recorded node uses
+// cannot run between mapf_graph_begin and mapf_graph_end
+int check_not_recording(mapf_handle_t h, const char *what) {
+    if (h->capturing) return fail(MAPF_EINVAL, std::string(what) + ": not allowed while a graph is being recorded (call mapf_graph_end first)");
     return MAPF_OK;
 }
 
@@ -221,6 +246,9 @@ void destroy_impl(mapf_handle_t h) {
                          &h->q_prob, &h->q_reward, &h->q_done, &h->q_coll, &h->q_next_in})
         b->release();
     h->pinned.release();
+    if (h->scen) (void)hipFree(h->scen);
+    if (h->scen_rows) (void)hipFree(h->scen_rows);
+    if (h->t_dev) (void)hipFree(h->t_dev);
     if (h->mv) (void)hipFree(h->mv);
     if (h->policy_cells) (void)hipFree(h->policy_cells);
     if (h->slip) (void)hipFree(h->slip);
@@ -239,7 +267,7 @@ extern "C" {
 
 const char *mapf_last_error(void) { return g_last_error.c_str(); }
 
-const char *mapf_version(void) { return "mapf_hip 0.2.0 (abi 2, gfx950)"; }
+const char *mapf_version(void) { return "mapf_hip 0.3.0 (abi 3, gfx950)"; }
 
 int mapf_device_count(int *out_count) {
     if (!out_count) return fail(MAPF_EINVAL, "out_count is null");
@@ -376,6 +404,35 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
     CREATE_TRY(hipMemcpy(h->mv, packed.data(), packed.size() * sizeof(mapf::MoveEntry), hipMemcpyHostToDevice));
     if (n_start) CREATE_TRY(hipMemcpy(h->start, d->start, n_start * sizeof(uint16_t), hipMemcpyHostToDevice));
     if (n_goal) CREATE_TRY(hipMemcpy(h->goal, d->goal, n_goal * sizeof(uint16_t), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->t_dev), sizeof(uint64_t)));
+    CREATE_TRY(hipMemset(h->t_dev, 0, sizeof(uint64_t)));
+    if (!(sb && gb) && E > 0 && h->tune.scen_table) {
+        // Scenario table: the distinct (start row, goal row) pairs of the batch, when there are few (the BASELINE
+        // configurations draw every env's rows from 6 or 25 scenario files), and one byte per env naming its pair.
+        std::unordered_map<std::string, uint32_t> ids;
+        std::vector<uint8_t> scen(E);
+        std::vector<uint16_t> rows;
+        bool few = true;
+        std::string key(2 * row, '\0');
+        for (uint64_t e = 0; e < E && few; ++e) {
+            std::memcpy(&key[0], d->start + (sb ? 0 : e * A), row);
+            std::memcpy(&key[row], d->goal + (gb ? 0 : e * A), row);
+            auto it = ids.find(key);
+            if (it == ids.end()) {
+                if (ids.size() == 256) { few = false; break; }
+                it = ids.emplace(key, uint32_t(ids.size())).first;
+                rows.insert(rows.end(), reinterpret_cast<const uint16_t *>(key.data()), reinterpret_cast<const uint16_t *>(key.data()) + 2 * A);
+            }
+            scen[e] = uint8_t(it->second);
+        }
+        if (few) {
+            h->n_scen = uint32_t(ids.size());
+            CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->scen), E));
+            CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->scen_rows), rows.size() * sizeof(uint16_t)));
+            CREATE_TRY(hipMemcpy(h->scen, scen.data(), E, hipMemcpyHostToDevice));
+            CREATE_TRY(hipMemcpy(h->scen_rows, rows.data(), rows.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        }
+    }
     CREATE_TRY(mapf::launch_reset(int(A), h->state, h->start, sb, nullptr, E, h->stream));
     {   // is any env's start state terminal?  (the rollout kernels specialise on "no": state == start right now)
         std::vector<uint8_t> flags(E ? E : 1, 0);
@@ -393,12 +450,19 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
 
 int mapf_destroy(mapf_handle_t h) {
     if (!h) return fail(MAPF_EINVAL, "null handle");
+    if (h->capturing) {   // an open recording dies with the handle
+        hipGraph_t g = nullptr;
+        (void)hipStreamEndCapture(h->stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        h->capturing = false;
+    }
     destroy_impl(h);
     return MAPF_OK;
 }
 
 int mapf_sync(mapf_handle_t h) {
     if (int rc = check_handle(h)) return rc;
+    if (int rc = check_not_recording(h, "mapf_sync")) return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
     return MAPF_OK;
 }
@@ -416,6 +480,7 @@ int mapf_get_stream(mapf_handle_t h, void **out_stream) {
 
 int mapf_timer_begin(mapf_handle_t h) {
     if (int rc = check_handle(h)) return rc;
+    if (int rc = check_not_recording(h, "mapf_timer_begin")) return rc;
     HIP_TRY(hipEventRecord(h->ev_begin, h->stream));
     return MAPF_OK;
 }
@@ -423,6 +488,7 @@ int mapf_timer_begin(mapf_handle_t h) {
 int mapf_timer_end(mapf_handle_t h, double *out_ms) {
     if (int rc = check_handle(h)) return rc;
     if (!out_ms) return fail(MAPF_EINVAL, "out_ms is null");
+    if (int rc = check_not_recording(h, "mapf_timer_end")) return rc;
     HIP_TRY(hipEventRecord(h->ev_end, h->stream));
     HIP_TRY(hipEventSynchronize(h->ev_end));
     float ms = 0.f;
@@ -450,7 +516,11 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     const size_t E = size_t(h->E), EA = E * h->A;
     mapf::StepArgs a{};
     a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
-    a.n_envs = h->E; a.env_id_offset = h->env_id_offset; a.t = h->t;
+    a.n_envs = h->E; a.env_id_offset = h->env_id_offset;
+    // a recorded launch: offset inside the recording + the device-side index (see StepArgs::t_dev)
+    a.t = h->capturing ? h->cap_steps : h->t;
+    a.t_dev = h->capturing ? h->t_dev : nullptr;
+    a.scen = h->scen; a.scen_rows = h->scen_rows;
     a.start_broadcast = h->start_broadcast; a.goal_broadcast = h->goal_broadcast;
     a.auto_reset = step_flags & MAPF_STEP_AUTO_RESET;
     if (!h->device_ptrs) {
@@ -513,7 +583,7 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     if (int rc = stage_out(h, h->s_term, out_was_terminal, E, &a.out_was_terminal, "out_was_terminal")) return rc;
     HIP_TRY(h->lane_group ? mapf::launch_step_lg(int(h->A), a, h->tune, h->stream) : mapf::launch_step(int(h->A), a, h->stream));
     if (h->last_step_kernel != g_noted_kernel) h->last_step_kernel = g_noted_kernel;
-    h->t += 1;
+    if (h->capturing) h->cap_steps += 1; else h->t += 1;
     if (!h->device_ptrs) {
         if (int rc = fetch_out(h, a.out_local, out_local, EA)) return rc;
         if (int rc = fetch_out(h, a.out_reward, out_reward, E)) return rc;
@@ -548,7 +618,9 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     const size_t E = size_t(h->E), T = io->n_steps, TE = T * E, TEA = TE * h->A;
     mapf::RolloutArgs a{};
     a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
-    a.n_envs = h->E; a.env_id_offset = h->env_id_offset; a.t = h->t; a.n_steps = io->n_steps;
+    a.n_envs = h->E; a.env_id_offset = h->env_id_offset; a.n_steps = io->n_steps;
+    a.t = h->capturing ? h->cap_steps : h->t;
+    a.t_dev = h->capturing ? h->t_dev : nullptr;
     a.policy_cells = h->policy_cells;
     a.start_broadcast = h->start_broadcast; a.goal_broadcast = h->goal_broadcast;
     a.auto_reset = io->step_flags & MAPF_STEP_AUTO_RESET;
@@ -565,7 +637,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
         if (int rc = complete_recording(h, a, TE, TEA)) return rc;
         HIP_TRY(h->lane_group_rollout ? mapf::launch_rollout_lg(int(h->A), a, h->tune, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
         if (h->last_rollout_kernel != g_noted_kernel) h->last_rollout_kernel = g_noted_kernel;
-        h->t += io->n_steps;
+        if (h->capturing) h->cap_steps += io->n_steps; else h->t += io->n_steps;
         return MAPF_OK;
     }
     // host-pointer mode: stage everything through device scratch
@@ -608,6 +680,8 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
 
 int mapf_set_policy(mapf_handle_t h, int policy, const uint32_t *cell_rc) {
     if (int rc = check_handle(h)) return rc;
+    if (int rc = check_not_recording(h, "mapf_set_policy")) return rc;
+    if (h->live_graphs > 0) return fail(MAPF_EINVAL, "set_policy: recorded graphs hold the current policy table (destroy them first)");
     if (policy != MAPF_POLICY_RANDOM && policy != MAPF_POLICY_GREEDY) return fail(MAPF_EINVAL, "set_policy: unknown policy");
     HIP_TRY(hipStreamSynchronize(h->stream));   // no launch may still be reading the old table
     if (policy == MAPF_POLICY_RANDOM) {
@@ -739,6 +813,7 @@ int mapf_query_terminal(mapf_handle_t h, uint8_t *out_terminal) {
 
 int mapf_get_state(mapf_handle_t h, uint16_t *local, uint64_t *t) {
     if (int rc = check_handle(h)) return rc;
+    if (int rc = check_not_recording(h, "mapf_get_state")) return rc;
     if (t) *t = h->t;
     if (local) {
         const size_t bytes = size_t(h->E) * h->A * sizeof(uint16_t);
@@ -750,6 +825,7 @@ int mapf_get_state(mapf_handle_t h, uint16_t *local, uint64_t *t) {
 
 int mapf_set_state(mapf_handle_t h, const uint16_t *local, uint64_t t) {
     if (int rc = check_handle(h)) return rc;
+    if (int rc = check_not_recording(h, "mapf_set_state")) return rc;
     if (local) {
         const size_t n = size_t(h->E) * h->A;
         if (!h->device_ptrs) {
@@ -761,6 +837,80 @@ int mapf_set_state(mapf_handle_t h, const uint16_t *local, uint64_t t) {
         if (!h->device_ptrs) HIP_TRY(hipStreamSynchronize(h->stream));
     }
     h->t = t;
+    return MAPF_OK;
+}
+
+int mapf_state_view(mapf_handle_t h, const uint16_t **out_state) {
+    if (int rc = check_handle(h)) return rc;
+    if (!out_state) return fail(MAPF_EINVAL, "out_state is null");
+    *out_state = h->state;
+    return MAPF_OK;
+}
+
+int mapf_graph_begin(mapf_handle_t h) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->device_ptrs) return fail(MAPF_EINVAL, "graph_begin: only handles created with MAPF_FLAG_DEVICE_PTRS can be recorded (host-pointer calls wait for the stream)");
+    if (h->capturing) return fail(MAPF_EINVAL, "graph_begin: already recording");
+    HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
+    h->capturing = true;
+    h->cap_steps = 0;
+    return MAPF_OK;
+}
+
+int mapf_graph_end(mapf_handle_t h, mapf_graph_t *out_graph) {
+    if (int rc = check_handle(h)) return rc;
+    if (!h->capturing) return fail(MAPF_EINVAL, "graph_end: not recording");
+    hipError_t adv = hipSuccess;
+    if (out_graph && h->cap_steps) adv = mapf::launch_advance_step_index(h->t_dev, h->cap_steps, h->stream);   // the recording's last node
+    hipGraph_t graph = nullptr;
+    const hipError_t end = hipStreamEndCapture(h->stream, &graph);
+    h->capturing = false;
+    if (out_graph) *out_graph = nullptr;
+    if (adv != hipSuccess || end != hipSuccess || !graph || !out_graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        if (!out_graph) return fail(MAPF_EINVAL, "graph_end: out_graph is null (the recording was dropped)");
+        return hip_fail(adv != hipSuccess ? adv : (end != hipSuccess ? end : hipErrorUnknown), "graph_end: the recording failed");
+    }
+    mapf_graph_t g = new (std::nothrow) mapf_graph_s();
+    if (!g) { (void)hipGraphDestroy(graph); return fail(MAPF_EHIP, "out of host memory"); }
+    g->owner = h; g->graph = graph; g->steps = h->cap_steps;
+    const hipError_t inst = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+    if (inst != hipSuccess) { (void)hipGraphDestroy(graph); delete g; return hip_fail(inst, "hipGraphInstantiate"); }
+    h->live_graphs += 1;
+    *out_graph = g;
+    return MAPF_OK;
+}
+
+int mapf_graph_launch(mapf_handle_t h, mapf_graph_t g, uint32_t n_replays) {
+    if (int rc = check_handle(h)) return rc;
+    if (int rc = check_not_recording(h, "mapf_graph_launch")) return rc;
+    if (!g || g->owner != h) return fail(MAPF_EINVAL, "graph_launch: not a graph of this handle");
+    // the device-side index must hold the handle's step index when the first recorded launch reads it
+    if (h->t_dev_value != h->t) {
+        HIP_TRY(mapf::launch_set_step_index(h->t_dev, h->t, h->stream));
+        h->t_dev_value = h->t;
+    }
+    for (uint32_t r = 0; r < n_replays; ++r) HIP_TRY(hipGraphLaunch(g->exec, h->stream));
+    h->t += uint64_t(n_replays) * g->steps;
+    h->t_dev_value = h->t;
+    return MAPF_OK;
+}
+
+int mapf_graph_steps(mapf_graph_t g, uint64_t *out_steps) {
+    if (!g || !out_steps) return fail(MAPF_EINVAL, "null graph or output");
+    *out_steps = g->steps;
+    return MAPF_OK;
+}
+
+int mapf_graph_destroy(mapf_handle_t h, mapf_graph_t g) {
+    if (int rc = check_handle(h)) return rc;
+    if (!g || g->owner != h) return fail(MAPF_EINVAL, "graph_destroy: not a graph of this handle");
+    HIP_TRY(hipStreamSynchronize(h->stream));   // no replay may still be running
+    if (g->exec) (void)hipGraphExecDestroy(g->exec);
+    if (g->graph) (void)hipGraphDestroy(g->graph);
+    h->live_graphs -= 1;
+    delete g;
     return MAPF_OK;
 }
 

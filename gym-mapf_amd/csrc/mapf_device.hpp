@@ -80,11 +80,18 @@ __device__ __forceinline__ void store_row(T *base, uint64_t row, const Row<T, N>
     *reinterpret_cast<Row<T, N> *>(base + row * N) = r;
 }
 
+// step index of a launch's first step (StepArgs::t_dev): one scalar load when the launch was recorded into a graph
+template <typename ArgsT>
+__device__ __forceinline__ uint64_t first_step_index(const ArgsT &p) {
+    return p.t_dev ? p.t + *p.t_dev : p.t;
+}
+
 // end-of-step signal of a ONE-WAVE launch (StepArgs::done_flag): every store of the wave is older than this release
 __device__ __forceinline__ void signal_step_done(uint32_t *flag, uint32_t seq) {
     if (flag) {
         __threadfence_system();
-        if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        // (a flagged launch has at most 64 live threads, all in the first wave of block 0: no other wave may publish)
+        if (blockIdx.x == 0u && threadIdx.x == 0u) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -51,7 +51,7 @@ __global__ void __launch_bounds__(256) step_kernel(const StepArgs p) {
     }
 
     StepResult<A> res;
-    env_transition<A, EXT_UNIFORMS>(p.c, p.mv, slip, prev, goal, act, uext, p.env_id_offset + e, p.t, res);
+    env_transition<A, EXT_UNIFORMS>(p.c, p.mv, slip, prev, goal, act, uext, p.env_id_offset + e, first_step_index(p), res);
 
     Row<uint16_t, A> nx;
 #pragma unroll
@@ -85,10 +85,10 @@ __global__ void __launch_bounds__(256) rollout_kernel(const RolloutArgs p) {
     double ret = (p.accumulate && p.out_returns) ? p.out_returns[e] : 0.0;
     uint32_t episodes = (p.accumulate && p.out_episodes) ? p.out_episodes[e] : 0u;
     uint32_t collisions = (p.accumulate && p.out_collisions) ? p.out_collisions[e] : 0u;
-    const uint64_t env_id = p.env_id_offset + e;
+    const uint64_t env_id = p.env_id_offset + e, t0 = first_step_index(p);
 
     for (uint32_t s = 0; s < p.n_steps; ++s) {
-        const uint64_t t = p.t + s;
+        const uint64_t t = t0 + s;
         const uint64_t row = uint64_t(s) * p.n_envs + e;
         uint32_t act[A];
         if (p.actions) {
@@ -167,22 +167,28 @@ hipError_t MAPF_G(launch_step_g)(int n_agents, const StepArgs &args, hipStream_t
     return hipGetLastError();
 }
 
+// Only the spill-free specialisations exist in the shipped objects (kTpeRolloutMaxAgents; inside a template the
+// discarded branch is not instantiated): the larger ones are built by `make tpe16` for tools/exp/tpe_spill_repro.sh only.
+template <int N>
+static hipError_t launch_tpe_rollout(const RolloutArgs &args, unsigned grid, unsigned block, hipStream_t stream) {
+    if constexpr (N <= kTpeRolloutMaxAgents) {
+        hipLaunchKernelGGL((rollout_kernel<N>), dim3(grid), dim3(block), 0, stream, args);
+        return hipGetLastError();
+    } else {
+        return hipErrorInvalidValue;
+    }
+}
+
 hipError_t MAPF_G(launch_rollout_g)(int n_agents, const RolloutArgs &args, hipStream_t stream) {
     if (args.n_envs == 0) return hipSuccess;
     const unsigned block = pick_block(args.n_envs), grid = grid_for(args.n_envs, block);
     note_kernel("rollout_kernel<A=%d> block=%u (thread per env)", n_agents, block);
     switch (n_agents) {
-#define X(N)                                                                                       \
-    case N:                                                                                        \
-        if constexpr (N <= kTpeRolloutMaxAgents)                                                   \
-            hipLaunchKernelGGL((rollout_kernel<N>), dim3(grid), dim3(block), 0, stream, args);    \
-        else return hipErrorInvalidValue;                                                          \
-        break;
+#define X(N) case N: return launch_tpe_rollout<N>(args, grid, block, stream);
         MAPF_FOR_EACH_A(X)
 #undef X
         default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
 }
 
 }  // namespace mapf

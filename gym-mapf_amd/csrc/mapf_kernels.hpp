@@ -55,6 +55,15 @@ struct StepArgs {
     double *out_reward, *out_prob;
     uint8_t *out_done, *out_collision, *out_was_terminal;
     uint64_t n_envs, env_id_offset, t;
+    // Step index of a launch = t + (t_dev ? *t_dev : 0).  Plain launches bake the handle's index into t (t_dev null); a launch
+    // recorded into a hipGraph (mapf_graph_begin .. mapf_graph_end) carries its offset inside the recording in t and reads
+    // the recording's first index from device memory, which the graph's last node advances -- so a replay draws fresh numbers.
+    const uint64_t *t_dev;
+    // Scenario table (mapf_create builds it when the batch has at most 256 distinct (start row, goal row) pairs): scen[e]
+    // names env e's pair, scen_rows[(2 * scen + 0 | 1) * A ..] are its start / goal cells -- the packed single step reads
+    // one byte per env instead of two A-cell rows.  Null when the rows are broadcast or too varied.
+    const uint8_t *scen;
+    const uint16_t *scen_rows;
     uint32_t *done_flag;           // one-wave launches only (else null): host-visible word that receives done_seq
     uint32_t done_seq;             //   after every output of the step has been written (system-scope release)
     bool start_broadcast, goal_broadcast, auto_reset;
@@ -74,6 +83,7 @@ struct RolloutArgs {
     double *rec_reward, *rec_prob;
     uint8_t *rec_done, *rec_collision;
     uint64_t n_envs, env_id_offset, t;
+    const uint64_t *t_dev;         // see StepArgs: first step index = t + (t_dev ? *t_dev : 0)
     uint32_t n_steps;
     bool start_broadcast, goal_broadcast, auto_reset, accumulate;
     bool start_terminal_any;       // some env's START state is terminal (two starts coincide / every start is its goal)
@@ -114,6 +124,11 @@ hipError_t launch_reset(int n_agents, uint16_t *state, const uint16_t *start, bo
 hipError_t launch_fill_actions(int n_agents, uint8_t *actions, const EnvConsts &c, uint64_t env_id_offset,
                                uint64_t n_envs, uint64_t t0, uint64_t n_steps, hipStream_t stream);
 
+// *t_dev += n from one thread: the last node of a recorded graph (mapf_graph_end)
+hipError_t launch_advance_step_index(uint64_t *t_dev, uint64_t n, hipStream_t stream);
+// *t_dev = value (mapf_graph_launch, when the host side moved the step index since the last replay)
+hipError_t launch_set_step_index(uint64_t *t_dev, uint64_t value, hipStream_t stream);
+
 hipError_t launch_query_terminal(int n_agents, const uint16_t *state, const uint16_t *goal, bool goal_broadcast,
                                  uint8_t *out, uint64_t n_envs, hipStream_t stream);
 
@@ -133,6 +148,7 @@ struct RolloutTuning {
                                      //   two waves on every SIMD)
     int force_k = 0;                 // MAPF_LQ_K=2|4|8 pins the agents per lane of the packed layout (tests)
     size_t mv_lds_max_bytes = 0;     // largest move table staged into LDS (MAPF_MV_LDS_MAX_BYTES; default: two blocks per CU)
+    bool scen_table = true;          // MAPF_SCEN_TABLE=0: never build the scenario table (StepArgs::scen) -- tests compare both forms
 };
 RolloutTuning default_rollout_tuning(int device);
 hipError_t launch_step_lg(int n_agents, const StepArgs &args, const RolloutTuning &tune, hipStream_t stream);

@@ -16,6 +16,9 @@
 #pragma once
 #include "mapf_kernels.hpp"
 #include "mapf_device.hpp"
+#include <mutex>
+#include <set>
+#include <utility>
 
 #ifdef MAPF_STAMPS   // diagnostic build only: per-segment cycle sums of the rollout loop (never shipped)
 struct StampCtx { unsigned long long seg[8]; unsigned long long last; };
@@ -483,6 +486,20 @@ __device__ __forceinline__ LaneCtx<L> lane_ctx(uint32_t n_agents, uint64_t n_env
     x.v1 = live && 2u * x.g + 1u < n_agents;
     if (!live) x.e = 0;
     return x;
+}
+
+// Dynamic LDS beyond the 32 KB default needs an explicit opt-in per (device, kernel).  The driver call is made once per
+// pair and remembered: it would otherwise sit in the enqueue path of every launch (and of every launch a bench times).
+static inline hipError_t allow_large_lds(const void *kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void *>> done;
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev)) return e;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count({dev, kernel})) return hipSuccess;
+    if (hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) return e;
+    done.insert({dev, kernel});
+    return hipSuccess;
 }
 
 static inline void lg_geometry(int L, uint64_t n_envs, unsigned &grid, unsigned &block) {

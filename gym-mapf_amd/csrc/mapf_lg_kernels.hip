@@ -30,9 +30,10 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
     StampCtx st{};
 #endif
     Words4 rng{0u, 0u, 0u, 0u};
-    if (!EXT_UNIFORMS && p.c.need_rng) rng = slip_words(p.c, p.env_id_offset + e, p.t >> 2, x.g, 0u, 0u);
+    const uint64_t t = first_step_index(p);
+    if (!EXT_UNIFORMS && p.c.need_rng) rng = slip_words(p.c, p.env_id_offset + e, t >> 2, x.g, 0u, 0u);
     lg_transition<L, FULL, EXT_UNIFORMS, false, false, false, !EXT_UNIFORMS>(p.c, p.mv, rows, nullptr, x, n_agents, cur0, cur1, goal0, goal1, act0, act1,
-                                                u0, u1, p.env_id_offset + e, p.t, rng, false, next0, next1, o STAMP_ARG);
+                                                u0, u1, p.env_id_offset + e, t, rng, false, next0, next1, o STAMP_ARG);
     if (!live) return;
 
     if (p.out_local) store_cells(p.out_local, e, n_agents, x.g, x.v0, x.v1, next0, next1);
@@ -97,6 +98,21 @@ __global__ void __launch_bounds__(256) fill_actions_kernel(uint8_t *actions, Env
 #pragma unroll
     for (uint32_t k = 0; k < 4; ++k)
         if (4u * q + k < n_agents) dst[k] = uint8_t(__umulhi(w[k], 5u));
+}
+
+// the device-side step index of a recorded graph (StepArgs::t_dev): advanced by the graph's last node
+__global__ void __launch_bounds__(64) advance_step_index_kernel(uint64_t *t_dev, uint64_t n, bool set) {
+    if (blockIdx.x == 0u && threadIdx.x == 0u) *t_dev = set ? n : *t_dev + n;
+}
+
+hipError_t launch_advance_step_index(uint64_t *t_dev, uint64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(advance_step_index_kernel, dim3(1), dim3(64), 0, stream, t_dev, n, false);
+    return hipGetLastError();
+}
+
+hipError_t launch_set_step_index(uint64_t *t_dev, uint64_t value, hipStream_t stream) {
+    hipLaunchKernelGGL(advance_step_index_kernel, dim3(1), dim3(64), 0, stream, t_dev, value, true);
+    return hipGetLastError();
 }
 
 static inline hipError_t grid_1d(uint64_t n, unsigned block, unsigned &grid) {

@@ -170,8 +170,9 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     uint32_t goal_rc0 = 0u, goal_rc1 = 0u;   // greedy policy: my agents' goal coordinates
     if (!STREAM && p.policy_cells) { goal_rc0 = p.policy_cells[goal0].x; goal_rc1 = p.policy_cells[goal1].x; }
 
+    const uint64_t t_first = first_step_index(p);
     for (uint32_t s = 0; s < p.n_steps; ++s) {
-        const uint64_t t = p.t + s;
+        const uint64_t t = t_first + s;
         uint32_t act0, act1;
         if (STREAM) {
             act0 = raw & 0xFFu; act1 = (raw >> 8) & 0xFFu;   // only the low half-word of `raw` is defined
@@ -255,6 +256,7 @@ RolloutTuning default_rollout_tuning(int device) {
     if (const char *e = getenv("MAPF_OCT_MIN_LANES")) t.oct_min_lanes = uint64_t(strtoull(e, nullptr, 10));
     t.mv_lds_max_bytes = (kLdsBytes - kLdsReserve) / 2;
     if (const char *e = getenv("MAPF_MV_LDS_MAX_BYTES")) t.mv_lds_max_bytes = size_t(strtoull(e, nullptr, 10));
+    if (const char *e = getenv("MAPF_SCEN_TABLE")) t.scen_table = atoi(e) != 0;
     return t;
 }
 
@@ -262,7 +264,7 @@ template <int L, bool FULL, bool RECORD, bool STREAM>
 static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, const RolloutTuning &tune, hipStream_t stream) {
     const size_t mv_bytes = size_t(args.c.n_cells) * 5 * sizeof(MoveEntry);
     const uint64_t threads = args.n_envs * uint64_t(L);
-    if (mv_bytes + kLdsReserve <= tune.mv_lds_max_bytes && threads >= 64 * 256) {
+    if (mv_bytes + kLdsReserve <= tune.mv_lds_max_bytes && mv_bytes + kLdsReserve <= kLdsBytes && threads >= 64 * 256) {
         // block size: as many waves as can share one table copy while >= 16 waves stay resident per CU
         const size_t copies = (kLdsBytes - kLdsReserve) / (mv_bytes + sizeof(SlipRow) * 8);   // blocks per CU by LDS
         unsigned block = copies >= 4 ? 256u : (copies >= 2 ? 512u : 1024u);
@@ -271,10 +273,8 @@ static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, co
         const unsigned grid = unsigned((args.n_envs + per_block - 1) / per_block);
         const bool dense = FULL && args.n_envs % per_block == 0;
         auto kern = dense ? lg_rollout_kernel<L, FULL, true, RECORD, STREAM, FULL> : lg_rollout_kernel<L, FULL, true, RECORD, STREAM, false>;
-        if (mv_bytes > 32 * 1024) {   // dynamic LDS beyond the default cap needs an explicit opt-in;
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),   // per device, so not cached
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, int(kLdsBytes - kLdsReserve));
-            if (e != hipSuccess) return e;
+        if (mv_bytes > 32 * 1024) {
+            if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), int(kLdsBytes - kLdsReserve))) return e;
         }
         note_kernel("lg_rollout_kernel<L=%d,%s,MV_LDS,%s,%s,%s> block=%u (pair layout: 2 agents per lane)", L,
                     FULL ? "FULL" : "RAGGED", RECORD ? "RECORD" : "TOTALS", STREAM ? "STREAM" : "POLICY", dense ? "DENSE" : "GUARDED", block);

@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     uint32_t episodes = (p.accumulate && epi_p && leader) ? *epi_p : 0u;
     uint32_t collisions = (p.accumulate && col_p && leader) ? *col_p : 0u;
     const uint64_t env_id = p.env_id_offset + e;
+    const uint64_t t_first = first_step_index(p);
     const uint32_t n_envs = uint32_t(p.n_envs);
 
     // per-lane pointers into the step rows; they advance by wave-uniform strides
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         constexpr int W = decltype(w_tag)::value;
         constexpr bool FIRST = decltype(first_tag)::value, TAIL = decltype(tail_tag)::value;
         constexpr bool MAYBE_TERMINAL = TERM || FIRST;   // (the launch's first step finds whatever state the last launch left)
-        const uint64_t t = p.t + s;
+        const uint64_t t = t_first + s;
         uint32_t cur[K], act[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) cur[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu;
@@ -461,7 +462,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     // a single step outside the unrolled loop: its slip word is still picked statically (one four-way branch instead of
     // the word selects inside the step), its prefetch address is clamped
     auto single_step = [&](const uint32_t s) __attribute__((always_inline)) {
-        switch (uint32_t(p.t + s) & 3u) {
+        switch (uint32_t(t_first + s) & 3u) {
             case 0: one_step(s, raw[0], W0{}, No{}, Yes{}); break;
             case 1: one_step(s, raw[0], W1{}, No{}, Yes{}); break;
             case 2: one_step(s, raw[0], W2{}, No{}, Yes{}); break;
@@ -477,7 +478,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         shift_raw();
         s = 1;
     }
-    for (; s < p.n_steps && ((p.t + s) & 3u) != 0u; ++s) single_step(s);
+    for (; s < p.n_steps && ((t_first + s) & 3u) != 0u; ++s) single_step(s);
     for (; s + 2u * kAhead <= p.n_steps; s += kAhead) {        // the group's last step prefetches row s + 2 kAhead - 1
         one_step(s, raw[0], W0{}, No{}, No{});
         one_step(s + 1u, raw[1], W1{}, No{}, No{});
@@ -518,10 +519,8 @@ hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size
     auto kern = args.c.criteria != 0u ? lq_rollout_kernel<Q, K, RECORD, STREAM, true, COMPACT, true>
                 : term            ? lq_rollout_kernel<Q, K, RECORD, STREAM, false, COMPACT, true>
                                   : lq_rollout_kernel<Q, K, RECORD, STREAM, false, COMPACT, false>;
-    if (lds_bytes > 32 * 1024) {   // dynamic LDS beyond the default cap needs an explicit opt-in (per device: not cached)
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           int(kLdsBytes - kLdsReserve));
-        if (e != hipSuccess) return e;
+    if (lds_bytes > 32 * 1024) {
+        if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), int(kLdsBytes - kLdsReserve))) return e;
     }
     const unsigned grid = unsigned(args.n_envs / (block / unsigned(Q)));
     note_kernel("lq_rollout_kernel<Q=%d,K=%d,%s,%s,%s%s%s> block=%u (packed layout: %d agents per lane%s)", Q, K, RECORD ? "RECORD" : "TOTALS",
@@ -626,7 +625,7 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
     int Q = 0, K = 0;
     bool compact = false;
     size_t lds_bytes = kMoveAt + size_t(args.c.n_cells) * kMoveCols * sizeof(MoveEntry);   // the kernel's whole LDS image
-    if (lds_bytes <= tune.mv_lds_max_bytes) {
+    if (lds_bytes <= tune.mv_lds_max_bytes && lds_bytes <= kLdsBytes - kLdsReserve) {
         // Four agents per lane halve the waves: that form needs tune.quad_min_lanes lanes (default: enough to put one
         // wave on every SIMD); below that the two-agents-per-lane form of the same kernel runs.
         // Eight agents per lane halve them again (at 8 agents nothing crosses lanes any more): worth it from two waves

@@ -15,7 +15,10 @@ namespace mapf {
 
 namespace {
 
-template <int Q, int K>
+// SCEN: the env's start / goal rows come from the handle's scenario table (StepArgs::scen) -- one byte per env and two
+// small gathers that hit in L1 / L2, issued beside the move-table gathers, instead of two A-cell rows from HBM; the
+// start cells are then at hand when the step ends the episode, so the state store needs no branch either.
+template <int Q, int K, bool SCEN>
 __global__ void __launch_bounds__(256) lq_step_kernel(const StepArgs p, const uint32_t n_agents) {
     constexpr int P = K / 2;
     LaneCtx<Q> x;
@@ -27,17 +30,27 @@ __global__ void __launch_bounds__(256) lq_step_kernel(const StepArgs p, const ui
     const uint32_t e = x.e;
     const uint32_t lane_cell = e * n_agents + uint32_t(K) * x.g;    // my first agent's element index
     const uint32_t fixed_cell = uint32_t(K) * x.g;                  // ... in a broadcast row
-    const uint64_t env_id = p.env_id_offset + e, t = p.t;
+    const uint64_t env_id = p.env_id_offset + e, t = first_step_index(p);
 
-    uint32_t c[P], g[P];
+    uint32_t c[P], g[P], sc[P];
+    uint32_t scen_row = 0u;
+    if (SCEN) scen_row = uint32_t(*at(p.scen, e)) * 2u * n_agents + fixed_cell;   // my cells of the env's start row; goal row: + A
     {
         const Packed<P> cells = Packed<P>::load(at(p.state, lane_cell));
-        const Packed<P> gl = Packed<P>::load(at(p.goal, p.goal_broadcast ? fixed_cell : lane_cell));
 #pragma unroll
-        for (int i = 0; i < P; ++i) { c[i] = cells.v[i]; g[i] = gl.v[i]; }
+        for (int i = 0; i < P; ++i) c[i] = cells.v[i];
     }
     const uint32_t raw = K == 4 ? *reinterpret_cast<const uint32_t *>(at(p.actions, lane_cell))
                                 : uint32_t(*reinterpret_cast<const uint16_t *>(at(p.actions, lane_cell)));
+    if (SCEN) {
+        const Packed<P> gl = Packed<P>::load(at(p.scen_rows, scen_row + n_agents)), sl = Packed<P>::load(at(p.scen_rows, scen_row));
+#pragma unroll
+        for (int i = 0; i < P; ++i) { g[i] = gl.v[i]; sc[i] = sl.v[i]; }
+    } else {
+        const Packed<P> gl = Packed<P>::load(at(p.goal, p.goal_broadcast ? fixed_cell : lane_cell));
+#pragma unroll
+        for (int i = 0; i < P; ++i) { g[i] = gl.v[i]; sc[i] = 0u; }
+    }
     // the slip call of my pair(s) for steps 4h .. 4h+3 (one call per pair per step: a single step cannot amortise it)
     Words4 rng[P];
 #pragma unroll
@@ -126,7 +139,13 @@ __global__ void __launch_bounds__(256) lq_step_kernel(const StepArgs p, const ui
         if (p.out_collision) *at(p.out_collision, e) = (coll && !was_terminal) ? 1 : 0;
         if (p.out_was_terminal) *at(p.out_was_terminal, e) = was_terminal ? 1 : 0;
     }
-    if (p.auto_reset && done) {                                    // MapfEnv.reset(): start cells, no reseed
+    if (SCEN) {                                                    // MapfEnv.reset(): start cells, no reseed
+        const bool back = p.auto_reset && done;                    // (a terminal state that stays is rewritten as it is)
+        Packed<P> keep;
+#pragma unroll
+        for (int i = 0; i < P; ++i) keep.v[i] = back ? sc[i] : n[i];
+        keep.store(at(p.state, lane_cell));
+    } else if (p.auto_reset && done) {
         Packed<P>::load(at(p.start, p.start_broadcast ? fixed_cell : lane_cell)).store(at(p.state, lane_cell));
     } else if (!was_terminal) {
         out.store(at(p.state, lane_cell));
@@ -152,10 +171,13 @@ bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning 
     if (args.n_envs == 0 || args.n_envs % per_block != 0) return false;
     const unsigned grid = unsigned(args.n_envs / per_block);
     const uint32_t A = uint32_t(n_agents);
-    note_kernel("lq_step_kernel<Q=%d,K=%d> block=%u (packed layout: %d agents per lane)", Q, K, block, K);
+    const bool scen = args.scen != nullptr;
+    note_kernel("lq_step_kernel<Q=%d,K=%d%s> block=%u (packed layout: %d agents per lane%s)", Q, K, scen ? ",SCEN" : "", block, K,
+                scen ? ", start / goal rows from the scenario table" : "");
 #define MAPF_LQ_STEP(QQ, KK)                                                                                   \
     if (Q == QQ && K == KK) {                                                                                  \
-        hipLaunchKernelGGL((lq_step_kernel<QQ, KK>), dim3(grid), dim3(block), 0, stream, args, A);             \
+        if (scen) hipLaunchKernelGGL((lq_step_kernel<QQ, KK, true>), dim3(grid), dim3(block), 0, stream, args, A);   \
+        else hipLaunchKernelGGL((lq_step_kernel<QQ, KK, false>), dim3(grid), dim3(block), 0, stream, args, A);       \
         *err = hipGetLastError();                                                                              \
         return true;                                                                                           \
     }

@@ -58,6 +58,12 @@ SIGNATURES = {
     'mapf_query_terminal': (c_int, [c_void_p, c_void_p]),
     'mapf_get_state': (c_int, [c_void_p, c_void_p, POINTER(c_uint64)]),
     'mapf_set_state': (c_int, [c_void_p, c_void_p, c_uint64]),
+    'mapf_state_view': (c_int, [c_void_p, POINTER(c_void_p)]),
+    'mapf_graph_begin': (c_int, [c_void_p]),
+    'mapf_graph_end': (c_int, [c_void_p, POINTER(c_void_p)]),
+    'mapf_graph_launch': (c_int, [c_void_p, c_void_p, c_uint32]),
+    'mapf_graph_steps': (c_int, [c_void_p, POINTER(c_uint64)]),
+    'mapf_graph_destroy': (c_int, [c_void_p, c_void_p]),
     'mapf_sync': (c_int, [c_void_p]),
     'mapf_timer_begin': (c_int, [c_void_p]),
     'mapf_timer_end': (c_int, [c_void_p, POINTER(c_double)]),

@@ -34,6 +34,39 @@ def _locs_to_local(loc_to_int, locs):
     return [loc_to_int[(int(l[0]), int(l[1]))] for l in locs]
 
 
+class _DeviceView:
+    """``__cuda_array_interface__`` carrier: lets torch wrap a device pointer the library owns without copying."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {'shape': tuple(shape), 'typestr': typestr, 'data': (int(ptr), False), 'version': 2}
+        self._owner = owner   # the view must not outlive the env
+
+
+class StepGraph:
+    """A recorded sequence of ``step`` / ``rollout`` calls (``VecMapfEnv.graph_begin`` .. ``graph_end``): ``launch(n)``
+    replays it n times.  The step index lives in device memory for recorded launches, so every replay draws fresh
+    random numbers -- n replays of an N-step recording equal n * N ``step`` calls with the same arrays."""
+
+    def __init__(self, env, handle, steps):
+        self._env, self._g, self.steps = env, handle, steps
+
+    def launch(self, n_replays=1):
+        rc = self._env._lib.mapf_graph_launch(self._env._h, self._g, int(n_replays))
+        if rc:
+            nat.check(rc)
+
+    def close(self):
+        g, self._g = self._g, None
+        if g and self._env._h:
+            nat.check(self._env._lib.mapf_graph_destroy(self._env._h, g))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class VecMapfEnv:
     def __init__(self, grid, n_agents, start_locations, goal_locations, fail_prob,
                  reward_of_collision, reward_of_goal, reward_of_living, optimization_criteria,
@@ -188,10 +221,12 @@ class VecMapfEnv:
         info = {'prob': out['prob'], 'collision': out['collision'], 'was_terminal': out['was_terminal']}
         return out['local'], out['reward'], out['done'], info
 
-    def prepare_step(self, actions, uniforms=None, auto_reset=False, out=None):
+    def prepare_step(self, actions, uniforms=None, auto_reset=False, out=None, write_local=True):
         """Validate once, call many times: returns ``(call, out)`` where ``call()`` performs
         ``mapf_step`` on exactly these arrays (the per-call Python cost is one ctypes call).  Meant
-        for device mode, where a training loop refills ``actions`` in place every iteration."""
+        for device mode, where a training loop refills ``actions`` in place every iteration.
+        ``write_local=False`` leaves ``out_local`` out of the call: the next observation is then read from
+        ``state_view()`` (the handle's own state buffer, after auto-reset) and the step writes the cells once."""
         E, A = self.n_envs, self.n_agents
         actions = self._coerce(actions, np.uint8, (E, A), 'actions')
         uniforms = self._coerce(uniforms, np.float64, (E, A), 'uniforms')
@@ -199,11 +234,12 @@ class VecMapfEnv:
         spec = (('local', np.uint16, (E, A)), ('reward', np.float64, (E,)), ('done', np.uint8, (E,)),
                 ('collision', np.uint8, (E,)), ('prob', np.float64, (E,)), ('was_terminal', np.uint8, (E,)))
         for name, dt, shp in spec:
-            if name not in out:
+            if name not in out and (write_local or name != 'local'):
                 out[name] = self._empty(shp, dt)
         args = (self._h, self._ptr(actions, np.uint8, (E, A), 'actions'),
                 self._ptr(uniforms, np.float64, (E, A), 'uniforms'),
-                self._ptr(out['local'], np.uint16, (E, A), 'local'), self._ptr(out['reward'], np.float64, (E,), 'reward'),
+                self._ptr(out['local'], np.uint16, (E, A), 'local') if write_local else None,
+                self._ptr(out['reward'], np.float64, (E,), 'reward'),
                 self._ptr(out['done'], np.uint8, (E,), 'done'), self._ptr(out['collision'], np.uint8, (E,), 'collision'),
                 self._ptr(out['prob'], np.float64, (E,), 'prob'),
                 self._ptr(out['was_terminal'], np.uint8, (E,), 'was_terminal'),
@@ -217,6 +253,28 @@ class VecMapfEnv:
             return keep
 
         return call, out
+
+    def state_view(self):
+        """The handle's own state buffer as a uint16 [E, A] CUDA tensor (device mode only; no copy): ``env.s`` of every
+        env as per-agent cells -- after an auto-reset step the state the NEXT step starts from (a finished episode
+        shows its start cells).  Its contents change with every step / rollout / reset enqueued on the env's stream."""
+        if not self.device_arrays:
+            raise ValueError('state_view() needs device_arrays=True (use get_state() in host mode)')
+        ptr = ctypes.c_void_p()
+        nat.check(self._lib.mapf_state_view(self._h, ctypes.byref(ptr)))
+        return self._torch.as_tensor(_DeviceView(ptr.value, (self.n_envs, self.n_agents), '<u2', self), device=self._tdev)
+
+    def graph_begin(self):
+        """Start recording ``step`` / ``prepare_step`` calls / ``rollout`` / ``reset`` into a hipGraph (device mode only)."""
+        nat.check(self._lib.mapf_graph_begin(self._h))
+
+    def graph_end(self):
+        """Finish the recording: returns a ``StepGraph``."""
+        g = ctypes.c_void_p()
+        nat.check(self._lib.mapf_graph_end(self._h, ctypes.byref(g)))
+        steps = ctypes.c_uint64(0)
+        nat.check(self._lib.mapf_graph_steps(g, ctypes.byref(steps)))
+        return StepGraph(self, g, steps.value)
 
     def rollout(self, n_steps, actions=None, auto_reset=True, record=False, accumulate_into=None):
         """``n_steps`` fused steps in one launch.  ``actions`` uint8 [T, E, A] or None for the

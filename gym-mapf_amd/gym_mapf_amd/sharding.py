@@ -23,17 +23,29 @@ def split_evenly(n_total, rank, world):
     return offset, count
 
 
-def gather_returns(local_returns, group=None):
-    """All-gather equal-sized per-rank ``returns`` tensors into one tensor ordered by global env id.
-    Works on CUDA tensors with the nccl(RCCL) backend and on CPU tensors with gloo."""
+def gather_returns(local_returns, group=None, counts=None):
+    """All-gather per-rank ``returns`` tensors into one tensor ordered by global env id.  ``counts`` = every rank's
+    shard size (``split_evenly`` gives the lowest ranks one env more when the population does not divide): shards
+    are padded to the largest for the collective and the padding is cut out again.  Works on CUDA tensors with the
+    nccl(RCCL) backend and on CPU tensors with gloo."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    out = torch.empty((world * local_returns.numel(),), dtype=local_returns.dtype, device=local_returns.device)
-    if local_returns.is_cuda:
-        dist.all_gather_into_tensor(out, local_returns.contiguous(), group=group)
+    n = local_returns.numel()
+    counts = [n] * world if counts is None else [int(c) for c in counts]
+    if len(counts) != world or counts[dist.get_rank(group)] != n:
+        raise ValueError('counts %r do not describe this rank\'s shard of %d' % (counts, n))
+    width = max(counts)
+    padded = local_returns.contiguous()
+    if n < width:
+        padded = torch.cat([padded, padded.new_zeros(width - n)])
+    if padded.is_cuda:
+        out = torch.empty((world * width,), dtype=padded.dtype, device=padded.device)
+        dist.all_gather_into_tensor(out, padded, group=group)
+        parts = list(out.view(world, width))
     else:
-        parts = [torch.empty_like(local_returns) for _ in range(world)]
-        dist.all_gather(parts, local_returns.contiguous(), group=group)
-        out = torch.cat(parts)
-    return out
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded, group=group)
+    if all(c == width for c in counts):
+        return torch.cat(parts) if not padded.is_cuda else out
+    return torch.cat([p[:c] for p, c in zip(parts, counts)])

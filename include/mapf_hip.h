@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MAPF_ABI_VERSION 2
+#define MAPF_ABI_VERSION 3
 
 /* status codes */
 #define MAPF_OK            0
@@ -207,6 +207,34 @@ int mapf_query_terminal(mapf_handle_t h, uint8_t *out_terminal);
  * counter-based).  set_state validates cells < V. */
 int mapf_get_state(mapf_handle_t h, uint16_t *local, uint64_t *t);
 int mapf_set_state(mapf_handle_t h, const uint16_t *local, uint64_t t);
+
+/*
+ * The handle's state buffer itself: out_state receives a DEVICE pointer to u16[E*A], env.s of every env as per-agent cells
+ * -- after a step with MAPF_STEP_AUTO_RESET that is the state the next step starts from (a finished episode shows its start
+ * cells, the usual vector-env convention; mapf_step's out_local reports the state step() itself returned).  A caller that
+ * reads the next observation here passes out_local = NULL to mapf_step and the step writes the cells ONCE.  The pointer
+ * stays valid for the handle's lifetime; its contents change with every step / rollout / reset / set_state enqueued on
+ * the handle's stream (read it on that stream or after mapf_sync).  No reference counterpart: MapfEnv.s (mapf_env.py:265).
+ */
+int mapf_state_view(mapf_handle_t h, const uint16_t **out_state);
+
+/*
+ * Recording the caller-side loop around MapfEnv.step (mapf_env.py:237-266) into a hipGraph.  Between mapf_graph_begin and
+ * mapf_graph_end every mapf_step / mapf_rollout / mapf_reset / mapf_fill_random_actions call on a MAPF_FLAG_DEVICE_PTRS
+ * handle is recorded on the handle's stream instead of executed (work the caller enqueues on that stream in between --
+ * e.g. its policy network -- is recorded with it).  mapf_graph_launch replays the recording n_replays times; the step
+ * index t is kept in device memory for recorded launches and advanced by the recording's last node, so every replay draws
+ * fresh random numbers: K replays of an N-step recording produce exactly the results of K*N mapf_step calls with the same
+ * arguments.  The arrays named in recorded calls must stay allocated while the graph lives.  Calls that wait for the
+ * stream or move the step index from the host (mapf_sync, mapf_timer_*, mapf_get_state, mapf_set_state, mapf_set_policy)
+ * fail with MAPF_EINVAL while recording, as does recording on a host-pointer handle.
+ */
+typedef struct mapf_graph_s *mapf_graph_t;
+int mapf_graph_begin(mapf_handle_t h);
+int mapf_graph_end(mapf_handle_t h, mapf_graph_t *out_graph);
+int mapf_graph_launch(mapf_handle_t h, mapf_graph_t graph, uint32_t n_replays);
+int mapf_graph_steps(mapf_graph_t graph, uint64_t *out_steps);   /* env-steps one replay advances the handle by */
+int mapf_graph_destroy(mapf_handle_t h, mapf_graph_t graph);
 
 /* Block until everything enqueued on the handle's stream has finished. */
 int mapf_sync(mapf_handle_t h);

@@ -1,0 +1,190 @@
+"""GPU parity of the single-step fast path added in round 3: mapf_step launches recorded into a hipGraph and replayed
+(device-side step index: every replay must draw fresh random numbers), the scenario table (start / goal rows looked up
+through one byte per env) and the handle's state view (out_local = NULL: the cells are written once).  Everything is
+compared with the C oracle bit for bit: cells, flags and the float64 bit patterns of reward and prob."""
+import numpy as np
+import pytest
+
+import c_oracle
+import mapf_oracle as mo
+from gym_mapf_amd import _native as nat
+from gym_mapf_amd.envs.grid import MapfGrid
+from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv
+
+pytestmark = pytest.mark.gpu
+R = (-1000.0, 100.0, -1.0)
+
+
+def _bits(x):
+    return np.asarray(x, np.float64).view(np.uint64)
+
+
+def _c3_tables(n_envs, offset=0):
+    import bench
+    return bench.workload_tables(bench.CONFIGS['c3'], n_envs, offset)
+
+
+def _check(out, ref, tag, local=True):
+    if local:
+        assert np.array_equal(out['local'].cpu().numpy(), ref['local']), tag
+    assert np.array_equal(_bits(out['reward'].cpu().numpy()), _bits(ref['reward'])), tag
+    assert np.array_equal(_bits(out['prob'].cpu().numpy()), _bits(ref['prob'])), tag
+    assert np.array_equal(out['done'].cpu().numpy(), ref['done']), tag
+    assert np.array_equal(out['collision'].cpu().numpy(), ref['collision']), tag
+    assert np.array_equal(out['was_terminal'].cpu().numpy(), ref['was_terminal']), tag
+
+
+@pytest.mark.parametrize('criteria', ['Makespan', 'SoC'])
+def test_graph_replay_of_recorded_steps_matches_the_oracle(criteria):
+    """16 mapf_step calls recorded once, replayed 6 times = 96 env-steps of 2048 room-32-32-4 envs (the bench workload's
+    tables, six scenarios -> scenario table): every step of every replay against the C oracle.  The odd nodes leave
+    out_local out and are checked through the state view the next node would read."""
+    E, A, N = 2048, 8, 16
+    grid, _, nbr, start, goal = _c3_tables(E, 4096)
+    crit, ocrit = (OptimizationCriteria.SoC, mo.SOC) if criteria == 'SoC' else (OptimizationCriteria.Makespan, mo.MAKESPAN)
+    env = VecMapfEnv(grid, A, None, None, 0.2, *R, crit, seed=7, env_id_offset=4096, device_arrays=True,
+                     start_local=start, goal_local=goal)
+    co = c_oracle.COracle(nbr, A, start, goal, 0.2, *R, ocrit, seed=7, env_id_offset=4096)
+    actions = env.fill_random_actions(0, N)
+    env.sync()
+    acts_host = actions.cpu().numpy()
+    # three plain steps first: the recording must pick the step index up from where the host side left it
+    for t in range(3):
+        local, reward, done, info = env.step(actions[t], auto_reset=True)
+        env.sync()
+        _check(dict(local=local, reward=reward, done=done, **info), co.step(acts_host[t], auto_reset=True), 'plain %d' % t)
+    assert 'SCEN' in env.last_kernel('step'), env.last_kernel('step')
+    env.graph_begin()
+    outs = []
+    for k in range(N):
+        call, out = env.prepare_step(actions[k], auto_reset=True, write_local=(k % 2 == 0))
+        call()
+        outs.append(out)
+    with pytest.raises(nat.MapfNativeError):
+        env.sync()                                   # waiting for the stream is refused while recording
+    graph = env.graph_end()
+    assert graph.steps == N and env.t == 3           # recording executed nothing
+    view = env.state_view()
+    for rep in range(6):
+        graph.launch(1)
+        env.sync()
+        for k in range(N):
+            ref = co.step(acts_host[k], auto_reset=True)
+            _check(outs[k], ref, 'replay %d node %d' % (rep, k), local=(k % 2 == 0))
+        assert np.array_equal(view.cpu().numpy(), co.state), rep      # the state the next step starts from
+        assert env.t == 3 + (rep + 1) * N
+    # several replays in one call, then plain steps again: same stream of random numbers throughout
+    graph.launch(4)
+    env.sync()
+    for rep in range(4):
+        refs = [co.step(acts_host[k], auto_reset=True) for k in range(N)]
+    for k in range(N):                               # the output arrays hold the last replay's results
+        _check(outs[k], refs[k], 'batched replays, node %d' % k, local=(k % 2 == 0))
+    assert np.array_equal(env.get_state()[0].cpu().numpy(), co.state) and env.t == co.t == 3 + 10 * N
+    local, reward, done, info = env.step(actions[5], auto_reset=True)
+    env.sync()
+    _check(dict(local=local, reward=reward, done=done, **info), co.step(acts_host[5], auto_reset=True), 'plain after graph')
+    graph.close()
+    env.close()
+
+
+def test_graph_of_rollout_and_steps_and_host_side_index_moves():
+    """A recording that mixes a fused rollout (8 steps, in-kernel policy) with two single steps; between replays the host
+    side moves the step index (set_state), which the next replay must honour."""
+    E, A = 1024, 8
+    grid, _, nbr, start, goal = _c3_tables(E)
+    env = VecMapfEnv(grid, A, None, None, 0.2, *R, OptimizationCriteria.Makespan, seed=11, device_arrays=True,
+                     start_local=start, goal_local=goal)
+    co = c_oracle.COracle(nbr, A, start, goal, 0.2, *R, mo.MAKESPAN, seed=11)
+    actions = env.fill_random_actions(100, 2)
+    env.sync()
+    acts_host = actions.cpu().numpy()
+    env.graph_begin()
+    res = env.rollout(8, auto_reset=True)
+    outs = []
+    for k in range(2):
+        call, out = env.prepare_step(actions[k], auto_reset=True)
+        call()
+        outs.append(out)
+    graph = env.graph_end()
+    assert graph.steps == 10
+    for rep, t0 in enumerate((0, 10, 1000, 1010)):
+        if t0 == 1000:
+            env.set_state(None, t=1000)
+            co.t = 1000
+        graph.launch(1)
+        env.sync()
+        ref = co.rollout(8, auto_reset=True)
+        assert np.array_equal(_bits(res['returns'].cpu().numpy()), _bits(ref['returns'])), rep
+        assert np.array_equal(res['episodes'].cpu().numpy(), ref['episodes']), rep
+        for k in range(2):
+            _check(outs[k], co.step(acts_host[k], auto_reset=True), 'replay %d step %d' % (rep, k))
+        assert env.t == co.t == t0 + 10
+    graph.close()
+    env.close()
+
+
+@pytest.mark.parametrize('n_agents,n_envs', [(4, 512), (8, 256), (16, 256), (32, 128)])
+def test_scenario_table_step_equals_plain_rows(monkeypatch, n_agents, n_envs):
+    """The packed single step with and without the scenario table (MAPF_SCEN_TABLE=0), 5 scenarios, goals reachable so
+    that episodes end and auto-reset takes the start rows from the table: both against the C oracle, and the library
+    must report the intended kernel instance."""
+    rs = np.random.RandomState(100 + n_agents)
+    lines = [''.join('@' if rs.rand() < 0.08 else '.' for _ in range(12)) for _ in range(12)]
+    grid = MapfGrid(lines)
+    valid, _, nbr = grid.tables()
+    V = len(valid)
+    scen_start = np.argsort(rs.rand(5, V), axis=1)[:, :n_agents].astype(np.uint16)
+    scen_goal = scen_start.copy()
+    for s in range(5):                               # goals one move away from the starts: episodes end quickly
+        for i in range(n_agents):
+            scen_goal[s, i] = nbr[scen_start[s, i]][1 + (s + i) % 4]
+    which = rs.randint(0, 5, n_envs)
+    start, goal = np.ascontiguousarray(scen_start[which]), np.ascontiguousarray(scen_goal[which])
+    for use_table in (True, False):
+        if use_table:
+            monkeypatch.delenv('MAPF_SCEN_TABLE', raising=False)
+        else:
+            monkeypatch.setenv('MAPF_SCEN_TABLE', '0')
+        env = VecMapfEnv(grid, n_agents, None, None, 0.1, *R, OptimizationCriteria.SoC, seed=5, start_local=start, goal_local=goal)
+        co = c_oracle.COracle(nbr, n_agents, start, goal, 0.1, *R, mo.SOC, seed=5)
+        n_done = 0
+        for t in range(24):
+            acts = ((np.arange(n_envs)[:, None] + np.arange(n_agents)[None, :] + t + which[:, None]) % 5).astype(np.uint8)
+            acts[t % 3::3] = ((1 + (which[t % 3::3, None] + np.arange(n_agents)[None, :]) % 4)).astype(np.uint8)   # head for the goals
+            local, reward, done, info = env.step(acts, auto_reset=(t % 8 != 7))
+            ref = co.step(acts, auto_reset=(t % 8 != 7))
+            assert np.array_equal(local, ref['local']) and np.array_equal(_bits(reward), _bits(ref['reward'])), (use_table, t)
+            assert np.array_equal(_bits(info['prob']), _bits(ref['prob'])) and np.array_equal(done, ref['done']), (use_table, t)
+            assert np.array_equal(info['collision'], ref['collision']) and np.array_equal(info['was_terminal'], ref['was_terminal']), (use_table, t)
+            assert np.array_equal(env.get_state()[0], co.state), (use_table, t)
+            n_done += int(done.sum())
+        name = env.last_kernel('step')
+        assert name.startswith('lq_step_kernel') and (',SCEN>' in name) == use_table, name
+        assert n_done > 0
+        env.close()
+
+
+def test_recording_is_refused_where_it_cannot_work():
+    grid = MapfGrid(['....', '....'])
+    kw = dict(start_local=np.array([[0, 5]], np.uint16).repeat(64, 0), goal_local=np.array([[7, 2]], np.uint16).repeat(64, 0))
+    host = VecMapfEnv(grid, 2, None, None, 0.2, -1.0, 1.0, -1.0, OptimizationCriteria.SoC, **kw)
+    with pytest.raises(nat.MapfNativeError) as err:
+        host.graph_begin()                           # host-pointer calls wait for the stream: nothing to record
+    assert 'MAPF_FLAG_DEVICE_PTRS' in str(err.value)
+    host.close()
+    dev = VecMapfEnv(grid, 2, None, None, 0.2, -1.0, 1.0, -1.0, OptimizationCriteria.SoC, device_arrays=True, **kw)
+    with pytest.raises(nat.MapfNativeError):
+        dev.graph_end()                              # not recording
+    dev.graph_begin()
+    with pytest.raises(nat.MapfNativeError):
+        dev.graph_begin()
+    with pytest.raises(nat.MapfNativeError):
+        dev.set_state(None, t=5)
+    g = dev.graph_end()                              # an empty recording is a valid (empty) graph
+    assert g.steps == 0
+    g.launch(3)
+    dev.sync()
+    assert dev.t == 0
+    g.close()
+    dev.close()

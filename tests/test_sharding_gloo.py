@@ -53,6 +53,32 @@ def test_two_rank_sharding_and_gather(tmp_path):
     assert np.array_equal(shards, start_all)                                    # slices tile the global workload
 
 
+def _uneven_worker(rank, world, port, n_total, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    counts = [sharding.split_evenly(n_total, r, world)[1] for r in range(world)]
+    offset, count = sharding.split_evenly(n_total, rank, world)
+    local = torch.arange(offset, offset + count, dtype=torch.float64) * 0.25
+    gathered = sharding.gather_returns(local, counts=counts)
+    np.save(os.path.join(out_dir, 'u%d.npy' % rank), gathered.numpy())
+    try:
+        sharding.gather_returns(local, counts=[count + 1] * world)
+    except ValueError:
+        np.save(os.path.join(out_dir, 'e%d.npy' % rank), np.ones(1))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_of_unequal_shards(tmp_path):
+    """A population that does not divide over the ranks (bench.py --config c4 --gpus 3, ...): shards are padded for
+    the collective and cut back, the result is ordered by global env id."""
+    world, n_total = 3, 100                                                     # shards of 34, 33, 33
+    mp.spawn(_uneven_worker, args=(world, _free_port(), n_total, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / ('u%d.npy' % r)), np.arange(n_total) * 0.25)
+        assert (tmp_path / ('e%d.npy' % r)).exists()                            # counts that do not fit are refused
+
+
 def test_split_evenly_covers_every_env_once():
     for n, world in ((262144, 8), (131072, 8), (10, 4), (7, 8), (0, 3)):
         spans = [sharding.split_evenly(n, r, world) for r in range(world)]
