@@ -80,7 +80,7 @@ void note_kernel(const char *fmt, ...) {
 
 struct mapf_handle_s {
     int device = 0;
-    std::string last_step_kernel, last_rollout_kernel;
+    std::string last_step_kernel, last_rollout_kernel, last_transitions_kernel;
     uint32_t V = 0, A = 0, flags = 0;
     uint64_t E = 0, env_id_offset = 0, t = 0;
     mapf::EnvConsts c{};
@@ -469,6 +469,7 @@ int mapf_sync(mapf_handle_t h) {
 
 const char *mapf_last_kernel(mapf_handle_t h, int which) {
     if (!h) return "";
+    if (which == MAPF_KERNEL_TRANSITIONS) return h->last_transitions_kernel.c_str();
     return which == MAPF_KERNEL_ROLLOUT ? h->last_rollout_kernel.c_str() : h->last_step_kernel.c_str();
 }
 
@@ -753,6 +754,7 @@ int mapf_transitions_window(mapf_handle_t h, uint64_t n_queries, const uint16_t 
     if (int rc = stage_out(h, h->q_done, out_done, NM, &a.out_done, "out_done")) return rc;
     if (int rc = stage_out(h, h->q_coll, out_collision, NM, &a.out_collision, "out_collision")) return rc;
     HIP_TRY(mapf::launch_transitions(a, h->stream));
+    if (h->last_transitions_kernel != g_noted_kernel) h->last_transitions_kernel = g_noted_kernel;
     if (int rc = fetch_out(h, a.out_count, out_count, N)) return rc;
     if (int rc = fetch_out(h, a.out_next, out_next, NM * h->A)) return rc;
     if (int rc = fetch_out(h, a.out_prob, out_prob, NM)) return rc;

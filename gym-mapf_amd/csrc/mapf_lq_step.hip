@@ -15,51 +15,95 @@ namespace mapf {
 
 namespace {
 
+// The slip-stream call(s) of a lane as a state that can be advanced a few rounds at a time, so that the rounds fill
+// the two memory waits of the step (first loads, then table gathers) instead of running in one piece before the gathers
+// are even issued.  NS = 1 or 2 calls in lockstep (same key, counters differ in the last word).
+template <int NS>
+struct PhiloxRounds {
+    uint32_t c[NS][4], k0, k1;
+    template <int R>
+    __device__ __forceinline__ void run() {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            uint64_t p0[NS], p1[NS];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) { p0[s] = uint64_t(0xD2511F53u) * c[s][0]; p1[s] = uint64_t(0xCD9E8D57u) * c[s][2]; }
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                c[s][0] = __builtin_amdgcn_bitop3_b32(uint32_t(p1[s] >> 32), c[s][1], k0, 0x96);
+                c[s][1] = uint32_t(p1[s]);
+                c[s][2] = __builtin_amdgcn_bitop3_b32(uint32_t(p0[s] >> 32), c[s][3], k1, 0x96);
+                c[s][3] = uint32_t(p0[s]);
+            }
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+            asm volatile("" : "+s"(k0), "+s"(k1));   // (see philox4x32_10: keeps the key schedule out of 20 SGPRs)
+        }
+    }
+};
+
 // SCEN: the env's start / goal rows come from the handle's scenario table (StepArgs::scen) -- one byte per env and two
 // small gathers that hit in L1 / L2, issued beside the move-table gathers, instead of two A-cell rows from HBM; the
 // start cells are then at hand when the step ends the episode, so the state store needs no branch either.
+//
+// A single step is a chain of memory round trips with ~370 vector instructions between them; what this kernel is
+// written around is the LENGTH of that chain (profiles/r03_single_step_*.txt):
+//   * the pointers of the first loads, the agent count and the block size are LEADING SCALAR ARGUMENTS: this file is
+//     compiled with -amdgpu-kernarg-preload-count, so the command processor delivers them in SGPRs with the wave and the
+//     first loads are issued before any s_load of the argument block has come back (reading blockDim.x would be one
+//     more scalar load in front of the address arithmetic: the block size travels as an argument);
+//   * state, actions and the scenario byte are requested together; the scenario's rows and the move-table rows are the
+//     second trip; the Philox rounds are split over the two waits.
 template <int Q, int K, bool SCEN>
-__global__ void __launch_bounds__(256) lq_step_kernel(const StepArgs p, const uint32_t n_agents) {
+__global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, const uint8_t *const actions, const uint8_t *const scen,
+                                                      const uint16_t *const rows, const MoveEntry *const mv, const uint32_t n_agents,
+                                                      const uint32_t block_threads, const StepArgs p) {
     constexpr int P = K / 2;
     LaneCtx<Q> x;
     x.lane = threadIdx.x & 63u;
     x.g = x.lane & uint32_t(Q - 1);
     x.base = x.lane & ~uint32_t(Q - 1);
-    x.e = ((blockIdx.x * blockDim.x + threadIdx.x) >> 6) * uint32_t(64 / Q) + x.lane / uint32_t(Q);
+    x.e = ((blockIdx.x * block_threads + threadIdx.x) >> 6) * uint32_t(64 / Q) + x.lane / uint32_t(Q);
     x.v0 = x.v1 = true;
     const uint32_t e = x.e;
     const uint32_t lane_cell = e * n_agents + uint32_t(K) * x.g;    // my first agent's element index
     const uint32_t fixed_cell = uint32_t(K) * x.g;                  // ... in a broadcast row
-    const uint64_t env_id = p.env_id_offset + e, t = first_step_index(p);
 
+    // ---- first trip: state, actions, scenario byte (or my cells of the goal row)
     uint32_t c[P], g[P], sc[P];
-    uint32_t scen_row = 0u;
-    if (SCEN) scen_row = uint32_t(*at(p.scen, e)) * 2u * n_agents + fixed_cell;   // my cells of the env's start row; goal row: + A
-    {
-        const Packed<P> cells = Packed<P>::load(at(p.state, lane_cell));
-#pragma unroll
-        for (int i = 0; i < P; ++i) c[i] = cells.v[i];
-    }
-    const uint32_t raw = K == 4 ? *reinterpret_cast<const uint32_t *>(at(p.actions, lane_cell))
-                                : uint32_t(*reinterpret_cast<const uint16_t *>(at(p.actions, lane_cell)));
-    if (SCEN) {
-        const Packed<P> gl = Packed<P>::load(at(p.scen_rows, scen_row + n_agents)), sl = Packed<P>::load(at(p.scen_rows, scen_row));
-#pragma unroll
-        for (int i = 0; i < P; ++i) { g[i] = gl.v[i]; sc[i] = sl.v[i]; }
-    } else {
-        const Packed<P> gl = Packed<P>::load(at(p.goal, p.goal_broadcast ? fixed_cell : lane_cell));
-#pragma unroll
-        for (int i = 0; i < P; ++i) { g[i] = gl.v[i]; sc[i] = 0u; }
-    }
-    // the slip call of my pair(s) for steps 4h .. 4h+3 (one call per pair per step: a single step cannot amortise it)
-    Words4 rng[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) rng[i] = Words4{0u, 0u, 0u, 0u};
-    if (p.c.need_rng) {
-        if constexpr (P == 2) slip_words_x2(p.c, env_id, t >> 2, 2u * x.g, 2u * x.g + 1u, rng[0], rng[1]);
-        else rng[0] = slip_words(p.c, env_id, t >> 2, x.g, 0u, 0u);
-    }
+    const Packed<P> cells = Packed<P>::load(at(state, lane_cell));
+    const uint32_t raw = K == 4 ? *reinterpret_cast<const uint32_t *>(at(actions, lane_cell))
+                                : uint32_t(*reinterpret_cast<const uint16_t *>(at(actions, lane_cell)));
+    uint32_t scen_id = 0u;
+    Packed<P> gl{}, sl{};
+    if (SCEN) scen_id = *at(scen, e);
+    else gl = Packed<P>::load(at(rows, p.goal_broadcast ? fixed_cell : lane_cell));      // rows = the goal array
+    __builtin_amdgcn_sched_barrier(0);
 
+    // ---- the slip call of my pair(s) for steps 4h .. 4h+3 (one call per pair per step: a single step cannot amortise
+    // it), first six rounds while the loads are in flight
+    const uint64_t env_id = p.env_id_offset + e, t = first_step_index(p);
+    PhiloxRounds<P> rng_state;
+    {
+        const uint32_t hi16 = uint32_t((t >> 2) >> 32) & 0xFFFFu;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            rng_state.c[i][0] = uint32_t(env_id); rng_state.c[i][1] = uint32_t(env_id >> 32); rng_state.c[i][2] = uint32_t(t >> 2);
+            rng_state.c[i][3] = hi16 | ((uint32_t(P) * x.g + uint32_t(i)) << 16);   // pair index; rslot = refine = 0 (slip_words)
+        }
+        rng_state.k0 = p.c.seed_lo; rng_state.k1 = p.c.seed_hi;
+    }
+    if (p.c.need_rng) rng_state.template run<6>();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- second trip: the scenario's rows, then the move-table rows of my agents
+    if (SCEN) {
+        const uint32_t scen_row = scen_id * 2u * n_agents + fixed_cell;   // my cells of the env's start row; goal row: + A
+        gl = Packed<P>::load(at(rows, scen_row + n_agents));
+        sl = Packed<P>::load(at(rows, scen_row));
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) c[i] = cells.v[i];
     uint32_t cur[K], act[K], hi[K];
     MoveEntry entry[K];
 #pragma unroll
@@ -67,8 +111,17 @@ __global__ void __launch_bounds__(256) lq_step_kernel(const StepArgs p, const ui
         cur[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu;
         const uint32_t byte = (raw >> (8 * k)) & 0xFFu;
         act[k] = byte > 4u ? 0u : byte;
-        entry[k] = move_entry<true>(p.mv, p.c.n_cells, cur[k], act[k]);
+        entry[k] = move_entry<true>(mv, p.c.n_cells, cur[k], act[k]);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    if (p.c.need_rng) rng_state.template run<4>();
+    Words4 rng[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+        rng[i] = p.c.need_rng ? Words4{rng_state.c[i][0], rng_state.c[i][1], rng_state.c[i][2], rng_state.c[i][3]} : Words4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < P; ++i) { g[i] = gl.v[i]; sc[i] = sl.v[i]; }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const uint32_t word = step_word(rng[i], t);
@@ -144,11 +197,11 @@ __global__ void __launch_bounds__(256) lq_step_kernel(const StepArgs p, const ui
         Packed<P> keep;
 #pragma unroll
         for (int i = 0; i < P; ++i) keep.v[i] = back ? sc[i] : n[i];
-        keep.store(at(p.state, lane_cell));
+        keep.store(at(state, lane_cell));
     } else if (p.auto_reset && done) {
-        Packed<P>::load(at(p.start, p.start_broadcast ? fixed_cell : lane_cell)).store(at(p.state, lane_cell));
+        Packed<P>::load(at(p.start, p.start_broadcast ? fixed_cell : lane_cell)).store(at(state, lane_cell));
     } else if (!was_terminal) {
-        out.store(at(p.state, lane_cell));
+        out.store(at(state, lane_cell));
     }
     signal_step_done(p.done_flag, p.done_seq);
 }
@@ -176,8 +229,10 @@ bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning 
                 scen ? ", start / goal rows from the scenario table" : "");
 #define MAPF_LQ_STEP(QQ, KK)                                                                                   \
     if (Q == QQ && K == KK) {                                                                                  \
-        if (scen) hipLaunchKernelGGL((lq_step_kernel<QQ, KK, true>), dim3(grid), dim3(block), 0, stream, args, A);   \
-        else hipLaunchKernelGGL((lq_step_kernel<QQ, KK, false>), dim3(grid), dim3(block), 0, stream, args, A);       \
+        if (scen) hipLaunchKernelGGL((lq_step_kernel<QQ, KK, true>), dim3(grid), dim3(block), 0, stream, args.state, args.actions,  \
+                                     args.scen, args.scen_rows, args.mv, A, block, args);                                          \
+        else hipLaunchKernelGGL((lq_step_kernel<QQ, KK, false>), dim3(grid), dim3(block), 0, stream, args.state, args.actions,    \
+                                static_cast<const uint8_t *>(nullptr), args.goal, args.mv, A, block, args);                        \
         *err = hipGetLastError();                                                                              \
         return true;                                                                                           \
     }

@@ -206,8 +206,9 @@ hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream) {
     const uint64_t grid64 = (threads + 255) / 256;
     if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const dim3 grid{unsigned(grid64)}, block{256};
-    note_kernel("transitions_kernel<%d agents> %u lanes x %u rows per group, %u groups per query", args.n_agents, lanes, walks,
-                chunks_per_query);
+    const int inst = args.n_agents <= 4 ? 4 : (args.n_agents <= 8 ? 8 : int(args.n_agents));
+    note_kernel("transitions_kernel<%d%s> %u agents, %u lanes x %u rows per group, %u groups per query", inst, inst > 8 ? ",EXACT" : "",
+                args.n_agents, lanes, walks, chunks_per_query);
     if (args.n_agents <= 4) hipLaunchKernelGGL(transitions_kernel<4>, grid, block, 0, stream, args, lanes_log2, chunk, chunks_per_query);
     else if (args.n_agents <= 8) hipLaunchKernelGGL(transitions_kernel<8>, grid, block, 0, stream, args, lanes_log2, chunk, chunks_per_query);
     else switch (args.n_agents) {

@@ -17,7 +17,7 @@ MAPF_FLAG_THREAD_PER_ENV, MAPF_FLAG_LANE_GROUP = 0x10, 0x20
 MAPF_TPE_MAX_AGENTS = 16
 MAPF_POLICY_RANDOM, MAPF_POLICY_GREEDY = 0, 1
 MAPF_STEP_AUTO_RESET = 0x1
-MAPF_KERNEL_STEP, MAPF_KERNEL_ROLLOUT = 0, 1
+MAPF_KERNEL_STEP, MAPF_KERNEL_ROLLOUT, MAPF_KERNEL_TRANSITIONS = 0, 1, 2
 
 
 class MapfNativeError(RuntimeError):

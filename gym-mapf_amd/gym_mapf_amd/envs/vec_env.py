@@ -419,7 +419,7 @@ class VecMapfEnv:
     def last_kernel(self, which='rollout'):
         """Name of the kernel instance that took this env's last ``step`` / ``rollout`` launch (the library picks
         the lane layout from A, E and the table size); '' before the first launch."""
-        code = {'step': nat.MAPF_KERNEL_STEP, 'rollout': nat.MAPF_KERNEL_ROLLOUT}[which]
+        code = {'step': nat.MAPF_KERNEL_STEP, 'rollout': nat.MAPF_KERNEL_ROLLOUT, 'transitions': nat.MAPF_KERNEL_TRANSITIONS}[which]
         return self._lib.mapf_last_kernel(self._h, code).decode()
 
     @property

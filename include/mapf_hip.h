@@ -247,13 +247,14 @@ int mapf_timer_end(mapf_handle_t h, double *out_ms);
 /* The hipStream_t the handle enqueues on (for interop with other libraries). */
 int mapf_get_stream(mapf_handle_t h, void **out_stream);
 
-/* Which kernel instance took the handle's most recent mapf_step (MAPF_KERNEL_STEP) or mapf_rollout
- * (MAPF_KERNEL_ROLLOUT) launch, e.g. "lq_rollout_kernel<Q=2,RECORD,STREAM> block=512": the library chooses the
+/* Which kernel instance took the handle's most recent mapf_step (MAPF_KERNEL_STEP), mapf_rollout
+ * (MAPF_KERNEL_ROLLOUT) or mapf_transitions (MAPF_KERNEL_TRANSITIONS) launch, e.g. "lq_rollout_kernel<Q=2,RECORD,STREAM> block=512": the library chooses the
  * lane layout from A, E and the table size, so measurements label themselves with what actually ran (no reference
  * counterpart: the reference has one code path, mapf_env.py:237-266).  "" before the first launch.  The string is
  * owned by the handle and valid until its next launch of that kind. */
 #define MAPF_KERNEL_STEP    0
 #define MAPF_KERNEL_ROLLOUT 1
+#define MAPF_KERNEL_TRANSITIONS 2   /* mapf_transitions / mapf_transitions_window */
 const char *mapf_last_kernel(mapf_handle_t h, int which);
 
 int mapf_device_count(int *out_count);

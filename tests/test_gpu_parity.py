@@ -699,6 +699,57 @@ def test_transitions_of_large_teams_come_in_windows():
     menv.close()
 
 
+@pytest.mark.parametrize('n_agents', list(range(7, 17)))
+def test_every_transitions_kernel_instance_against_oracle(n_agents):
+    """mapf_transitions dispatches transitions_kernel<8> for 5..8 agents and an exact-size instance for each of 9..16
+    (mapf_transitions.hip launch_transitions): every one of them against the pinned Python oracle's enumeration
+    (reference mapf_env.py:448-478), both criteria, per-query goals, several window sizes and offsets.  At most seven
+    agents of a query move (the others STAY: one-entry lists), which keeps the oracle's list at <= 3^7 branches while
+    every agent still takes part in the pair tests, the goal test and the SoC living reward."""
+    A = n_agents
+    rs = np.random.RandomState(700 + A)
+    lines = ['......', '.@....', '....@.', '......', '..@...', '......']
+    grid = MapfGrid(lines)
+    valid = grid.tables()[0]
+    V, E, N = len(valid), 3, 6
+    start = np.stack([rs.choice(V, A, replace=False) for _ in range(E)]).astype(np.uint16)
+    goal = np.stack([rs.choice(V, A, replace=False) for _ in range(E)]).astype(np.uint16)
+    criteria = 'SoC' if A % 2 else 'Makespan'
+    env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, CRIT[criteria], start_local=start, goal_local=goal)
+    oracles = [mo.OracleEnv(lines, A, [valid[c] for c in start[e]], [valid[c] for c in goal[e]], 0.2, -1000.0, 100.0, -1.0,
+                            OCRIT[criteria]) for e in range(E)]
+    env_index = (np.arange(N) % E).astype(np.uint32)
+    local = np.stack([rs.choice(V, A, replace=False) for _ in range(N)]).astype(np.uint16)
+    local[1] = goal[env_index[1]]                                     # terminal: every agent on its goal
+    local[2, 1] = local[2, 0]                                         # terminal: two agents share a cell
+    local[3] = goal[env_index[3]]
+    local[3, A - 1] = grid.tables()[2][goal[env_index[3], A - 1]][1]  # one move short of the goal branch (if not blocked)
+    acts = np.zeros((N, A), np.uint8)
+    for q in range(N):
+        movers = rs.choice(A, min(A, 7), replace=False)
+        acts[q, movers] = rs.randint(1, 5, size=len(movers))
+    acts[3] = 0
+    acts[3, A - 1] = 3                                                # DOWN undoes UP
+    exp = [oracles[env_index[q]].transitions(tuple(int(c) for c in local[q]), acts[q].tolist()) for q in range(N)]
+    assert max(len(x) for x in exp) > 300 and len(exp[1]) == 1 and len(exp[2]) == 1
+    longest = max(len(x) for x in exp)
+    for window in (longest, 1000, 257):
+        first = 0
+        while first < longest:
+            res = env.transitions(local, acts, max_branches=window, env_index=env_index, first_branch=first)
+            for q in range(N):
+                assert int(res['count'][q]) == len(exp[q]), (A, q)
+                for b in range(min(window, max(0, len(exp[q]) - first))):
+                    (ep, ec), enxt, er, ed = exp[q][first + b]
+                    assert res['next'][q, b].tolist() == list(enxt), (A, window, q, first + b)
+                    assert _bits(res['prob'][q, b]) == _bits(ep) and _bits(res['reward'][q, b]) == _bits(er), (A, window, q, first + b)
+                    assert (bool(res['done'][q, b]), bool(res['collision'][q, b])) == (ed, ec), (A, window, q, first + b)
+            first += window
+    assert sum(1 for x in exp for t in x if t[0][1]) > 0              # collision branches were among them
+    assert env.last_kernel('transitions').startswith('transitions_kernel<8>' if A <= 8 else 'transitions_kernel<%d,EXACT>' % A)
+    env.close()
+
+
 # ----------------------------------------------------------------------- edge cases of the boundary
 def test_empty_batch_and_single_cell_map():
     """E = 0 handles are legal no-ops; a 1-cell map with one agent is terminal from the start (start == goal)."""
