@@ -18,6 +18,17 @@ namespace {
 // The slip-stream call(s) of a lane as a state that can be advanced a few rounds at a time, so that the rounds fill
 // the two memory waits of the step (first loads, then table gathers) instead of running in one piece before the gathers
 // are even issued.  NS = 1 or 2 calls in lockstep (same key, counters differ in the last word).
+// Diagnostic build only (make step_stamps; never shipped): every wave records when it passed the stages of the step --
+// s_memrealtime (100 MHz, one clock for the whole chip) at entry and exit, s_memtime (shader cycles) deltas in between,
+// each stage stamp behind a full wait for the memory operations issued so far -- into the buffer passed as `uniforms`.
+#ifdef MAPF_STEP_STAMPS
+#define STEP_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+        stamp_[i] = t_ - cyc0_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STEP_STAMP(i)
+#endif
+
 template <int NS>
 struct PhiloxRounds {
     uint32_t c[NS][4], k0, k1;
@@ -59,6 +70,10 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
                                                       const uint16_t *const rows, const MoveEntry *const mv, const uint32_t n_agents,
                                                       const uint32_t block_threads, const StepArgs p) {
     constexpr int P = K / 2;
+#ifdef MAPF_STEP_STAMPS
+    unsigned long long stamp_[8] = {}, real0_, cyc0_;
+    asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0_), "=s"(cyc0_) :: "memory");
+#endif
     LaneCtx<Q> x;
     x.lane = threadIdx.x & 63u;
     x.g = x.lane & uint32_t(Q - 1);
@@ -93,8 +108,15 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
         }
         rng_state.k0 = p.c.seed_lo; rng_state.k1 = p.c.seed_hi;
     }
+#ifdef MAPF_STEP_STAMPS
+    { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_[0] = t_ - cyc0_; __builtin_amdgcn_sched_barrier(0); }   // argument block arrived
+#endif
     if (p.c.need_rng) rng_state.template run<6>();
     __builtin_amdgcn_sched_barrier(0);
+#ifdef MAPF_STEP_STAMPS
+    { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_[1] = t_ - cyc0_; __builtin_amdgcn_sched_barrier(0); }   // six rounds done
+    STEP_STAMP(2);   // first loads arrived
+#endif
 
     // ---- second trip: the scenario's rows, then the move-table rows of my agents
     if (SCEN) {
@@ -115,6 +137,10 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
     }
     __builtin_amdgcn_sched_barrier(0);
     if (p.c.need_rng) rng_state.template run<4>();
+#ifdef MAPF_STEP_STAMPS
+    { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_[3] = t_ - cyc0_; __builtin_amdgcn_sched_barrier(0); }   // gathers issued, four rounds done
+    STEP_STAMP(4);   // gathers arrived
+#endif
     Words4 rng[P];
 #pragma unroll
     for (int i = 0; i < P; ++i)
@@ -184,6 +210,10 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
     Packed<P> out;
 #pragma unroll
     for (int i = 0; i < P; ++i) out.v[i] = n[i];
+#ifdef MAPF_STEP_STAMPS
+    asm volatile("" :: "v"(reward), "v"(prob), "v"(out.v[0]));
+    STEP_STAMP(5);   // everything computed
+#endif
     if (p.out_local) out.store(at(p.out_local, lane_cell));
     if (x.g == uint32_t(Q - 1) && p.out_prob) *at(p.out_prob, e) = was_terminal ? 0.0 : prob;
     if (x.g == 0u) {
@@ -203,6 +233,25 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
     } else if (!was_terminal) {
         out.store(at(state, lane_cell));
     }
+#ifdef MAPF_STEP_STAMPS
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long t6_, t7_, real1_;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t6_) :: "memory");                          // stores issued
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(t7_), "=s"(real1_) :: "memory");   // stores acknowledged
+        uint32_t hw_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        uint32_t xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        if (x.lane == 0u && p.uniforms) {
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(const_cast<double *>(p.uniforms)) +
+                                      uint64_t((blockIdx.x * block_threads + threadIdx.x) >> 6) * 12u;
+            dst[0] = real0_; dst[1] = real1_;
+            for (int i = 0; i < 6; ++i) dst[2 + i] = stamp_[i];
+            dst[8] = t6_ - cyc0_; dst[9] = t7_ - cyc0_; dst[10] = hw_id; dst[11] = xcc_id;
+        }
+    }
+#endif
     signal_step_done(p.done_flag, p.done_seq);
 }
 
@@ -210,7 +259,10 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
 
 // true when the packed layout took the launch (*err = its status); false = not applicable, use lg_step_kernel
 bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err) {
-    if (!tune.quad_lanes || args.uniforms != nullptr) return false;
+#ifndef MAPF_STEP_STAMPS   // (the diagnostic build receives its stamp buffer through `uniforms`)
+    if (args.uniforms != nullptr) return false;
+#endif
+    if (!tune.quad_lanes) return false;
     int K = 0;
     if (tune.force_k != 2 && n_agents % 4 == 0) K = 4;
     else if (tune.force_k != 4 && n_agents % 2 == 0 && n_agents >= 4) K = 2;

@@ -538,6 +538,18 @@ def main():
                          lines, lambda j, env_id, st=st, gl=gl: (tuple(map(tuple, st[env_id].tolist())), tuple(map(tuple, gl[env_id].tolist()))),
                          A, fp, crit, list(range(n_env)), T, auto, None, action_fn=towards)
 
+    # the reference's LARGE maps (the only scenario that constructs at 32 agents on maze-128-128-10 is
+    # scen 18; Berlin_1_256 -- the map the reference's own grid test opens, mapf_grid_tests.py:22-32 -- constructs at
+    # 4 agents for scen 11 only and at 2 agents for eight scen ids): 14818 and 47540 free cells, i.e. move tables far
+    # beyond the LDS budget -- the global-table kernels
+    run_trajectories('maze128_a32_slip02', ref_map_lines('maze-128-128-10'), scen_locs('maze-128-128-10', [18], 32), 32, 0.2,
+                     'Makespan', list(range(6)), 96, True, 'maze-128-128-10')
+    run_trajectories('berlin256_a4_slip02', ref_map_lines('Berlin_1_256'), scen_locs('Berlin_1_256', [11], 4), 4, 0.2,
+                     'SoC', list(range(6)), 96, True, 'Berlin_1_256')
+    run_trajectories('berlin256_a2_slip01', ref_map_lines('Berlin_1_256'),
+                     scen_locs('Berlin_1_256', [2, 4, 8, 11, 14, 18, 22, 24], 2), 2, 0.1, 'Makespan', list(range(8)), 64, True,
+                     'Berlin_1_256')
+
     with open(os.path.join(HERE, 'generation_info.json'), 'w') as f:
         json.dump(info, f, indent=1)
 
