@@ -176,6 +176,26 @@ __device__ __forceinline__ void slip_move_hi_members(const EnvConsts &c, const M
     q = __dadd_rn(__dadd_rn((mem & 1u) ? c.p_cand[0] : 0.0, (mem & 2u) ? c.p_cand[1] : 0.0), (mem & 4u) ? c.p_cand[2] : 0.0);
 }
 
+// Exact sampling with the full 53-bit mantissa and NO memory access (the single step's answer to a 16-bit tie: the wave
+// that takes this path is the launch's straggler, so it must not add a dependent load): the list's probabilities are
+// rebuilt from the slots' members as in slip_move_hi_members, the cumulative sums are formed in list order like the
+// host's (build_slip_table: run = q0, run + q1, ...), and u = mant * 2^-53 is exact -- so `cum[k] > u` is literally
+// categorical_sample's comparison (and equals the rows' `mant < ceil(cum[k] * 2^53)`).  An absent slot adds 0.0 and
+// repeats the comparison of the slot before it, which cannot turn a False into the first True.
+__device__ __forceinline__ void slip_move_exact_members(const EnvConsts &c, const MoveEntry &entry, uint64_t mant, uint32_t &next, double &q) {
+    const double u = __dmul_rn(__ull2double_rn(mant), 0x1p-53);
+    double qs[3], cum[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const uint32_t mem = (entry.y >> (19u + 3u * uint32_t(k))) & 7u;
+        qs[k] = __dadd_rn(__dadd_rn((mem & 1u) ? c.p_cand[0] : 0.0, (mem & 2u) ? c.p_cand[1] : 0.0), (mem & 4u) ? c.p_cand[2] : 0.0);
+        cum[k] = k == 0 ? qs[0] : __dadd_rn(cum[k - 1], qs[k]);
+    }
+    const uint32_t idx = cum[0] > u ? 0u : (cum[1] > u ? 1u : (cum[2] > u ? 2u : 0u));
+    next = entry_cell(entry, idx);
+    q = idx == 0u ? qs[0] : (idx == 1u ? qs[1] : qs[2]);
+}
+
 // Slip stream (oracle/philox.py): one call with rslot = refine = 0 yields the four words that serve agents
 // (2*pair, 2*pair+1) at steps 4h .. 4h+3 -- word (t & 3): low half = top 16 bits of agent 2*pair's uniform, high
 // half = agent 2*pair+1's.  The low 37 bits of a slot's uniform come from a separate call (refine = 1, rslot =

@@ -57,23 +57,37 @@ struct PhiloxRounds {
 // small gathers that hit in L1 / L2, issued beside the move-table gathers, instead of two A-cell rows from HBM; the
 // start cells are then at hand when the step ends the episode, so the state store needs no branch either.
 //
-// A single step is a chain of memory round trips with ~370 vector instructions between them; what this kernel is
-// written around is the LENGTH of that chain (profiles/r03_single_step_*.txt):
-//   * the pointers of the first loads, the agent count and the block size are LEADING SCALAR ARGUMENTS: this file is
-//     compiled with -amdgpu-kernarg-preload-count, so the command processor delivers them in SGPRs with the wave and the
-//     first loads are issued before any s_load of the argument block has come back (reading blockDim.x would be one
-//     more scalar load in front of the address arithmetic: the block size travels as an argument);
-//   * state, actions and the scenario byte are requested together; the scenario's rows and the move-table rows are the
-//     second trip; the Philox rounds are split over the two waits.
+// A single step is a chain of memory round trips with vector work between them; the kernel is written around the
+// LENGTH of that chain and the instruction count of its last link (profiles/r03_step_stamps_*.txt: of a 4.1 us launch
+// at 65536 envs ~1 us is dispatch / completion overhead, the waves live 2.2 us, and the wave that finishes last is the
+// launch's duration):
+//   * what the first instructions need travels as LEADING SCALAR ARGUMENTS (14 dwords): this file is compiled with
+//     -amdgpu-kernarg-preload-count, so the command processor delivers them in SGPRs with the wave: the pointers of the
+//     first loads, the agent count and the block size (reading blockDim.x would be a scalar load in front of the address
+//     arithmetic) let those loads go out before any s_load of the argument block has come back; the step index's
+//     device-side base (StepArgs::t_dev) is requested at once as well;
+//   * state, actions, the scenario byte and (first lanes of the block) the slip rows are requested together; the
+//     scenario's rows and the move-table rows are the second trip; the Philox rounds are split over the two waits;
+//   * the slip rows and the 16-row outcome table live in 1 KB of LDS (written while the table gathers are in flight, one
+//     barrier), so sampling and the per-env outcome are the fused rollout's code: packed 16-bit threshold compares
+//     (sample_slot_packed), one integer outcome code per env, reward / flags read from the code's LDS row;
+//   * a 16-bit tie is resolved by register arithmetic alone (slip_move_exact_members), only for the slots that tie.
+constexpr uint32_t kStepSlipAt = 0, kStepOutcomeAt = sizeof(SlipRow) * 8, kStepLds = kStepOutcomeAt + sizeof(OutcomeRow) * 16;
+
 template <int Q, int K, bool SCEN>
 __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, const uint8_t *const actions, const uint8_t *const scen,
-                                                      const uint16_t *const rows, const MoveEntry *const mv, const uint32_t n_agents,
-                                                      const uint32_t block_threads, const StepArgs p) {
+                                                      const SlipRow *const slip_rows, const uint64_t *const t_dev,
+                                                      const uint32_t agents_block, const uint32_t t_lo, const uint32_t seed_lo,
+                                                      const uint32_t seed_hi, const StepArgs p) {
     constexpr int P = K / 2;
 #ifdef MAPF_STEP_STAMPS
     unsigned long long stamp_[8] = {}, real0_, cyc0_;
     asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0_), "=s"(cyc0_) :: "memory");
 #endif
+    // the kernel's only LDS object, so it sits at LDS address 0 (lds_at() names LDS locations by their byte address)
+    __shared__ __attribute__((aligned(16))) unsigned char lds_image[kStepLds];
+    if (uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lds_image)) != 0u) __builtin_trap();
+    const uint32_t n_agents = agents_block & 0xFFu, block_threads = agents_block >> 8;
     LaneCtx<Q> x;
     x.lane = threadIdx.x & 63u;
     x.g = x.lane & uint32_t(Q - 1);
@@ -84,7 +98,8 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
     const uint32_t lane_cell = e * n_agents + uint32_t(K) * x.g;    // my first agent's element index
     const uint32_t fixed_cell = uint32_t(K) * x.g;                  // ... in a broadcast row
 
-    // ---- first trip: state, actions, scenario byte (or my cells of the goal row)
+    // ---- first trip: state, actions, scenario byte (or my cells of the goal row); the block's first 64 lanes also fetch
+    // the slip rows (96 eight-byte words) for the LDS copy
     uint32_t c[P], g[P], sc[P];
     const Packed<P> cells = Packed<P>::load(at(state, lane_cell));
     const uint32_t raw = K == 4 ? *reinterpret_cast<const uint32_t *>(at(actions, lane_cell))
@@ -92,12 +107,22 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
     uint32_t scen_id = 0u;
     Packed<P> gl{}, sl{};
     if (SCEN) scen_id = *at(scen, e);
-    else gl = Packed<P>::load(at(rows, p.goal_broadcast ? fixed_cell : lane_cell));      // rows = the goal array
+    uint64_t slip_w0 = 0u, slip_w1 = 0u;
+    const bool stager = threadIdx.x < 64u;
+    if (stager) {
+        const uint64_t *src = reinterpret_cast<const uint64_t *>(slip_rows);
+        slip_w0 = src[threadIdx.x];
+        if (threadIdx.x < 32u) slip_w1 = src[64u + threadIdx.x];
+    }
+    const uint64_t t_base = t_dev ? *t_dev : 0ull;
     __builtin_amdgcn_sched_barrier(0);
+    if (!SCEN) gl = Packed<P>::load(at(p.goal, p.goal_broadcast ? fixed_cell : lane_cell));
 
     // ---- the slip call of my pair(s) for steps 4h .. 4h+3 (one call per pair per step: a single step cannot amortise
     // it), first six rounds while the loads are in flight
-    const uint64_t env_id = p.env_id_offset + e, t = first_step_index(p);
+    // (p.t's low word is preloaded; the high word -- zero for the first 2^32 steps of a handle -- comes with the block)
+    const uint64_t env_id = p.env_id_offset + e;
+    const uint64_t t = ((p.t & 0xFFFFFFFF00000000ull) | t_lo) + t_base;
     PhiloxRounds<P> rng_state;
     {
         const uint32_t hi16 = uint32_t((t >> 2) >> 32) & 0xFFFFu;
@@ -106,7 +131,7 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
             rng_state.c[i][0] = uint32_t(env_id); rng_state.c[i][1] = uint32_t(env_id >> 32); rng_state.c[i][2] = uint32_t(t >> 2);
             rng_state.c[i][3] = hi16 | ((uint32_t(P) * x.g + uint32_t(i)) << 16);   // pair index; rslot = refine = 0 (slip_words)
         }
-        rng_state.k0 = p.c.seed_lo; rng_state.k1 = p.c.seed_hi;
+        rng_state.k0 = seed_lo; rng_state.k1 = seed_hi;
     }
 #ifdef MAPF_STEP_STAMPS
     { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_[0] = t_ - cyc0_; __builtin_amdgcn_sched_barrier(0); }   // argument block arrived
@@ -121,74 +146,94 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
     // ---- second trip: the scenario's rows, then the move-table rows of my agents
     if (SCEN) {
         const uint32_t scen_row = scen_id * 2u * n_agents + fixed_cell;   // my cells of the env's start row; goal row: + A
-        gl = Packed<P>::load(at(rows, scen_row + n_agents));
-        sl = Packed<P>::load(at(rows, scen_row));
+        gl = Packed<P>::load(at(p.scen_rows, scen_row + n_agents));
+        sl = Packed<P>::load(at(p.scen_rows, scen_row));
     }
 #pragma unroll
     for (int i = 0; i < P; ++i) c[i] = cells.v[i];
-    uint32_t cur[K], act[K], hi[K];
+    uint32_t cur[K], act[K];
     MoveEntry entry[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         cur[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu;
         const uint32_t byte = (raw >> (8 * k)) & 0xFFu;
         act[k] = byte > 4u ? 0u : byte;
-        entry[k] = move_entry<true>(mv, p.c.n_cells, cur[k], act[k]);
+        entry[k] = move_entry<true>(p.mv, p.c.n_cells, cur[k], act[k]);
     }
+    // the LDS image, while the gathers are in flight: slip rows (fetched with the first trip) and the outcome table
+    if (stager) {
+        uint64_t *dst = reinterpret_cast<uint64_t *>(lds_image + kStepSlipAt);
+        dst[threadIdx.x] = slip_w0;
+        if (threadIdx.x < 32u) dst[64u + threadIdx.x] = slip_w1;
+    }
+    stage_outcome_table(p.c, reinterpret_cast<OutcomeRow *>(lds_image + kStepOutcomeAt));
     __builtin_amdgcn_sched_barrier(0);
     if (p.c.need_rng) rng_state.template run<4>();
+    __syncthreads();
 #ifdef MAPF_STEP_STAMPS
     { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_[3] = t_ - cyc0_; __builtin_amdgcn_sched_barrier(0); }   // gathers issued, four rounds done
     STEP_STAMP(4);   // gathers arrived
 #endif
-    Words4 rng[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i)
-        rng[i] = p.c.need_rng ? Words4{rng_state.c[i][0], rng_state.c[i][1], rng_state.c[i][2], rng_state.c[i][3]} : Words4{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < P; ++i) { g[i] = gl.v[i]; sc[i] = sl.v[i]; }
     __builtin_amdgcn_sched_barrier(0);
+
+    // ---- sampling (the fused rollout's packed form): both threshold compares of an agent in one saturating packed
+    // subtract, the slot's probability address and cell selector from one dot product each
+    uint32_t pk_eights = 0x00080008u, pk_steps = 0x02020202u, sel_base = 0x0C0C0504u;
+    asm volatile("" : "+v"(pk_eights), "+v"(pk_steps), "+v"(sel_base));
+    double q[K];
+    uint32_t n[P], word[P], d[K], tie_all = 0u;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        const uint32_t word = step_word(rng[i], t);
-        hi[2 * i] = word & 0xFFFFu;
-        hi[2 * i + 1] = word >> 16;
+        word[i] = p.c.need_rng ? step_word(Words4{rng_state.c[i][0], rng_state.c[i][1], rng_state.c[i][2], rng_state.c[i][3]}, t) : 0u;
+        const uint32_t biased = word[i] ^ kHalfBias;                 // low half: agent 2i's uniform, high half: agent 2i+1's
+        uint32_t q_at[2], cell[2];
+        MoveEntry e0 = entry[2 * i], e1 = entry[2 * i + 1];
+        e0.z ^= kHalfBias; e1.z ^= kHalfBias;                        // (the rollout's LDS copy of the table carries this bias)
+        d[2 * i] = sample_slot_packed(e0, __builtin_amdgcn_perm(biased, biased, 0x01000100u), pk_eights, pk_steps, sel_base, q_at[0], cell[0]);
+        d[2 * i + 1] = sample_slot_packed(e1, __builtin_amdgcn_perm(biased, biased, 0x03020302u), pk_eights, pk_steps, sel_base, q_at[1], cell[1]);
+        q[2 * i] = lds_at<double>(kStepSlipAt + 16u + q_at[0]);
+        q[2 * i + 1] = lds_at<double>(kStepSlipAt + 16u + q_at[1]);
+        n[i] = cell[0] | (cell[1] << 16);
+        tie_all = i == 0 ? pk_min_u16(d[0], d[1]) : pk_min_u16(tie_all, pk_min_u16(d[2 * i], d[2 * i + 1]));
     }
-    double q[K];
-    uint32_t nx[K], tie_all = 0xFFFFFFFFu;
+    // (without slip the words are zero and every threshold is 65535: no tie can fire)
+    if (__builtin_expect(__any(zero_half(tie_all) != 0u), 0)) {
+        // A top-16-bit tie somewhere in the wave (about one wave in 80 at 8 agents): the agent slots that tie are redone
+        // with all 53 bits.  This wave finishes last, i.e. it IS the launch's duration, so the redo is one Philox call per
+        // tying slot and register arithmetic only (the four calls + three dependent loads of the slip rows this path
+        // once cost kept the slowest wave alive 1.1 us after 90 % of the others had left).
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        uint32_t tie;
-        slip_move_hi_members(p.c, entry[k], hi[k], nx[k], q[k], tie);
-        tie_all = min(tie_all, tie);
+        for (int k = 0; k < K; ++k) {
+            if (__any(zero_half(d[k]) != 0u)) {
+                const uint32_t hi = (k & 1) ? word[k / 2] >> 16 : word[k / 2] & 0xFFFFu;
+                uint32_t nx;
+                slip_move_exact_members(p.c, entry[k], refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi), nx, q[k]);
+                n[k / 2] = (k & 1) ? (n[k / 2] & 0xFFFFu) | (nx << 16) : (n[k / 2] & 0xFFFF0000u) | nx;
+            }
+        }
     }
-    if (__builtin_expect(__any(tie_all == 0u && p.c.need_rng), 0)) {
-        // a top-16-bit tie somewhere in the wave: redo with all 53 bits (the slip rows are read from global memory here)
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-            slip_move<false>(p.slip, entry[k], refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi[k]), 0.0, nx[k], q[k]);
-    }
-    uint32_t n[P];
-#pragma unroll
-    for (int i = 0; i < P; ++i) n[i] = nx[2 * i] | (nx[2 * i + 1] << 16);
 
-    // is_terminal(prev) and the collision tests in one pass over the agent pairs; per-env facts OR-reduced over the group
+    // ---- is_terminal(prev) and the collision tests in one pass over the agent pairs; the per-env facts as ONE integer
+    // code = vertex | swap << 1 | off_goal << 2 | was_terminal << 3 (mapf_env.py:210-223, :225-235, :378-389)
     const PairAcc<true> acc = packed_pair_tests<Q, P, true, true>(x, c, n);
-    uint32_t away_next = 0u, away_prev = 0u;
+    uint32_t away_next = n[0] ^ g[0], away_prev = c[0] ^ g[0];
 #pragma unroll
-    for (int i = 0; i < P; ++i) { away_next |= n[i] ^ g[i]; away_prev |= c[i] ^ g[i]; }
-    uint32_t flags = (PairAcc<true>::hit(acc.vertex) ? 1u : 0u) | (PairAcc<true>::hit(acc.swap) ? 2u : 0u) | (away_next ? 4u : 0u) |
-                     (PairAcc<true>::hit(acc.dup) ? 8u : 0u) | (away_prev ? 16u : 0u);
-    flags = group_reduce<Q, false>(flags, x);
-    const bool was_terminal = (flags & 8u) != 0u || (flags & 16u) == 0u;     // mapf_env.py:210-223
-    const uint32_t f = flags & 7u;
-
-    // total_prob: left-to-right product over agents 0..A-1 (mapf_env.py:257); the total ends in the group's last lane
-    const double prob = packed_prob_product<Q, K>(q);
-
-    // _living_reward (mapf_env.py:436-446), calc_transition_reward_from_local_states (:225-235: collision before goal)
-    double living = p.c.r_living;
+    for (int i = 1; i < P; ++i) { away_next |= n[i] ^ g[i]; away_prev |= c[i] ^ g[i]; }
+    asm volatile("" : "+v"(away_next), "+v"(away_prev));   // stay integers: as compares they would travel through scalar masks
+    // zero_half() leaves bits 15 / 31: vertex -> bits 0 / 16, swap -> bits 1 / 17, dup -> bits 3 / 19; halves folded together
+    uint32_t bits = (zero_half(acc.vertex) >> 15) | (zero_half(acc.swap) >> 14) | (zero_half(acc.dup) >> 12);
+    bits |= bits >> 16;
+    const uint32_t flags = group_reduce<Q, false>((min(away_next, 1u) << 2) | (min(away_prev, 1u) << 4) | (bits & 0xBu), x);
+    // was_terminal: two agents share a cell (bit 3), or every agent is on its goal (bit 4 clear)
+    const uint32_t term = ((flags >> 3) | (~flags >> 4)) & 1u;
+    const uint32_t code16 = ((flags & 7u) | (term << 3)) << 4;
+    const bool was_terminal = code16 > 7u * 16u;
+    const u32x4 row = lds_at<u32x4>(kStepOutcomeAt + code16);      // {reward lo, hi, status, done | collision << 16}
+    double reward = __hiloint2double(int(row.y), int(row.x));
     if (p.c.criteria == 1u) {
+        // _living_reward: mapf_env.py:436-446
         uint32_t mine = 0u;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
@@ -196,16 +241,21 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
             mine += (cur[k] == goal_k && act[k] == 0u) ? 1u : 0u;
         }
         const int stayed = int(group_reduce<Q, true>(mine, x));
-        living = __dmul_rn(double(int(n_agents) - stayed), p.c.r_living);
+        const double living = __dmul_rn(double(int(n_agents) - stayed), p.c.r_living);
+        const uint32_t f = (code16 >> 4) & 7u;
+        const bool coll_ = (f & 3u) != 0u, goal_next = (f & 4u) == 0u;
+        const double r = coll_ ? __dadd_rn(p.c.r_clash, living) : (goal_next ? __dadd_rn(p.c.r_goal, living) : living);
+        reward = was_terminal ? 0.0 : r;                           // mapf_env.py:239-240 -- (s, 0, True, {"prob": 0})
     }
-    const bool coll = (f & 3u) != 0u, goal_next = (f & 4u) == 0u;
-    const double r = coll ? __dadd_rn(p.c.r_clash, living) : (goal_next ? __dadd_rn(p.c.r_goal, living) : living);
-    const double reward = was_terminal ? 0.0 : r;                  // mapf_env.py:239-240 -- (s, 0, True, {"prob": 0})
-    const bool done = coll || goal_next || was_terminal;
-    if (was_terminal) {
+    const uint32_t done_coll = row.w;                              // done | collision << 16
+    const bool done = (done_coll & 1u) != 0u;
+    // a step from a terminal state changes nothing
 #pragma unroll
-        for (int i = 0; i < P; ++i) n[i] = c[i];
-    }
+    for (int i = 0; i < P; ++i) n[i] = was_terminal ? c[i] : n[i];
+
+    // total_prob: left-to-right product over agents 0..A-1 (mapf_env.py:257); the total ends in the group's last lane
+    q[0] = was_terminal ? 0.0 : q[0];                              // (a zero factor makes the whole product +0.0)
+    const double prob = packed_prob_product<Q, K>(q);
 
     Packed<P> out;
 #pragma unroll
@@ -215,11 +265,11 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
     STEP_STAMP(5);   // everything computed
 #endif
     if (p.out_local) out.store(at(p.out_local, lane_cell));
-    if (x.g == uint32_t(Q - 1) && p.out_prob) *at(p.out_prob, e) = was_terminal ? 0.0 : prob;
+    if (x.g == uint32_t(Q - 1) && p.out_prob) *at(p.out_prob, e) = prob;
     if (x.g == 0u) {
         if (p.out_reward) *at(p.out_reward, e) = reward;
-        if (p.out_done) *at(p.out_done, e) = done ? 1 : 0;
-        if (p.out_collision) *at(p.out_collision, e) = (coll && !was_terminal) ? 1 : 0;
+        if (p.out_done) *at(p.out_done, e) = uint8_t(done_coll);
+        if (p.out_collision) *at(p.out_collision, e) = uint8_t(done_coll >> 16);
         if (p.out_was_terminal) *at(p.out_was_terminal, e) = was_terminal ? 1 : 0;
     }
     if (SCEN) {                                                    // MapfEnv.reset(): start cells, no reseed
@@ -262,7 +312,9 @@ bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning 
 #ifndef MAPF_STEP_STAMPS   // (the diagnostic build receives its stamp buffer through `uniforms`)
     if (args.uniforms != nullptr) return false;
 #endif
-    if (!tune.quad_lanes) return false;
+    // top_tie: a three-entry list whose last cumulative sum rounds below 1.0 needs a third compare per agent; the packed
+    // sampling does two (as in the packed rollout), so such a table stays with the lane-group kernel
+    if (!tune.quad_lanes || args.c.top_tie) return false;
     int K = 0;
     if (tune.force_k != 2 && n_agents % 4 == 0) K = 4;
     else if (tune.force_k != 4 && n_agents % 2 == 0 && n_agents >= 4) K = 2;
@@ -282,9 +334,11 @@ bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning 
 #define MAPF_LQ_STEP(QQ, KK)                                                                                   \
     if (Q == QQ && K == KK) {                                                                                  \
         if (scen) hipLaunchKernelGGL((lq_step_kernel<QQ, KK, true>), dim3(grid), dim3(block), 0, stream, args.state, args.actions,  \
-                                     args.scen, args.scen_rows, args.mv, A, block, args);                                          \
+                                     args.scen, args.slip, args.t_dev, A | (block << 8), uint32_t(args.t), args.c.seed_lo,         \
+                                     args.c.seed_hi, args);                                                                        \
         else hipLaunchKernelGGL((lq_step_kernel<QQ, KK, false>), dim3(grid), dim3(block), 0, stream, args.state, args.actions,    \
-                                static_cast<const uint8_t *>(nullptr), args.goal, args.mv, A, block, args);                        \
+                                static_cast<const uint8_t *>(nullptr), args.slip, args.t_dev, A | (block << 8), uint32_t(args.t),  \
+                                args.c.seed_lo, args.c.seed_hi, args);                                                             \
         *err = hipGetLastError();                                                                              \
         return true;                                                                                           \
     }
