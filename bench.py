@@ -29,9 +29,10 @@ time of that region.  Rank 0 prints ONE JSON line.  Keys beyond the contract:
   roofline      dominant kernel (the fused rollout; `kernel` = what the library reports it dispatched): algorithmic
                 bytes / HIP-event time per launch; `traffic` = HBM bytes per launch from the committed PMC passes
                 (profiles/traffic.json: per-step + fixed part), `traffic_frac` = that / the same time / peak;
-                `valu_frac` = VALU wave-instructions per launch (committed SQ pass, profiles/valu.json) x 4 cycles /
-                (SIMDs x live launch time x the shader clock that pass measured): the share of the chip's vector-issue
-                slots the kernel fills -- the resource that binds it, printed beside the HBM figure
+                `valu_frac` = share of the SIMDs' cycles with a vector instruction in flight (4 cycles each): measured
+                by the committed SQ counter pass (profiles/valu.json: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves per
+                SIMD) and scaled by that pass's launch duration / the live one -- the resource that binds the kernel
+                (DESIGN.md 4.1), printed beside the HBM figure
   single_step_launches   the same env-steps as one mapf_step launch each, recorded ONCE into a hipGraph (64 nodes; the
                 step index lives in device memory, so every replay draws fresh numbers) and replayed; the next
                 observation is read from the handle's state view (cells written once); `plain_launches` = the same
@@ -231,17 +232,19 @@ def scalar_env_rate(budget_s=2.0):
     return out
 
 
-def measured_valu(kernel, n_envs, n_agents):
-    """(VALU wave-instructions per env-step launch-step, shader clock in Hz, SIMDs) of `kernel` at this batch from the
-    committed SQ counter pass (profiles/valu.json, written by tools/sq_summary.py --json), or None."""
+def measured_valu(kernel, n_envs, n_agents, steps_per_launch):
+    """The committed SQ counter pass of `kernel` at this batch (profiles/valu.json, tools/derive_valu.py): (VALU
+    wave-instructions per launch, share of the SIMDs' cycles with a vector instruction in flight during that pass, mean
+    launch duration of that pass in ms), or None when no such pass is committed."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'valu.json')) as f:
             entries = json.load(f)['kernels']
     except (OSError, KeyError, ValueError):
         return None
     for entry in entries:
-        if entry.get('kernel') == kernel and entry.get('n_envs') == n_envs and entry.get('n_agents') == n_agents:
-            return entry['valu_insts_per_env_step'], entry['shader_clock_hz'], entry['simds']
+        if entry.get('kernel') == kernel and entry.get('n_envs') == n_envs and entry.get('n_agents') == n_agents and \
+                entry.get('env_steps_per_launch') == steps_per_launch:
+            return entry['valu_insts_per_launch'], entry['valu_busy_share_of_simd_cycles'], entry['launch_ms_in_pass']
     return None
 
 
@@ -544,7 +547,7 @@ def main():
                                      "ms_per_launch": p_blocks[0][0] * 1e3 / 2000, "ms_per_launch_hip_events": p_blocks[0][1] / 2000}}
 
     ro_traffic = measured_traffic(rollout_kernel, E, A, T)          # PMC bytes per launch (profiles/)
-    ro_valu = measured_valu(rollout_kernel, E, A)                   # SQ pass: VALU wave-instructions per env-step
+    ro_valu = measured_valu(rollout_kernel, E, A, T)                # SQ pass: VALU wave-instructions, busy share
     if rank == 0:
         line = {
             "metric": "agent-steps/sec (batched MapfEnv.step)", "value": value, "unit": "agent-steps/s",
@@ -570,8 +573,8 @@ def main():
                          "frac": ro_achieved / HBM_PEAK_GBS,
                          "traffic": ro_traffic,
                          "traffic_frac": (ro_traffic / (ro_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ro_traffic else None,
-                         "valu_frac": (ro_valu[0] * T * 4.0 / (ro_valu[2] * ro_launch_ms * 1e-3 * ro_valu[1])) if ro_valu else None,
-                         "valu_insts_per_launch": (ro_valu[0] * T) if ro_valu else None,
+                         "valu_frac": min(1.0, ro_valu[1] * ro_valu[2] / ro_launch_ms) if ro_valu else None,
+                         "valu_insts_per_launch": ro_valu[0] if ro_valu else None,
                          "kernel": rollout_kernel, "bytes_per_launch": ro_bytes,
                          "ms_per_launch_hip_events": ro_launch_ms,
                          "note": "achieved = algorithmic bytes (5 + 18/A per agent-step, SURVEY.md 8(d)) per launch / HIP-event "

@@ -199,6 +199,7 @@ class MapfEnv(_EnvBase):
 
         self.P = _TransitionModel(self)
         self._transitions_memo = {}
+        self._reward_memo, self._collision_memo = {}, {}   # (prev, a, next) / (prev, next): the reference lru_caches :378
         self._vec = None        # one-env VecMapfEnv, created on first use (needs the GPU)
         self._single = None     # one-agent helper env for single_agent_movements
         self._terminal = None   # is_terminal(self.s) if known
@@ -315,17 +316,25 @@ class MapfEnv(_EnvBase):
         """``(reward, done, is_collision)`` of moving from ``prev_local_states`` to ``next_local_states`` (tuples of
         local cell ids) under joint action ``action``: collision reward first, then goal, else the living reward
         (reference :225-235).  Evaluated by the ``mapf_transition_rewards`` kernel."""
-        n = self.n_agents
-        digits = integer_to_vector(action, [len(ACTIONS)] * n, n, lambda x: x)
-        prev, nxt = self._locals_query(prev_local_states, next_local_states)
-        reward, done, coll = self._device().transition_rewards(prev, np.asarray([digits], dtype=np.uint8), nxt)
-        return float(reward[0]), bool(done[0]), bool(coll[0])
+        key = (tuple(prev_local_states), action, tuple(next_local_states))
+        hit = self._reward_memo.get(key)
+        if hit is None:                                   # one launch per NEW triple; planners revisit transitions
+            n = self.n_agents
+            digits = integer_to_vector(action, [len(ACTIONS)] * n, n, lambda x: x)
+            prev, nxt = self._locals_query(prev_local_states, next_local_states)
+            reward, done, coll = self._device().transition_rewards(prev, np.asarray([digits], dtype=np.uint8), nxt)
+            hit = self._reward_memo[key] = (float(reward[0]), bool(done[0]), bool(coll[0]))
+        return hit
 
     def _is_collision_transition_from_local_states(self, prev_local_states, next_local_states):
         """Vertex collision (two agents end in one cell) or swap (two agents exchange cells); reference :378-389."""
-        prev, nxt = self._locals_query(prev_local_states, next_local_states)
-        _, _, coll = self._device().transition_rewards(prev, np.zeros((1, self.n_agents), np.uint8), nxt)
-        return bool(coll[0])
+        key = (tuple(prev_local_states), tuple(next_local_states))
+        hit = self._collision_memo.get(key)
+        if hit is None:
+            prev, nxt = self._locals_query(prev_local_states, next_local_states)
+            _, _, coll = self._device().transition_rewards(prev, np.zeros((1, self.n_agents), np.uint8), nxt)
+            hit = self._collision_memo[key] = bool(coll[0])
+        return hit
 
     def _living_reward(self, prev_local_states, a: int):
         """Makespan: ``reward_of_living``; SoC: every agent pays it unless it sits on its goal and stays

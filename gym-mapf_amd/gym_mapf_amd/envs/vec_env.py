@@ -308,7 +308,7 @@ class VecMapfEnv:
         nat.check(self._lib.mapf_rollout(self._h, ctypes.byref(io)))
         return res
 
-    def transitions(self, local, actions, max_branches=None, env_index=None, first_branch=0):
+    def transitions(self, local, actions, max_branches=None, env_index=None, first_branch=0, out=None):
         """``env.P[s][a]`` for N (state, joint action) queries (reference mapf_env.py:448-478): every branch of the
         joint slip distribution in the reference's order.  ``local`` uint16 [N, A], ``actions`` uint8 [N, A],
         ``env_index`` uint32 [N] picks whose goals apply (default env 0).  Returns a dict: ``count`` uint32 [N] (always
@@ -322,9 +322,10 @@ class VecMapfEnv:
         local = self._coerce(local, np.uint16, (N, A), 'local')
         actions = self._coerce(actions, np.uint8, (N, A), 'actions')
         env_index = self._coerce(env_index, np.uint32, (N,), 'env_index')
-        res = {'count': self._empty((N,), np.uint32), 'next': self._empty((N, M, A), np.uint16),
-               'prob': self._empty((N, M), np.float64), 'reward': self._empty((N, M), np.float64),
-               'done': self._empty((N, M), np.uint8), 'collision': self._empty((N, M), np.uint8)}
+        res = out if out is not None else {
+            'count': self._empty((N,), np.uint32), 'next': self._empty((N, M, A), np.uint16),
+            'prob': self._empty((N, M), np.float64), 'reward': self._empty((N, M), np.float64),
+            'done': self._empty((N, M), np.uint8), 'collision': self._empty((N, M), np.uint8)}
         nat.check(self._lib.mapf_transitions_window(
             self._h, N, self._ptr(local, np.uint16, (N, A), 'local'), self._ptr(actions, np.uint8, (N, A), 'actions'),
             self._ptr(env_index, np.uint32, (N,), 'env_index'), int(first_branch), M, self._ptr(res['count'], np.uint32, (N,), 'count'),

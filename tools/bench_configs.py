@@ -62,8 +62,9 @@ def measure(name, grid, start, goal, A, fail_prob, T=64, reps=12):
     ms1 = env.timer_end()
     st = 4 * T * E * A / (ms1 * 1e-3)
     bpas = 5.0 + 18.0 / A
-    print('%-46s E=%7d A=%3d V=%5d | rollout %7.1f G agent-steps/s (%.3f of 8 TB/s) | single-step %6.1f G (%.3f)' % (
-        name, E, A, len(grid.tables()[0]), ro / 1e9, ro * bpas / 8e12, st / 1e9, st * bpas / 8e12))
+    print('%-46s E=%7d A=%3d V=%5d | rollout %7.1f G agent-steps/s (%.3f of 8 TB/s) | single-step %6.1f G (%.3f) | %s | %s' % (
+        name, E, A, len(grid.tables()[0]), ro / 1e9, ro * bpas / 8e12, st / 1e9, st * bpas / 8e12,
+        env.last_kernel('rollout').split(' (')[0], env.last_kernel('step').split(' (')[0]), flush=True)
     env.close()
 
 
@@ -78,5 +79,12 @@ if __name__ == '__main__':
     measure('C5 share: random-64-64-20*, 32 agents, 16384/GPU', g, s, t, 32, 0.2)
     g, s, t = scen_tables('room-64-64-16', [1, 2, 5, 7], 32, 16384)
     measure('room-64-64-16, 32 agents, 16384 envs', g, s, t, 32, 0.2)
+    # the reference's large maps: move tables of 1.2 MB / 3.8 MB, i.e. the global-table (L2-resident) kernels
+    g, s, t = scen_tables('maze-128-128-10', [18], 32, 16384)
+    measure('maze-128-128-10, 32 agents (scen 18), 16384 envs', g, s, t, 32, 0.2)
+    g, s, t = scen_tables('Berlin_1_256', [11], 4, 65536)
+    measure('Berlin_1_256, 4 agents (scen 11), 65536 envs', g, s, t, 4, 0.2)
+    g, s, t = scen_tables('Berlin_1_256', [2, 4, 8, 11, 14, 18, 22, 24], 2, 65536)
+    measure('Berlin_1_256, 2 agents (8 scens), 65536 envs', g, s, t, 2, 0.1)
     g, s, t = scen_tables('empty-8-8', [1], 2, 65536)
     measure('empty-8-8, 2 agents, slip 0 (C1 map), 65536 envs', g, s, t, 2, 0.0)

@@ -25,15 +25,27 @@ def run(name, map_name, scen, A, local, acts, M):
     at = torch.from_numpy(acts).cuda()
     res = env.transitions(lt, at, max_branches=M)
     env.sync()
-    env.timer_begin()
     reps = 5
+    env.timer_begin()
     for _ in range(reps):
-        res = env.transitions(lt, at, max_branches=M)
+        env.transitions(lt, at, max_branches=M, out=res)          # the output arrays are reserved once
     ms = env.timer_end() / reps
     branches = int(res['count'].to(torch.int64).sum().item())
-    print('%-44s queries %8d  branches %9d  %.3f ms  -> %6.1f M queries/s, %7.1f M branches/s' % (
-        name, local.shape[0], branches, ms, local.shape[0] / ms / 1e3, branches / ms / 1e3))
+    # the same calls letting every call allocate its own output arrays (what profiles/r02_transitions.txt timed): the
+    # HIP-event interval then contains torch's allocator -- hipMalloc of N * M * (2A + 18) bytes once the cache is cold
+    env.timer_begin()
+    for _ in range(reps):
+        fresh = env.transitions(lt, at, max_branches=M)
+    ms_alloc = env.timer_end() / reps
+    del fresh
+    reserved = local.shape[0] * M * (2 * A + 18)
+    print('%-44s queries %8d  branches %9d  reserved %7.1f MB  %.3f ms  -> %6.1f M queries/s, %7.1f M branches/s, %6.1f GB/s written'
+          '   | allocating per call: %.3f ms' % (
+              name, local.shape[0], branches, reserved / 1e6, ms, local.shape[0] / ms / 1e3, branches / ms / 1e3,
+              branches * (2 * A + 18) / ms / 1e6, ms_alloc), flush=True)
     env.close()
+    del res
+    torch.cuda.empty_cache()
 
 
 if __name__ == '__main__':

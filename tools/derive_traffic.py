@@ -1,7 +1,7 @@
 """Derive profiles/traffic.json from rocprofv3 PMC passes of `python3 bench.py --no-cpu-baseline` run at TWO launch
 lengths (--rollout-steps T1 and T2): per kernel instance and batch, HBM bytes per launch = fixed + per_env_step * T.
 
-usage: python tools/derive_traffic.py <label> <E> <A> <T1> <fetch1.csv> <write1.csv> <T2> <fetch2.csv> <write2.csv> [...]
+usage: python tools/derive_traffic.py [--merge] <label> <E> <A> <T1> <fetch1.csv> <write1.csv> <T2> <fetch2.csv> <write2.csv> [...]
        (label = "<rollout kernel>||<single-step kernel>" as the library reports them for that batch: bench line
         `roofline.kernel` and `single_step_launches.kernel`; a group of nine arguments per configuration)
 
@@ -45,7 +45,17 @@ def hbm_bytes(fetch, write, key):
 
 def main():
     args = sys.argv[1:]
+    merge = bool(args) and args[0] == "--merge"   # keep what profiles/traffic.json holds for batches not named in this call
+    if merge:
+        args = args[1:]
     out = {"_how": __doc__.strip().split("\n\n")[2].replace("\n", " "), "kernels": [], "calibration": {}}
+    old = {"kernels": [], "calibration": {}}
+    if merge:
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                old = json.load(f)
+        except (OSError, ValueError):
+            pass
     while len(args) >= 9:
         label, E, A, T1, f1, w1, T2, f2, w2 = args[:9]
         label, _, step_label = label.partition("||")
@@ -76,6 +86,9 @@ def main():
                 out["calibration"]["%s E=%d A=%d" % (k, E, A)] = {
                     "FETCH_SIZE_KB": round(F1[k][0], 2), "WRITE_SIZE_KB": round(W1[k][0], 2), "hbm_bytes_per_launch": int(hbm_bytes(F1, W1, k)),
                     "known_bytes": (E * A * 2 * 2) if k == "reset_kernel" else None}
+    fresh = {(k["kernel"], k["n_envs"], k["n_agents"]) for k in out["kernels"]}
+    out["kernels"] = [k for k in old.get("kernels", []) if (k.get("kernel"), k.get("n_envs"), k.get("n_agents")) not in fresh] + out["kernels"]
+    out["calibration"] = dict(old.get("calibration", {}), **out["calibration"])
     dst = os.path.join(ROOT, "profiles", "traffic.json")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
