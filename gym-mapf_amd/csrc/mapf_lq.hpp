@@ -177,6 +177,84 @@ __device__ __forceinline__ PairAcc<true> packed_pair_tests(const LaneCtx<Q> &x, 
     return acc;
 }
 
+// ---- vertex / swap facts of an env through a per-env LDS occupancy bitmap instead of all agent pairs (32 agents: 496
+// pairs are ~3/4 of a step's vector instructions; this is O(A)).  TWO bits per cell -- "an agent stood here when the step
+// began" and "an agent ends here" -- so one returning atomic per agent answers both questions.  The env's lanes sit in
+// ONE wave and a wave's LDS operations execute in program order, so no barrier is needed between the phases:
+//   1. every agent sets the START bit of its current cell;
+//   2. every agent sets the END bit of its next cell with a returning atomic OR and looks at the old word:
+//      END bit already set  <=>  two agents end in one cell: the vertex collision (mapf_env.py:386-387);
+//      START bit set and next != current  <=>  it moves onto a cell another agent held when the step began -- the only
+//      agents that can be half of a swap (:382-384): "candidates";
+//   3. the touched words are cleared;
+//   4. a swap needs TWO candidates in one env (each partner moves onto the other's cell), which is rare (an agent in a
+//      hundred is a candidate on the 32-agent maps): only while some env of the wave has two does each group elect its
+//      lowest candidate, broadcast its (current, next) pair, and every lane compare its own agents' (next, current)
+//      against it -- equal <=> the two swap.
+// min over my group (result in every lane); Q <= 16 lanes
+template <int Q>
+__device__ __forceinline__ uint32_t group_reduce_min(uint32_t v) {
+    if constexpr (Q >= 2) v = min(v, dpp_mov<0xB1>(v));            // quad_perm [1,0,3,2]
+    if constexpr (Q >= 4) v = min(v, dpp_mov<0x4E>(v));            // quad_perm [2,3,0,1]
+    if constexpr (Q >= 8) v = min(v, dpp_mov<0x141>(v));           // row_half_mirror
+    if constexpr (Q >= 16) v = min(v, dpp_mov<0x140>(v));          // row_mirror
+    return v;
+}
+using lds_u32 = __attribute__((address_space(3))) uint32_t *;
+template <int Q, int K>
+__device__ __forceinline__ PairAcc<true> bitmap_pair_tests(const LaneCtx<Q> &x, uint32_t bitmap_at, const uint32_t (&c)[K / 2],
+                                                           const uint32_t (&n)[K / 2]) {
+    static_assert(Q <= 16 && K <= 8, "a group is at most one 16-lane row");
+    uint32_t cur[K], nxt[K], wc[K], wn[K], sn[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        cur[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu;
+        nxt[k] = (k & 1) ? n[k / 2] >> 16 : n[k / 2] & 0xFFFFu;
+        wc[k] = bitmap_at + ((cur[k] >> 4) << 2);
+        wn[k] = bitmap_at + ((nxt[k] >> 4) << 2);
+        sn[k] = (nxt[k] & 15u) << 1;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) __hip_atomic_fetch_or((lds_u32)(uintptr_t(wc[k])), 1u << ((cur[k] & 15u) << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    uint32_t old[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) old[k] = __hip_atomic_fetch_or((lds_u32)(uintptr_t(wn[k])), 2u << sn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+    for (int k = 0; k < K; ++k) { *(lds_u32)(uintptr_t(wc[k])) = 0u; *(lds_u32)(uintptr_t(wn[k])) = 0u; }
+    uint32_t cand = 0u, vertex_hit = 0u;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const uint32_t bits = old[k] >> sn[k];                      // bit 0: START of my next cell, bit 1: END of it
+        vertex_hit |= bits & 2u;
+        cand |= ((bits & 1u) != 0u && nxt[k] != cur[k]) ? 1u << k : 0u;
+    }
+    uint32_t swap_hit = 0u;
+    const uint32_t n_cand = group_reduce<Q, true>(uint32_t(__builtin_popcount(cand)), x);
+    if (__builtin_expect(__any(n_cand >= 2u), 0)) {
+        while (__any(cand != 0u)) {
+            const uint32_t k_low = uint32_t(__builtin_ctz(cand | 0x100u));              // my lowest candidate slot (8 = none)
+            const uint32_t key = cand ? (x.g << 3) | k_low : 0xFFFFu;
+            const uint32_t best = group_reduce_min<Q>(key);                              // the group's elected (lane, slot)
+            const bool owner = best == key && cand != 0u;
+            uint32_t mine = 0u;                                                           // the elected agent's current | next << 16
+#pragma unroll
+            for (int k = 0; k < K; ++k) mine = (owner && k_low == uint32_t(k)) ? (cur[k] | (nxt[k] << 16)) : mine;
+            const uint32_t fwd = group_reduce<Q, false>(mine, x);                        // (every other lane contributes 0)
+            const uint32_t rev = swap_halves(fwd);                                        // a partner's current | next << 16
+            uint32_t diff = 0xFFFFFFFFu;
+#pragma unroll
+            for (int k = 0; k < K; ++k) diff = min(diff, (cur[k] | (nxt[k] << 16)) ^ rev);
+            swap_hit |= (diff == 0u && best != 0xFFFFu) ? 1u : 0u;
+            cand = owner ? cand & (cand - 1u) : cand;                                     // done with my lowest candidate
+        }
+    }
+    PairAcc<true> acc;
+    acc.dup = 0xFFFFFFFFu;
+    acc.vertex = min(vertex_hit, 1u) - 1u;   // 0 <=> hit (both half-words zero), else all ones
+    acc.swap = swap_hit - 1u;
+    return acc;
+}
+
 // non-zero <=> one of the two half-words of a is zero (the classic "has a zero byte" test on 16-bit fields): the only
 // bits that can be set are 15 and 31
 __device__ __forceinline__ uint32_t zero_half(uint32_t a) {

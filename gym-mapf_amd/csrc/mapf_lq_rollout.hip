@@ -51,13 +51,17 @@ static_assert(sizeof(SlipRow) * 8 + sizeof(OutcomeRow) * 16 <= kLdsReserve, "sta
 // in-kernel policy.  Memory pipeline and store scheme as lg_rollout_kernel<DENSE>.
 constexpr uint32_t kSlipAt = 0, kOutcomeAt = sizeof(SlipRow) * 8, kMoveAt = kLdsReserve, kMoveCols = 6;
 constexpr uint32_t kCompactCols = 5, kCompactEntry = 8;   // COMPACT: cells + code only, no sixth column
+constexpr uint32_t kBitmapCols = 4;                       // COMPACT + BITMAP: no STAY column either
 static_assert(kOutcomeAt + sizeof(OutcomeRow) * 16 <= kMoveAt, "LDS image: slip rows, outcome rows, then the move table");
 
 // TERM = an env may be terminal when a step begins.  With auto-reset on and no env whose START state is itself
 // terminal (the handle knows: mapf_create looks) that cannot happen after the launch's first step -- a done env is back
 // on its start cells -- and the !TERM instance runs every later step without the was-terminal selects.
-template <int Q, int K, bool RECORD, bool STREAM, bool SOC, bool COMPACT, bool TERM>
-__global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents) {
+// BITMAP = the vertex / swap facts come from a per-env LDS occupancy bitmap (bitmap_pair_tests in mapf_lq.hpp) instead of
+// all agent pairs: O(A) instead of O(A^2) -- the 32-agent configurations, where 496 pairs were three quarters of a step.
+// The bitmaps (one per env of the block, ceil(V / 32) words each) follow the move table in the LDS image at `bitmap_base`.
+template <int Q, int K, bool RECORD, bool STREAM, bool SOC, bool COMPACT, bool TERM, bool BITMAP = false>
+__global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents, const uint32_t bitmap_base) {
     constexpr int P = K / 2;   // packed dwords per lane
     static_assert(K == 2 || K == 4 || K == 8, "two, four or eight agents per lane");
     // the kernel's only LDS object, so it sits at LDS address 0 and every offset below is an instruction immediate
@@ -88,14 +92,17 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     {   // move table -> LDS with six columns per cell (0..4 = the actions, 5 = STAY again: where out-of-range action
         // bytes are clamped to), batches of four independent loads per thread
         // (COMPACT: five columns, the first 8 bytes of every row)
-        const uint32_t n_words = p.c.n_cells * (COMPACT ? kCompactCols : kMoveCols);
+        // (COMPACT + BITMAP: FOUR columns -- the moves; a STAY row is (cell, cell, cell) with the all-equal code and is made
+        // up in registers -- which leaves room for the occupancy bitmaps behind the table)
+        constexpr uint32_t kCols = !COMPACT ? kMoveCols : (BITMAP ? kBitmapCols : kCompactCols);
+        const uint32_t n_words = p.c.n_cells * kCols;
         for (uint32_t w0 = threadIdx.x; w0 < n_words; w0 += 4u * blockDim.x) {
             MoveEntry part[4];
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) {
                 const uint32_t w = min(w0 + k * blockDim.x, n_words - 1u);
-                const uint32_t cell = w / kMoveCols, col = w - cell * kMoveCols;
-                part[k] = p.mv[COMPACT ? w : cell * 5u + (col == 5u ? 0u : col)];
+                const uint32_t cell = w / kCols, col = w - cell * kCols;
+                part[k] = p.mv[!COMPACT ? cell * 5u + (col == 5u ? 0u : col) : (BITMAP ? cell * 5u + col + 1u : w)];
             }
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) {
@@ -107,6 +114,13 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
                 }
             }
         }
+    }
+    uint32_t bitmap_at = 0u;
+    if (BITMAP) {
+        const uint32_t stride = (((p.c.n_cells + 15u) >> 4) * 4u + 15u) & ~15u;    // bytes per env: two bits per cell
+        bitmap_at = bitmap_base + (threadIdx.x / uint32_t(Q)) * stride;
+        const uint32_t n_words = (blockDim.x / uint32_t(Q)) * (stride >> 2);
+        for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) *(lds_u32)(uintptr_t(bitmap_base + 4u * w)) = 0u;
     }
     stage_outcome_table(p.c, outcome);
     stage_slip_table(p.slip, slip);   // ends with __syncthreads()
@@ -239,7 +253,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     // steps, so the prefetch address is clamped.  `raw` is the register that holds this step's action word.
     uint32_t pk_eights = 0x00080008u, pk_steps = 0x02020202u, sel_base = 0x0C0C0504u;   // sample_slot_packed's constants,
     asm volatile("" : "+v"(pk_eights), "+v"(pk_steps), "+v"(sel_base));                   // one vector register each
-    uint32_t row_bytes = COMPACT ? kCompactCols * kCompactEntry : kMoveCols * uint32_t(sizeof(MoveEntry));
+    uint32_t row_bytes = COMPACT ? (BITMAP ? kBitmapCols : kCompactCols) * kCompactEntry : kMoveCols * uint32_t(sizeof(MoveEntry));
     asm volatile("" : "+v"(row_bytes));   // (one register for the whole loop; as an SGPR operand the assembler rejects the SDWA form)
     auto one_step = [&](const uint32_t s, RawWord &raw, auto w_tag, auto first_tag, auto tail_tag) __attribute__((always_inline)) {
         constexpr int W = decltype(w_tag)::value;
@@ -300,7 +314,8 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         for (int k = 0; k < K; ++k) asm volatile("" : "+v"(cell_at[k]));
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (COMPACT) cells_code[k] = lds_at<u32x2>(kMoveAt + (act[k] << 3) + cell_at[k]);
+            if (COMPACT && BITMAP) cells_code[k] = lds_at<u32x2>(kMoveAt - kCompactEntry + (act[k] << 3) + cell_at[k]);   // column act - 1 (STAY: see below)
+            else if (COMPACT) cells_code[k] = lds_at<u32x2>(kMoveAt + (act[k] << 3) + cell_at[k]);
             else entry[k] = lds_entry_at(kMoveAt + (act[k] << 4) + cell_at[k]);
         }
         STAMP(0);   // loop top: action fetch / policy, table read issue
@@ -321,6 +336,14 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         STAMP(1);   // previous step: probability chain, totals, trajectory stores
         if (COMPACT) {   // the code's thresholds: a second LDS read that depends on the first; the row completes to a MoveEntry
             uint32_t row_off[K], th[K];
+            if (BITMAP) {   // a STAY row: the cell itself, the all-equal code (one entry: candidates m = r = l)
+#pragma unroll
+                for (int k = 0; k < K; ++k) {
+                    const bool stay = act[k] == 0u;
+                    cells_code[k].x = stay ? cur[k] : cells_code[k].x;
+                    cells_code[k].y = stay ? (7u * uint32_t(sizeof(SlipRow))) << 16 : cells_code[k].y;
+                }
+            }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 row_off[k] = cells_code[k].y >> 16;
@@ -374,7 +397,9 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         STAMP(3);   // sampling (table wait, thresholds, probability read issue)
 
         // --- pair tests, then the per-env facts as ONE integer: f = vertex | swap << 1 | off_goal << 2
-        const PairAcc<true> acc = packed_pair_tests<Q, P, false, true>(x, c, n);
+        PairAcc<true> acc;
+        if constexpr (BITMAP) acc = bitmap_pair_tests<Q, K>(x, bitmap_at, c, n);
+        else acc = packed_pair_tests<Q, P, false, true>(x, c, n);
         STAMP(4);   // pair tests
         uint32_t away = n[0] ^ g[0];
 #pragma unroll
@@ -512,21 +537,27 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     }
 }
 
-template <int Q, int K, bool RECORD, bool STREAM, bool COMPACT = false>
+// bytes of one env's occupancy bitmap (BITMAP instances)
+static size_t bitmap_stride(uint32_t n_cells) { return (size_t((n_cells + 15u) / 16u) * 4u + 15u) & ~size_t(15); }   // two bits per cell
+
+template <int Q, int K, bool RECORD, bool STREAM, bool COMPACT = false, bool BITMAP = false>
 hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream) {
     // (criteria, may-be-terminal): the instance without terminal handling exists for Makespan only
     const bool term = !(args.auto_reset && !args.start_terminal_any);
-    auto kern = args.c.criteria != 0u ? lq_rollout_kernel<Q, K, RECORD, STREAM, true, COMPACT, true>
-                : term            ? lq_rollout_kernel<Q, K, RECORD, STREAM, false, COMPACT, true>
-                                  : lq_rollout_kernel<Q, K, RECORD, STREAM, false, COMPACT, false>;
+    auto kern = args.c.criteria != 0u ? lq_rollout_kernel<Q, K, RECORD, STREAM, true, COMPACT, true, BITMAP>
+                : term            ? lq_rollout_kernel<Q, K, RECORD, STREAM, false, COMPACT, true, BITMAP>
+                                  : lq_rollout_kernel<Q, K, RECORD, STREAM, false, COMPACT, false, BITMAP>;
+    const uint32_t bitmap_base = uint32_t(lds_bytes);           // the bitmaps follow the table
+    if (BITMAP) lds_bytes += size_t(block / unsigned(Q)) * bitmap_stride(args.c.n_cells);
     if (lds_bytes > 32 * 1024) {
         if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), int(kLdsBytes - kLdsReserve))) return e;
     }
     const unsigned grid = unsigned(args.n_envs / (block / unsigned(Q)));
-    note_kernel("lq_rollout_kernel<Q=%d,K=%d,%s,%s,%s%s%s> block=%u (packed layout: %d agents per lane%s)", Q, K, RECORD ? "RECORD" : "TOTALS",
+    note_kernel("lq_rollout_kernel<Q=%d,K=%d,%s,%s,%s%s%s%s> block=%u (packed layout: %d agents per lane%s%s)", Q, K, RECORD ? "RECORD" : "TOTALS",
                 STREAM ? "STREAM" : "POLICY", args.c.criteria != 0u ? "SOC" : "MAKESPAN", COMPACT ? ",COMPACT" : "",
-                (args.c.criteria == 0u && !term) ? ",NO_TERMINAL" : "", block, K, COMPACT ? ", 8-byte table rows" : "");
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds_bytes, stream, args, A);
+                (args.c.criteria == 0u && !term) ? ",NO_TERMINAL" : "", BITMAP ? ",BITMAP" : "", block, K, COMPACT ? ", 8-byte table rows" : "",
+                BITMAP ? ", collisions through per-env occupancy bitmaps" : "");
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds_bytes, stream, args, A, bitmap_base);
     return hipGetLastError();
 }
 
@@ -540,14 +571,16 @@ hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size
 #define MAPF_LQ_CAT3(a, b, c) a##b##_r##c
 #define MAPF_LQ_NAME(k, r) MAPF_LQ_CAT3(launch_rollout_lq_k, k, r)
 
-hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream) {
+hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, int form, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream) {
     constexpr int K = MAPF_LQ_K;
     constexpr bool R = MAPF_LQ_RECORD != 0;
     const bool stream_actions = args.actions != nullptr;
+    const bool compact = form != 0, bitmap = form == 2;   // form: 0 full table rows, 1 8-byte rows, 2 8-byte rows + occupancy bitmaps
+    (void)bitmap;
 #if MAPF_LQ_K == 8
     // eight agents per lane: 8, 16 and 32 agents (Q = 1, 2, 4); 8-byte table rows for the 32-agent maps only
     if (compact) {
-        if (Q != 4) return hipErrorInvalidValue;
+        if (Q != 4 || bitmap) return hipErrorInvalidValue;
         return stream_actions ? launch_impl<4, K, R, true, true>(args, A, block, lds_bytes, stream)
                               : launch_impl<4, K, R, false, true>(args, A, block, lds_bytes, stream);
     }
@@ -562,6 +595,11 @@ hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, bool compact, const Ro
 }
 #else
 #if MAPF_LQ_K == 4
+    if (bitmap) {    // 32 agents only (that is where the 496 pairs dominate)
+        if (Q != 8) return hipErrorInvalidValue;
+        return stream_actions ? launch_impl<8, K, R, true, true, true>(args, A, block, lds_bytes, stream)
+                              : launch_impl<8, K, R, false, true, true>(args, A, block, lds_bytes, stream);
+    }
     if (compact) {   // instantiated for the group sizes whose maps need it: 16, 32 and 64 agents
         switch (Q) {
 #define X(QQ)                                                                                                        \
@@ -590,11 +628,11 @@ hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, bool compact, const Ro
 #endif
 
 #if MAPF_LQ_K == 4 && MAPF_LQ_RECORD == 1
-hipError_t launch_rollout_lq_k8_r1(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
-hipError_t launch_rollout_lq_k8_r0(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
-hipError_t launch_rollout_lq_k4_r0(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
-hipError_t launch_rollout_lq_k2_r1(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
-hipError_t launch_rollout_lq_k2_r0(int Q, bool compact, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_rollout_lq_k8_r1(int Q, int form, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_rollout_lq_k8_r0(int Q, int form, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_rollout_lq_k4_r0(int Q, int form, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_rollout_lq_k2_r1(int Q, int form, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
+hipError_t launch_rollout_lq_k2_r0(int Q, int form, const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream);
 
 // does the K-agents-per-lane form apply to this launch?  (full groups, power-of-two group size, full blocks)
 static bool layout_fits(int n_agents, int K, const RolloutArgs &args, size_t lds_bytes, unsigned *block_out, int *q_out) {
@@ -623,7 +661,7 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
     const uint32_t A = uint32_t(n_agents);
     unsigned block = 0;
     int Q = 0, K = 0;
-    bool compact = false;
+    bool compact = false, bitmap = false;
     size_t lds_bytes = kMoveAt + size_t(args.c.n_cells) * kMoveCols * sizeof(MoveEntry);   // the kernel's whole LDS image
     if (lds_bytes <= tune.mv_lds_max_bytes && lds_bytes <= kLdsBytes - kLdsReserve) {
         // Four agents per lane halve the waves: that form needs tune.quad_min_lanes lanes (default: enough to put one
@@ -643,11 +681,23 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
         if (tune.mv_lds_max_bytes == 0 || lds_bytes > kLdsBytes - kLdsReserve) return false;
         int n_cu = 256, dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
+        const size_t bitmap_lds = kMoveAt + size_t(args.c.n_cells) * kBitmapCols * kCompactEntry;   // (no STAY column in that form)
         // 32 agents: eight per lane (Q = 4, one 512-thread block per CU) once the batch gives every CU two such blocks' worth
+        // (C5 whole on one GPU: 484 G agent-steps/s against 444 G for the bitmap form below, profiles/r03_configs.txt)
         if ((tune.force_k == 0 || tune.force_k == 8) && n_agents == 32 && layout_fits(n_agents, 8, args, lds_bytes, &block, &Q) &&
             args.n_envs % (512u / 4u) == 0 && (tune.force_k == 8 || args.n_envs * 4u >= tune.oct_min_lanes)) {
             block = 512u;
             K = 8;
+        } else
+        // 32 agents below that: four per lane, collisions through per-env occupancy bitmaps (64 envs per 512-thread block)
+        // when the bitmaps fit behind the table -- O(A) instead of 496 pair tests per env (C5's share of one GPU: 419 G
+        // against 377 G)
+        if (tune.bitmap_pairs && n_agents == 32 && tune.force_k != 8 && tune.force_k != 2 && layout_fits(n_agents, 4, args, bitmap_lds, &block, &Q) &&
+            args.n_envs % (512u / 8u) == 0 && bitmap_lds + (512u / 8u) * bitmap_stride(args.c.n_cells) <= kLdsBytes) {
+            block = 512u;
+            K = 4;
+            bitmap = true;
+            lds_bytes = bitmap_lds;
         } else {
             if (tune.force_k == 8 || !layout_fits(n_agents, 4, args, lds_bytes, &block, &Q) || Q < 4) return false;
             block = 512u;
@@ -661,9 +711,10 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
         *err = hipErrorInvalidValue;
         return true;
     }
-    if (K == 8) *err = record ? launch_rollout_lq_k8_r1(Q, compact, args, A, block, lds_bytes, stream) : launch_rollout_lq_k8_r0(Q, compact, args, A, block, lds_bytes, stream);
-    else if (K == 4) *err = record ? launch_rollout_lq_k4_r1(Q, compact, args, A, block, lds_bytes, stream) : launch_rollout_lq_k4_r0(Q, compact, args, A, block, lds_bytes, stream);
-    else *err = record ? launch_rollout_lq_k2_r1(Q, compact, args, A, block, lds_bytes, stream) : launch_rollout_lq_k2_r0(Q, compact, args, A, block, lds_bytes, stream);
+    const int form = bitmap ? 2 : (compact ? 1 : 0);
+    if (K == 8) *err = record ? launch_rollout_lq_k8_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k8_r0(Q, form, args, A, block, lds_bytes, stream);
+    else if (K == 4) *err = record ? launch_rollout_lq_k4_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k4_r0(Q, form, args, A, block, lds_bytes, stream);
+    else *err = record ? launch_rollout_lq_k2_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k2_r0(Q, form, args, A, block, lds_bytes, stream);
     return true;
 }
 #endif

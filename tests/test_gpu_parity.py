@@ -418,7 +418,9 @@ def _goal_scenario_tables(n_agents, n_envs, seed):
     (32, 2048, 'lq_rollout_kernel<Q=4,K=8,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_LQ_K': '8'}),
     # (a full table "too large" for the LDS budget: the 8-byte-row form of the packed kernel, 512- and 1024-thread blocks)
     (16, 4096, 'lq_rollout_kernel<Q=4,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_PAIRS': '0'}),
+    # (32 agents, 8-byte rows: collisions through per-env LDS occupancy bitmaps instead of the 496 agent pairs -- the default)
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
     (64, 16384, 'lq_rollout_kernel<Q=16,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
     (8, 300, 'lg_rollout_kernel<L=4,FULL,MV_GLOBAL', {}), (5, 600, 'lg_rollout_kernel<L=4,RAGGED', {}),
     (8, 16417, 'lg_rollout_kernel<L=4,FULL,MV_LDS', {}), (6, 512, 'rollout_kernel<A=6>', {})])
@@ -462,6 +464,7 @@ def test_goal_reaching_episodes_against_c_oracle(n_agents, n_envs, layout, env_v
             seen = env.last_kernel('rollout')
             wanted = layout if (mode == 'streamed' and crit == OptimizationCriteria.Makespan) else layout.split(',RECORD')[0]
             assert wanted in seen, seen
+            assert ('BITMAP' in seen) == ('BITMAP' in layout), seen
         goals = clash_on_goal = 0
         for t in range(T):
             ref, (local, reward, prob, done, coll) = refs[t], got[t]

@@ -165,6 +165,34 @@ def test_scenario_table_step_equals_plain_rows(monkeypatch, n_agents, n_envs):
         env.close()
 
 
+def test_resident_grid_walks_a_batch_larger_than_the_device(monkeypatch):
+    """393216 envs x 8 agents = 3072 chunks of one block's worth: more than the 2048 blocks an MI355X holds at 8 waves per
+    SIMD, so the packed single step runs as a resident grid whose blocks walk one or two chunks each (the LDS image and
+    its barrier are set up in the first pass only).  Six steps against the C oracle, and the same with one block per
+    chunk (MAPF_STEP_RESIDENT_GRID=0)."""
+    E, A = 393216, 8
+    grid, _, nbr, start, goal = _c3_tables(E)
+    import philox
+    ids = np.arange(E)
+    for resident in (True, False):
+        if resident:
+            monkeypatch.delenv('MAPF_STEP_RESIDENT_GRID', raising=False)
+        else:
+            monkeypatch.setenv('MAPF_STEP_RESIDENT_GRID', '0')
+        env = VecMapfEnv(grid, A, None, None, 0.2, *R, OptimizationCriteria.SoC, seed=3, start_local=start, goal_local=goal)
+        co = c_oracle.COracle(nbr, A, start, goal, 0.2, *R, mo.SOC, seed=3)
+        for t in range(6):
+            acts = philox.random_actions_np(3, ids, t, A)
+            local, reward, done, info = env.step(acts, auto_reset=True)
+            ref = co.step(acts, auto_reset=True)
+            assert np.array_equal(local, ref['local']) and np.array_equal(_bits(reward), _bits(ref['reward'])), (resident, t)
+            assert np.array_equal(_bits(info['prob']), _bits(ref['prob'])) and np.array_equal(done, ref['done']), (resident, t)
+            assert np.array_equal(info['collision'], ref['collision']) and np.array_equal(info['was_terminal'], ref['was_terminal'])
+        assert np.array_equal(env.get_state()[0], co.state)
+        assert ('resident grid' in env.last_kernel('step')) == resident, env.last_kernel('step')
+        env.close()
+
+
 def test_recording_is_refused_where_it_cannot_work():
     grid = MapfGrid(['....', '....'])
     kw = dict(start_local=np.array([[0, 5]], np.uint16).repeat(64, 0), goal_local=np.array([[7, 2]], np.uint16).repeat(64, 0))

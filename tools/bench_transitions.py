@@ -33,9 +33,11 @@ def run(name, map_name, scen, A, local, acts, M):
     branches = int(res['count'].to(torch.int64).sum().item())
     # the same calls letting every call allocate its own output arrays (what profiles/r02_transitions.txt timed): the
     # HIP-event interval then contains torch's allocator -- hipMalloc of N * M * (2A + 18) bytes once the cache is cold
+    env.sync()
+    torch.cuda.empty_cache()                                      # cold allocator, as in a fresh process
     env.timer_begin()
     for _ in range(reps):
-        fresh = env.transitions(lt, at, max_branches=M)
+        fresh = env.transitions(lt, at, max_branches=M)           # (the previous `fresh` is still alive while this one is allocated)
     ms_alloc = env.timer_end() / reps
     del fresh
     reserved = local.shape[0] * M * (2 * A + 18)

@@ -4,7 +4,7 @@
 episode counters, so this build's outputs are not valid results) and prints median cycles per step and segment.
 
     make -C gym-mapf_amd/csrc stamps
-    MAPF_HIP_LIB=gym-mapf_amd/csrc/build/libmapf_hip_stamps.so python tools/stamp_profile.py [envs]
+    MAPF_HIP_LIB=gym-mapf_amd/gym_mapf_amd/lib/variants/libmapf_hip_stamps.so python tools/stamp_profile.py [envs] [c3|c5]
     (MAPF_LQ_K=2 profiles the packed layout with two agents per lane, MAPF_QUAD_LANES=0 the lane-group kernel)
 
 Stamps serialise the segments (a fence on each side), so read the SHARES, not the total (cdna_hip_programming.md
@@ -22,17 +22,20 @@ from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv  # noqa: 
 
 if 'stamps' not in os.environ.get('MAPF_HIP_LIB', ''):
     raise SystemExit('set MAPF_HIP_LIB to the stamps build (see the docstring)')
-E, A, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 65536), 8, 64
-# envs per wave: 32 with four agents per lane (default), 16 with two
-PER_WAVE = 16 if os.environ.get('MAPF_QUAD_LANES') == '0' or os.environ.get('MAPF_LQ_K') == '2' else 32
-print('layout: %s' % ('pair (2 agents per lane)' if PER_WAVE == 16 else 'quad (4 agents per lane)'))
-grid, _, nbr, start, goal = bench.workload_tables(bench.CONFIGS['c3'], E, 0)
-print('envs: %d' % E)
+cfg_name = sys.argv[2] if len(sys.argv) > 2 else 'c3'
+cfg = bench.CONFIGS[cfg_name]
+E, A, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 65536), cfg['agents'], 64
+# envs per wave: 64 / (lanes per env); 8 agents: 32 with four agents per lane (default), 16 with two
+pair_layout = os.environ.get('MAPF_QUAD_LANES') == '0' or os.environ.get('MAPF_LQ_K') == '2'
+PER_WAVE = 64 * (2 if pair_layout else 4) // A
+print('layout: %s' % ('pair (2 agents per lane)' if pair_layout else 'quad (4 agents per lane)'))
+grid, _, nbr, start, goal = bench.workload_tables(cfg, E, 0)
+print('config %s, envs: %d, agents: %d' % (cfg_name, E, A))
 env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=42,
                  device_arrays=True, start_local=start, goal_local=goal)
 actions = env.fill_random_actions(0, T)
 env.sync()
-if PER_WAVE == 16:
+if pair_layout:
     names = ['loop top (actions, delayed stores)', 'slip Philox (1 step in 4) + table read', 'sampling + probability read',
              'pair tests', 'flags + group reduce', 'probability product', 'reward / selects', 'reset handling']
 else:
@@ -45,6 +48,7 @@ for acts, label in ((actions, 'streamed actions'), (None, 'in-kernel policy')):
         env.rollout(T, actions=acts, auto_reset=True, record=record)
         res = env.rollout(T, actions=acts, auto_reset=True, record=record)
         env.sync()
+        print('kernel:', env.last_kernel('rollout'))
         seg = res['episodes'].cpu().numpy().view(np.uint32).reshape(-1, PER_WAVE)[:, :8].astype(np.float64) / T
         med = np.median(seg, axis=0)
         print('%s, record=%s: %d cycles per wave-step' % (label, record, med.sum()))
