@@ -90,6 +90,12 @@ struct mapf_handle_s {
     // plus A-wide unrolling); only spill-free kernels are dispatched, so those sizes use the lane-group rollout.
     bool lane_group_rollout = false;
     bool start_terminal_any = true;   // is_terminal(start) for some env (looked up once at create)
+    // Can some env be terminal right now?  Not after a call that auto-reset every finished episode (unless a START state
+    // is itself terminal) or after a full reset; yes after steps without auto-reset and after set_state.  The packed
+    // single step runs its instance without is_terminal(prev) when the answer is no.  While recording a graph the
+    // question is asked about the recording's own history only (cap_may_be_terminal: the first recorded step cannot know
+    // what precedes a replay).
+    bool may_be_terminal = true, cap_may_be_terminal = true;
     mapf::RolloutTuning tune;
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -120,6 +126,8 @@ struct mapf_graph_s {
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     uint64_t steps = 0;               // env-steps one replay advances the handle by
+    bool ends_may_be_terminal = true; // mapf_handle_s::may_be_terminal after a replay (conservative: true unless the
+                                      // recording's last state-changing call auto-resets every finished episode)
 };
 
 namespace {
@@ -442,6 +450,7 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
         CREATE_TRY(hipStreamSynchronize(h->stream));
         h->start_terminal_any = false;
         for (uint64_t e = 0; e < E; ++e) h->start_terminal_any |= flags[e] != 0;
+        h->may_be_terminal = h->start_terminal_any;
     }
 #undef CREATE_TRY
     *out_handle = h;
@@ -503,6 +512,7 @@ int mapf_reset(mapf_handle_t h, const uint8_t *mask) {
     const uint8_t *d_mask = nullptr;
     if (int rc = stage_in(h, h->s_mask, mask, size_t(h->E), &d_mask, "mask")) return rc;
     HIP_TRY(mapf::launch_reset(int(h->A), h->state, h->start, h->start_broadcast, d_mask, h->E, h->stream));
+    if (!mask) (h->capturing ? h->cap_may_be_terminal : h->may_be_terminal) = h->start_terminal_any;
     if (!h->device_ptrs) HIP_TRY(hipStreamSynchronize(h->stream));
     return MAPF_OK;
 }
@@ -524,6 +534,10 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     a.scen = h->scen; a.scen_rows = h->scen_rows;
     a.start_broadcast = h->start_broadcast; a.goal_broadcast = h->goal_broadcast;
     a.auto_reset = step_flags & MAPF_STEP_AUTO_RESET;
+    bool &may_be_terminal = h->capturing ? h->cap_may_be_terminal : h->may_be_terminal;
+    a.state_not_terminal = !may_be_terminal;
+    // after this step: every finished episode is back on its start cells (auto-reset), or anything goes
+    const bool may_be_terminal_after = a.auto_reset ? h->start_terminal_any : true;
     if (!h->device_ptrs) {
         // tiny host-mode call: inputs and outputs live in one pinned, device-mapped block (16-byte aligned slots)
         auto slot = [](size_t &off, size_t bytes) { const size_t at = off; off += (bytes + 15u) & ~size_t(15); return at; };
@@ -556,6 +570,7 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
             HIP_TRY(h->lane_group ? mapf::launch_step_lg(int(h->A), a, h->tune, h->stream) : mapf::launch_step(int(h->A), a, h->stream));
             if (h->last_step_kernel != g_noted_kernel) h->last_step_kernel = g_noted_kernel;
             h->t += 1;
+            may_be_terminal = may_be_terminal_after;
             // A one-wave launch signals its end itself: its last instruction stores the call's sequence number into the
             // pinned block (system-scope release after all outputs), and the host spins on that word instead of paying the
             // sleeping stream wait (~6 us of a ~16 us call).  Anything larger, or a slow launch, uses hipStreamSynchronize.
@@ -585,6 +600,7 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     HIP_TRY(h->lane_group ? mapf::launch_step_lg(int(h->A), a, h->tune, h->stream) : mapf::launch_step(int(h->A), a, h->stream));
     if (h->last_step_kernel != g_noted_kernel) h->last_step_kernel = g_noted_kernel;
     if (h->capturing) h->cap_steps += 1; else h->t += 1;
+    may_be_terminal = may_be_terminal_after;
     if (!h->device_ptrs) {
         if (int rc = fetch_out(h, a.out_local, out_local, EA)) return rc;
         if (int rc = fetch_out(h, a.out_reward, out_reward, E)) return rc;
@@ -639,6 +655,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
         HIP_TRY(h->lane_group_rollout ? mapf::launch_rollout_lg(int(h->A), a, h->tune, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
         if (h->last_rollout_kernel != g_noted_kernel) h->last_rollout_kernel = g_noted_kernel;
         if (h->capturing) h->cap_steps += io->n_steps; else h->t += io->n_steps;
+        if (io->n_steps) (h->capturing ? h->cap_may_be_terminal : h->may_be_terminal) = a.auto_reset ? h->start_terminal_any : true;
         return MAPF_OK;
     }
     // host-pointer mode: stage everything through device scratch
@@ -667,6 +684,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     HIP_TRY(h->lane_group_rollout ? mapf::launch_rollout_lg(int(h->A), a, h->tune, h->stream) : mapf::launch_rollout(int(h->A), a, h->stream));
     if (h->last_rollout_kernel != g_noted_kernel) h->last_rollout_kernel = g_noted_kernel;
     h->t += io->n_steps;
+    if (io->n_steps) h->may_be_terminal = a.auto_reset ? h->start_terminal_any : true;
     if (int rc = fetch_out(h, a.out_returns, io->out_returns, E)) return rc;
     if (int rc = fetch_out(h, a.out_episodes, io->out_episodes, E)) return rc;
     if (int rc = fetch_out(h, a.out_collisions, io->out_collisions, E)) return rc;
@@ -836,6 +854,7 @@ int mapf_set_state(mapf_handle_t h, const uint16_t *local, uint64_t t) {
         }
         HIP_TRY(hipMemcpyAsync(h->state, local, n * sizeof(uint16_t),
                                h->device_ptrs ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, h->stream));
+        h->may_be_terminal = true;   // (an arbitrary state)
         if (!h->device_ptrs) HIP_TRY(hipStreamSynchronize(h->stream));
     }
     h->t = t;
@@ -856,6 +875,7 @@ int mapf_graph_begin(mapf_handle_t h) {
     HIP_TRY(hipStreamBeginCapture(h->stream, hipStreamCaptureModeRelaxed));
     h->capturing = true;
     h->cap_steps = 0;
+    h->cap_may_be_terminal = true;   // whatever precedes a replay: the first recorded step tests is_terminal itself
     return MAPF_OK;
 }
 
@@ -877,6 +897,7 @@ int mapf_graph_end(mapf_handle_t h, mapf_graph_t *out_graph) {
     mapf_graph_t g = new (std::nothrow) mapf_graph_s();
     if (!g) { (void)hipGraphDestroy(graph); return fail(MAPF_EHIP, "out of host memory"); }
     g->owner = h; g->graph = graph; g->steps = h->cap_steps;
+    g->ends_may_be_terminal = h->cap_may_be_terminal;
     const hipError_t inst = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
     if (inst != hipSuccess) { (void)hipGraphDestroy(graph); delete g; return hip_fail(inst, "hipGraphInstantiate"); }
     h->live_graphs += 1;
@@ -896,6 +917,7 @@ int mapf_graph_launch(mapf_handle_t h, mapf_graph_t g, uint32_t n_replays) {
     for (uint32_t r = 0; r < n_replays; ++r) HIP_TRY(hipGraphLaunch(g->exec, h->stream));
     h->t += uint64_t(n_replays) * g->steps;
     h->t_dev_value = h->t;
+    if (n_replays) h->may_be_terminal = g->ends_may_be_terminal;
     return MAPF_OK;
 }
 

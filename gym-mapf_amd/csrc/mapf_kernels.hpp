@@ -67,6 +67,7 @@ struct StepArgs {
     uint32_t *done_flag;           // one-wave launches only (else null): host-visible word that receives done_seq
     uint32_t done_seq;             //   after every output of the step has been written (system-scope release)
     bool start_broadcast, goal_broadcast, auto_reset;
+    bool state_not_terminal;       // host promise: no env is terminal when this step begins (see mapf_handle_s::may_be_terminal)
 };
 
 struct RolloutArgs {
@@ -149,7 +150,6 @@ struct RolloutTuning {
     int force_k = 0;                 // MAPF_LQ_K=2|4|8 pins the agents per lane of the packed layout (tests)
     size_t mv_lds_max_bytes = 0;     // largest move table staged into LDS (MAPF_MV_LDS_MAX_BYTES; default: two blocks per CU)
     bool bitmap_pairs = true;        // MAPF_BITMAP_PAIRS=0: the 32-agent rollout keeps the all-pairs collision tests (tests compare both)
-    bool step_resident_grid = true;  // MAPF_STEP_RESIDENT_GRID=0: the packed single step launches one block per chunk whatever the batch
     bool scen_table = true;          // MAPF_SCEN_TABLE=0: never build the scenario table (StepArgs::scen) -- tests compare both forms
 };
 RolloutTuning default_rollout_tuning(int device);

@@ -74,11 +74,15 @@ struct PhiloxRounds {
 //   * a 16-bit tie is resolved by register arithmetic alone (slip_move_exact_members), only for the slots that tie.
 constexpr uint32_t kStepSlipAt = 0, kStepOutcomeAt = sizeof(SlipRow) * 8, kStepLds = kStepOutcomeAt + sizeof(OutcomeRow) * 16;
 
-template <int Q, int K, bool SCEN>
+//   * TERM = an env may be terminal when the step begins.  The host knows when none can (StepArgs::state_not_terminal:
+//     the previous call auto-reset every finished episode and no START state is itself terminal) -- the usual training
+//     loop -- and the !TERM instance drops is_terminal(prev): the duplicate-cell half of the pair tests, the on-goal test
+//     of the current cells and every was-terminal select.
+template <int Q, int K, bool SCEN, bool TERM>
 __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, const uint8_t *const actions, const uint8_t *const scen,
                                                       const SlipRow *const slip_rows, const uint64_t *const t_dev,
                                                       const uint32_t agents_block, const uint32_t t_lo, const uint32_t seed_lo,
-                                                      const uint32_t seed_hi, const StepArgs p, const uint32_t n_chunks) {
+                                                      const uint32_t seed_hi, const StepArgs p) {
     constexpr int P = K / 2;
 #ifdef MAPF_STEP_STAMPS
     unsigned long long stamp_[8] = {}, real0_, cyc0_;
@@ -88,17 +92,14 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
     __shared__ __attribute__((aligned(16))) unsigned char lds_image[kStepLds];
     if (uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lds_image)) != 0u) __builtin_trap();
     const uint32_t n_agents = agents_block & 0xFFu, block_threads = agents_block >> 8;
-    // A batch larger than the device holds at once (more blocks than 8 waves per SIMD) is walked by a RESIDENT grid: every
-    // block takes chunks blockIdx.x, blockIdx.x + gridDim.x, ... of one block's worth of envs.  The argument block, the LDS
-    // image and its barrier are then paid once per wave instead of once per chunk -- at 1 M envs the argument block alone
-    // took 1.4 us of a wave's 5.2 us (profiles/r03_step_stamps_1M.txt).  Small batches run the loop once.
-    for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    const bool first_pass = chunk == blockIdx.x;
+    // (One block per 256 lanes whatever the batch: a resident grid whose blocks walk several chunks -- argument block, LDS
+    // image and barrier paid once per wave -- was built and measured 6-8 % SLOWER at 0.5-4 M envs; the hardware dispatcher
+    // refills the SIMDs at least as well.)
     LaneCtx<Q> x;
     x.lane = threadIdx.x & 63u;
     x.g = x.lane & uint32_t(Q - 1);
     x.base = x.lane & ~uint32_t(Q - 1);
-    x.e = ((chunk * block_threads + threadIdx.x) >> 6) * uint32_t(64 / Q) + x.lane / uint32_t(Q);
+    x.e = ((blockIdx.x * block_threads + threadIdx.x) >> 6) * uint32_t(64 / Q) + x.lane / uint32_t(Q);
     x.v0 = x.v1 = true;
     const uint32_t e = x.e;
     const uint32_t lane_cell = e * n_agents + uint32_t(K) * x.g;    // my first agent's element index
@@ -114,7 +115,7 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
     Packed<P> gl{}, sl{};
     if (SCEN) scen_id = *at(scen, e);
     uint64_t slip_w0 = 0u, slip_w1 = 0u;
-    const bool stager = threadIdx.x < 64u && first_pass;
+    const bool stager = threadIdx.x < 64u;
     if (stager) {
         const uint64_t *src = reinterpret_cast<const uint64_t *>(slip_rows);
         slip_w0 = src[threadIdx.x];
@@ -172,10 +173,10 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
         dst[threadIdx.x] = slip_w0;
         if (threadIdx.x < 32u) dst[64u + threadIdx.x] = slip_w1;
     }
-    if (first_pass) stage_outcome_table(p.c, reinterpret_cast<OutcomeRow *>(lds_image + kStepOutcomeAt));
+    stage_outcome_table(p.c, reinterpret_cast<OutcomeRow *>(lds_image + kStepOutcomeAt));
     __builtin_amdgcn_sched_barrier(0);
     if (p.c.need_rng) rng_state.template run<4>();
-    if (first_pass) __syncthreads();
+    __syncthreads();
 #ifdef MAPF_STEP_STAMPS
     { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_[3] = t_ - cyc0_; __builtin_amdgcn_sched_barrier(0); }   // gathers issued, four rounds done
     STEP_STAMP(4);   // gathers arrived
@@ -223,19 +224,19 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
 
     // ---- is_terminal(prev) and the collision tests in one pass over the agent pairs; the per-env facts as ONE integer
     // code = vertex | swap << 1 | off_goal << 2 | was_terminal << 3 (mapf_env.py:210-223, :225-235, :378-389)
-    const PairAcc<true> acc = packed_pair_tests<Q, P, true, true>(x, c, n);
-    uint32_t away_next = n[0] ^ g[0], away_prev = c[0] ^ g[0];
+    const PairAcc<true> acc = packed_pair_tests<Q, P, TERM, true>(x, c, n);
+    uint32_t away_next = n[0] ^ g[0], away_prev = TERM ? c[0] ^ g[0] : 1u;
 #pragma unroll
-    for (int i = 1; i < P; ++i) { away_next |= n[i] ^ g[i]; away_prev |= c[i] ^ g[i]; }
+    for (int i = 1; i < P; ++i) { away_next |= n[i] ^ g[i]; if (TERM) away_prev |= c[i] ^ g[i]; }
     asm volatile("" : "+v"(away_next), "+v"(away_prev));   // stay integers: as compares they would travel through scalar masks
     // zero_half() leaves bits 15 / 31: vertex -> bits 0 / 16, swap -> bits 1 / 17, dup -> bits 3 / 19; halves folded together
-    uint32_t bits = (zero_half(acc.vertex) >> 15) | (zero_half(acc.swap) >> 14) | (zero_half(acc.dup) >> 12);
+    uint32_t bits = (zero_half(acc.vertex) >> 15) | (zero_half(acc.swap) >> 14) | (TERM ? zero_half(acc.dup) >> 12 : 0u);
     bits |= bits >> 16;
-    const uint32_t flags = group_reduce<Q, false>((min(away_next, 1u) << 2) | (min(away_prev, 1u) << 4) | (bits & 0xBu), x);
+    const uint32_t flags = group_reduce<Q, false>((min(away_next, 1u) << 2) | (TERM ? min(away_prev, 1u) << 4 : 0u) | (bits & 0xBu), x);
     // was_terminal: two agents share a cell (bit 3), or every agent is on its goal (bit 4 clear)
-    const uint32_t term = ((flags >> 3) | (~flags >> 4)) & 1u;
+    const uint32_t term = TERM ? ((flags >> 3) | (~flags >> 4)) & 1u : 0u;
     const uint32_t code16 = ((flags & 7u) | (term << 3)) << 4;
-    const bool was_terminal = code16 > 7u * 16u;
+    const bool was_terminal = TERM && code16 > 7u * 16u;
     const u32x4 row = lds_at<u32x4>(kStepOutcomeAt + code16);      // {reward lo, hi, status, done | collision << 16}
     double reward = __hiloint2double(int(row.y), int(row.x));
     if (p.c.criteria == 1u) {
@@ -301,14 +302,13 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
         if (x.lane == 0u && p.uniforms) {
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(const_cast<double *>(p.uniforms)) +
-                                      uint64_t((chunk * block_threads + threadIdx.x) >> 6) * 12u;
+                                      uint64_t((blockIdx.x * block_threads + threadIdx.x) >> 6) * 12u;
             dst[0] = real0_; dst[1] = real1_;
             for (int i = 0; i < 6; ++i) dst[2 + i] = stamp_[i];
             dst[8] = t6_ - cyc0_; dst[9] = t7_ - cyc0_; dst[10] = hw_id; dst[11] = xcc_id;
         }
     }
 #endif
-    }   // chunks
     signal_step_done(p.done_flag, p.done_seq);
 }
 
@@ -333,30 +333,28 @@ bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning 
     while (block > 64u && lanes < 256u * uint64_t(block)) block /= 2u;   // small batches: spread over the CUs
     const uint64_t per_block = block / unsigned(Q);
     if (args.n_envs == 0 || args.n_envs % per_block != 0) return false;
-    const unsigned n_chunks = unsigned(args.n_envs / per_block);
-    // resident grid: at most 8 waves per SIMD (the kernel needs < 64 vector registers and 1 KB of LDS per block)
-    int n_cu = 256, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
-    const unsigned resident = unsigned(n_cu) * (2048u / block);
-    const unsigned grid = tune.step_resident_grid && n_chunks > resident ? resident : n_chunks;
+    const unsigned grid = unsigned(args.n_envs / per_block);
     const uint32_t A = uint32_t(n_agents);
-    const bool scen = args.scen != nullptr;
-    note_kernel("lq_step_kernel<Q=%d,K=%d%s> block=%u%s (packed layout: %d agents per lane%s)", Q, K, scen ? ",SCEN" : "", block,
-                grid < n_chunks ? " resident grid" : "", K, scen ? ", start / goal rows from the scenario table" : "");
+    const bool scen = args.scen != nullptr, term = !args.state_not_terminal;
+    note_kernel("lq_step_kernel<Q=%d,K=%d%s%s> block=%u (packed layout: %d agents per lane%s)", Q, K, scen ? ",SCEN" : "",
+                term ? "" : ",NO_TERMINAL", block, K, scen ? ", start / goal rows from the scenario table" : "");
+#define MAPF_LQ_LAUNCH(QQ, KK, SS, TT, SCEN_PTR)                                                                                   \
+    hipLaunchKernelGGL((lq_step_kernel<QQ, KK, SS, TT>), dim3(grid), dim3(block), 0, stream, args.state, args.actions, SCEN_PTR,       \
+                       args.slip, args.t_dev, A | (block << 8), uint32_t(args.t), args.c.seed_lo, args.c.seed_hi, args)
 #define MAPF_LQ_STEP(QQ, KK)                                                                                   \
     if (Q == QQ && K == KK) {                                                                                  \
-        if (scen) hipLaunchKernelGGL((lq_step_kernel<QQ, KK, true>), dim3(grid), dim3(block), 0, stream, args.state, args.actions,  \
-                                     args.scen, args.slip, args.t_dev, A | (block << 8), uint32_t(args.t), args.c.seed_lo,         \
-                                     args.c.seed_hi, args, n_chunks);                                                              \
-        else hipLaunchKernelGGL((lq_step_kernel<QQ, KK, false>), dim3(grid), dim3(block), 0, stream, args.state, args.actions,    \
-                                static_cast<const uint8_t *>(nullptr), args.slip, args.t_dev, A | (block << 8), uint32_t(args.t),  \
-                                args.c.seed_lo, args.c.seed_hi, args, n_chunks);                                                   \
+        const uint8_t *const no_scen = nullptr;                                                                \
+        if (scen && term) MAPF_LQ_LAUNCH(QQ, KK, true, true, args.scen);                                       \
+        else if (scen) MAPF_LQ_LAUNCH(QQ, KK, true, false, args.scen);                                         \
+        else if (term) MAPF_LQ_LAUNCH(QQ, KK, false, true, no_scen);                                           \
+        else MAPF_LQ_LAUNCH(QQ, KK, false, false, no_scen);                                                    \
         *err = hipGetLastError();                                                                              \
         return true;                                                                                           \
     }
     MAPF_LQ_STEP(1, 4) MAPF_LQ_STEP(2, 4) MAPF_LQ_STEP(4, 4) MAPF_LQ_STEP(8, 4) MAPF_LQ_STEP(16, 4)
     MAPF_LQ_STEP(2, 2) MAPF_LQ_STEP(4, 2) MAPF_LQ_STEP(8, 2) MAPF_LQ_STEP(16, 2)
 #undef MAPF_LQ_STEP
+#undef MAPF_LQ_LAUNCH
     return false;
 }
 

@@ -62,6 +62,7 @@ def test_graph_replay_of_recorded_steps_matches_the_oracle(criteria):
         outs.append(out)
     with pytest.raises(nat.MapfNativeError):
         env.sync()                                   # waiting for the stream is refused while recording
+    assert 'NO_TERMINAL' in env.last_kernel('step')  # (a later recorded step follows a recorded auto-reset step)
     graph = env.graph_end()
     assert graph.steps == N and env.t == 3           # recording executed nothing
     view = env.state_view()
@@ -160,37 +161,72 @@ def test_scenario_table_step_equals_plain_rows(monkeypatch, n_agents, n_envs):
             assert np.array_equal(env.get_state()[0], co.state), (use_table, t)
             n_done += int(done.sum())
         name = env.last_kernel('step')
-        assert name.startswith('lq_step_kernel') and (',SCEN>' in name) == use_table, name
+        assert name.startswith('lq_step_kernel') and (',SCEN' in name) == use_table, name
         assert n_done > 0
         env.close()
 
 
-def test_resident_grid_walks_a_batch_larger_than_the_device(monkeypatch):
-    """393216 envs x 8 agents = 3072 chunks of one block's worth: more than the 2048 blocks an MI355X holds at 8 waves per
-    SIMD, so the packed single step runs as a resident grid whose blocks walk one or two chunks each (the LDS image and
-    its barrier are set up in the first pass only).  Six steps against the C oracle, and the same with one block per
-    chunk (MAPF_STEP_RESIDENT_GRID=0)."""
+def test_single_step_at_a_batch_larger_than_the_device_holds():
+    """393216 envs x 8 agents = 3072 blocks of the packed single step: more than the 2048 an MI355X holds at once (8 waves
+    per SIMD), so blocks are dispatched in waves -- six steps against the C oracle."""
     E, A = 393216, 8
     grid, _, nbr, start, goal = _c3_tables(E)
     import philox
     ids = np.arange(E)
-    for resident in (True, False):
-        if resident:
-            monkeypatch.delenv('MAPF_STEP_RESIDENT_GRID', raising=False)
-        else:
-            monkeypatch.setenv('MAPF_STEP_RESIDENT_GRID', '0')
-        env = VecMapfEnv(grid, A, None, None, 0.2, *R, OptimizationCriteria.SoC, seed=3, start_local=start, goal_local=goal)
-        co = c_oracle.COracle(nbr, A, start, goal, 0.2, *R, mo.SOC, seed=3)
-        for t in range(6):
-            acts = philox.random_actions_np(3, ids, t, A)
-            local, reward, done, info = env.step(acts, auto_reset=True)
-            ref = co.step(acts, auto_reset=True)
-            assert np.array_equal(local, ref['local']) and np.array_equal(_bits(reward), _bits(ref['reward'])), (resident, t)
-            assert np.array_equal(_bits(info['prob']), _bits(ref['prob'])) and np.array_equal(done, ref['done']), (resident, t)
-            assert np.array_equal(info['collision'], ref['collision']) and np.array_equal(info['was_terminal'], ref['was_terminal'])
+    env = VecMapfEnv(grid, A, None, None, 0.2, *R, OptimizationCriteria.SoC, seed=3, start_local=start, goal_local=goal)
+    co = c_oracle.COracle(nbr, A, start, goal, 0.2, *R, mo.SOC, seed=3)
+    for t in range(6):
+        acts = philox.random_actions_np(3, ids, t, A)
+        local, reward, done, info = env.step(acts, auto_reset=True)
+        ref = co.step(acts, auto_reset=True)
+        assert np.array_equal(local, ref['local']) and np.array_equal(_bits(reward), _bits(ref['reward'])), t
+        assert np.array_equal(_bits(info['prob']), _bits(ref['prob'])) and np.array_equal(done, ref['done']), t
+        assert np.array_equal(info['collision'], ref['collision']) and np.array_equal(info['was_terminal'], ref['was_terminal'])
+    assert np.array_equal(env.get_state()[0], co.state) and env.last_kernel('step').startswith('lq_step_kernel<Q=2,K=4,SCEN>')
+    env.close()
+
+
+def test_step_drops_is_terminal_only_when_no_env_can_be_terminal():
+    """The packed single step has an instance without is_terminal(prev) (NO_TERMINAL).  The library may use it only when no
+    env can be terminal: after a step that auto-reset every finished episode -- never for the first recorded step of a
+    graph, after a step without auto-reset, or after set_state.  Goal-seeking actions on the goal-scenario map make
+    episodes end all the time; every step against the C oracle."""
+    import goal_scenarios
+    A, E = 8, 512
+    lines, start_loc, goal_loc = goal_scenarios.goal_scenario(A, E, 4242)
+    grid = MapfGrid(lines)
+    valid, l2i, nbr = grid.tables()
+    ids = np.zeros((len(lines), len(lines[0])), np.uint16)
+    for loc, k in l2i.items():
+        ids[loc] = k
+    start = np.ascontiguousarray(ids[start_loc[..., 0], start_loc[..., 1]])
+    goal = np.ascontiguousarray(ids[goal_loc[..., 0], goal_loc[..., 1]])
+    rc = np.asarray([r | (c << 16) for r, c in valid], np.uint32)
+    env = VecMapfEnv(grid, A, None, None, 0.2, *R, OptimizationCriteria.SoC, seed=9, start_local=start, goal_local=goal)
+    co = c_oracle.COracle(nbr, A, start, goal, 0.2, *R, mo.SOC, seed=9)
+    seen = []
+    plan = [True, True, True, False, False, True, True, 'set_state', True, True, False, True]
+    n_terminal = 0
+    for what in plan:
+        if what == 'set_state':
+            terminal_state = np.ascontiguousarray(goal)              # every agent on its goal: terminal
+            env.set_state(terminal_state)
+            co.state[:] = terminal_state
+            continue
+        acts = co.greedy_actions(rc)
+        local, reward, done, info = env.step(acts, auto_reset=what)
+        ref = co.step(acts, auto_reset=what)
+        assert np.array_equal(local, ref['local']) and np.array_equal(_bits(reward), _bits(ref['reward'])), len(seen)
+        assert np.array_equal(_bits(info['prob']), _bits(ref['prob'])) and np.array_equal(done, ref['done']), len(seen)
+        assert np.array_equal(info['collision'], ref['collision']) and np.array_equal(info['was_terminal'], ref['was_terminal']), len(seen)
         assert np.array_equal(env.get_state()[0], co.state)
-        assert ('resident grid' in env.last_kernel('step')) == resident, env.last_kernel('step')
-        env.close()
+        n_terminal += int(ref['was_terminal'].sum())
+        seen.append('NO_TERMINAL' in env.last_kernel('step'))
+    # step 0 follows create (starts are not terminal here): no test needed; 1, 2 follow auto-reset steps; 3 follows one too;
+    # 4 follows a step without auto-reset; 5 likewise; 6 follows an auto-reset step; 7 follows set_state; ...
+    assert seen == [True, True, True, True, False, False, True, False, True, True, False], seen
+    assert n_terminal > 0
+    env.close()
 
 
 def test_recording_is_refused_where_it_cannot_work():
