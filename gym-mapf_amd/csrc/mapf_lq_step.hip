@@ -11,6 +11,8 @@
 // shows at large batches (profiles/r02_single_step_scaling.txt).
 #include "mapf_lq.hpp"
 
+#include <type_traits>
+
 namespace mapf {
 
 namespace {
@@ -78,28 +80,60 @@ constexpr uint32_t kStepSlipAt = 0, kStepOutcomeAt = sizeof(SlipRow) * 8, kStepL
 //     the previous call auto-reset every finished episode and no START state is itself terminal) -- the usual training
 //     loop -- and the !TERM instance drops is_terminal(prev): the duplicate-cell half of the pair tests, the on-goal test
 //     of the current cells and every was-terminal select.
-template <int Q, int K, bool SCEN, bool TERM>
-__global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, const uint8_t *const actions, const uint8_t *const scen,
+//   * BIG = the form for batches several times larger than the device holds at once (profiles/r03_single_step_scaling.txt):
+//     there the step is bound by the texture path's rate for DIVERGENT gathers -- four 16-byte table rows per lane, 64
+//     different cache lines per wave-instruction, ~1 line per cycle -- not by arithmetic or HBM.  A resident grid of
+//     1024-thread blocks (two per CU) stages the whole move table into LDS once and walks the batch in chunks of 1024
+//     lanes: the table rows become ds_read_b128 (a quarter of the cost), and the argument block, the LDS image and the
+//     barrier are paid once per block instead of once per chunk.
+constexpr uint32_t kStepMoveAt = 1024;
+static_assert(kStepLds <= kStepMoveAt, "LDS image of the BIG form: slip rows, outcome rows, then the move table");
+
+template <int Q, int K, bool SCEN, bool TERM, bool BIG = false>
+__global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *const state, const uint8_t *const actions, const uint8_t *const scen,
                                                       const SlipRow *const slip_rows, const uint64_t *const t_dev,
                                                       const uint32_t agents_block, const uint32_t t_lo, const uint32_t seed_lo,
-                                                      const uint32_t seed_hi, const StepArgs p) {
+                                                      const uint32_t seed_hi, const StepArgs p, const uint32_t n_chunks) {
     constexpr int P = K / 2;
 #ifdef MAPF_STEP_STAMPS
     unsigned long long stamp_[8] = {}, real0_, cyc0_;
     asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0_), "=s"(cyc0_) :: "memory");
 #endif
-    // the kernel's only LDS object, so it sits at LDS address 0 (lds_at() names LDS locations by their byte address)
-    __shared__ __attribute__((aligned(16))) unsigned char lds_image[kStepLds];
+    // the kernel's only LDS object, so it sits at LDS address 0 (lds_at() names LDS locations by their byte address):
+    // 1 KB static (slip rows, outcome rows); the BIG form owns a dynamic image with the move table behind them
+    unsigned char *lds_image;
+    if constexpr (BIG) {
+        extern __shared__ __attribute__((aligned(16))) unsigned char lds_dynamic[];
+        lds_image = lds_dynamic;
+    } else {
+        __shared__ __attribute__((aligned(16))) unsigned char lds_static[kStepLds];
+        lds_image = lds_static;
+    }
     if (uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lds_image)) != 0u) __builtin_trap();
     const uint32_t n_agents = agents_block & 0xFFu, block_threads = agents_block >> 8;
-    // (One block per 256 lanes whatever the batch: a resident grid whose blocks walk several chunks -- argument block, LDS
-    // image and barrier paid once per wave -- was built and measured 6-8 % SLOWER at 0.5-4 M envs; the hardware dispatcher
-    // refills the SIMDs at least as well.)
+    if (BIG) {   // move table -> LDS (16-byte rows, five columns), four independent loads per thread and round
+        const uint32_t n_rows = p.c.n_cells * 5u;
+        MoveEntry *const dst = reinterpret_cast<MoveEntry *>(lds_image + kStepMoveAt);
+        for (uint32_t w0 = threadIdx.x; w0 < n_rows; w0 += 4u * block_threads) {
+            const uint32_t w1 = w0 + block_threads, w2 = w1 + block_threads, w3 = w2 + block_threads, last = n_rows - 1u;
+            const MoveEntry r0 = p.mv[w0], r1 = p.mv[min(w1, last)], r2 = p.mv[min(w2, last)], r3 = p.mv[min(w3, last)];
+            dst[w0] = r0;
+            if (w1 < n_rows) dst[w1] = r1;
+            if (w2 < n_rows) dst[w2] = r2;
+            if (w3 < n_rows) dst[w3] = r3;
+        }
+        // ... and the slip / outcome rows, behind ONE barrier: every chunk of the block then finds the whole image in place
+        stage_outcome_table(p.c, reinterpret_cast<OutcomeRow *>(lds_image + kStepOutcomeAt));
+        stage_slip_table(slip_rows, reinterpret_cast<SlipRow *>(lds_image + kStepSlipAt));   // ends with __syncthreads()
+    }
+    // (!BIG: one block per 256 lanes, one pass.  A resident grid WITHOUT the LDS table was measured 6-8 % slower than that.)
+    auto one_chunk = [&](const uint32_t chunk, auto first_tag) __attribute__((always_inline)) {
+    constexpr bool first_pass = decltype(first_tag)::value;   // !BIG: the LDS image is written behind the chunk's first loads
     LaneCtx<Q> x;
     x.lane = threadIdx.x & 63u;
     x.g = x.lane & uint32_t(Q - 1);
     x.base = x.lane & ~uint32_t(Q - 1);
-    x.e = ((blockIdx.x * block_threads + threadIdx.x) >> 6) * uint32_t(64 / Q) + x.lane / uint32_t(Q);
+    x.e = ((chunk * block_threads + threadIdx.x) >> 6) * uint32_t(64 / Q) + x.lane / uint32_t(Q);
     x.v0 = x.v1 = true;
     const uint32_t e = x.e;
     const uint32_t lane_cell = e * n_agents + uint32_t(K) * x.g;    // my first agent's element index
@@ -115,7 +149,7 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
     Packed<P> gl{}, sl{};
     if (SCEN) scen_id = *at(scen, e);
     uint64_t slip_w0 = 0u, slip_w1 = 0u;
-    const bool stager = threadIdx.x < 64u;
+    const bool stager = threadIdx.x < 64u && first_pass;
     if (stager) {
         const uint64_t *src = reinterpret_cast<const uint64_t *>(slip_rows);
         slip_w0 = src[threadIdx.x];
@@ -165,7 +199,8 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
         cur[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu;
         const uint32_t byte = (raw >> (8 * k)) & 0xFFu;
         act[k] = byte > 4u ? 0u : byte;
-        entry[k] = move_entry<true>(p.mv, p.c.n_cells, cur[k], act[k]);
+        if (BIG) entry[k] = lds_entry_at(kStepMoveAt + (__umul24(min(cur[k], p.c.n_cells - 1u), 5u) + act[k]) * 16u);
+        else entry[k] = move_entry<true>(p.mv, p.c.n_cells, cur[k], act[k]);
     }
     // the LDS image, while the gathers are in flight: slip rows (fetched with the first trip) and the outcome table
     if (stager) {
@@ -173,10 +208,10 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
         dst[threadIdx.x] = slip_w0;
         if (threadIdx.x < 32u) dst[64u + threadIdx.x] = slip_w1;
     }
-    stage_outcome_table(p.c, reinterpret_cast<OutcomeRow *>(lds_image + kStepOutcomeAt));
+    if (first_pass) stage_outcome_table(p.c, reinterpret_cast<OutcomeRow *>(lds_image + kStepOutcomeAt));
     __builtin_amdgcn_sched_barrier(0);
     if (p.c.need_rng) rng_state.template run<4>();
-    __syncthreads();
+    if (first_pass) __syncthreads();
 #ifdef MAPF_STEP_STAMPS
     { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_[3] = t_ - cyc0_; __builtin_amdgcn_sched_barrier(0); }   // gathers issued, four rounds done
     STEP_STAMP(4);   // gathers arrived
@@ -302,13 +337,20 @@ __global__ void __launch_bounds__(256) lq_step_kernel(uint16_t *const state, con
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
         if (x.lane == 0u && p.uniforms) {
             unsigned long long *dst = reinterpret_cast<unsigned long long *>(const_cast<double *>(p.uniforms)) +
-                                      uint64_t((blockIdx.x * block_threads + threadIdx.x) >> 6) * 12u;
+                                      uint64_t((chunk * block_threads + threadIdx.x) >> 6) * 12u;
             dst[0] = real0_; dst[1] = real1_;
             for (int i = 0; i < 6; ++i) dst[2 + i] = stamp_[i];
             dst[8] = t6_ - cyc0_; dst[9] = t7_ - cyc0_; dst[10] = hw_id; dst[11] = xcc_id;
         }
     }
 #endif
+    };   // one_chunk
+    if constexpr (BIG) {
+#pragma nounroll
+        for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) one_chunk(chunk, std::false_type{});
+    } else {
+        one_chunk(blockIdx.x, std::true_type{});
+    }
     signal_step_done(p.done_flag, p.done_seq);
 }
 
@@ -329,21 +371,53 @@ bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning 
     const int Q = n_agents / K;
     if (Q > 16 || (Q & (Q - 1)) != 0) return false;
     const uint64_t lanes = args.n_envs * uint64_t(Q);
+    const uint32_t A = uint32_t(n_agents);
+    const bool scen = args.scen != nullptr, term = !args.state_not_terminal;
+    const uint8_t *const no_scen = nullptr;
+    // The BIG form (resident grid, move table in LDS): batches of at least four times what the device holds at once (8 agents:
+    // from 1 M envs; measured break-even at 0.5 M, +5 % at 1 M, +13 % at 2 M, +33 % at 4 M -- profiles/r03_single_step_scaling.txt),
+    // four agents per lane, a table that leaves room for two 1024-thread blocks per CU.  MAPF_STEP_BIG=0 never, =2 whenever it fits.
+    const size_t big_lds = kStepMoveAt + size_t(args.c.n_cells) * 5u * sizeof(MoveEntry);
+    int n_cu = 256, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
+    const bool big = K == 4 && Q <= 8 && tune.step_big != 0 && args.n_envs > 0 && args.n_envs % (1024u / unsigned(Q)) == 0 &&
+                     2u * big_lds <= 160u * 1024u && (tune.step_big == 2 || lanes >= 4u * uint64_t(n_cu) * 2048u);
+    if (big) {
+        const unsigned block = 1024u, n_chunks = unsigned(lanes / block), grid = n_chunks < 2u * unsigned(n_cu) ? n_chunks : 2u * unsigned(n_cu);
+        note_kernel("lq_step_kernel<Q=%d,K=%d%s%s,BIG> block=1024 resident grid (packed layout: 4 agents per lane, move table in LDS%s)", Q, K,
+                    scen ? ",SCEN" : "", term ? "" : ",NO_TERMINAL", scen ? ", start / goal rows from the scenario table" : "");
+#define MAPF_LQ_BIG(QQ, SS, TT, SCEN_PTR)                                                                                           \
+        {                                                                                                                           \
+            auto kern = lq_step_kernel<QQ, 4, SS, TT, true>;                                                                        \
+            if (big_lds > 32u * 1024u) { if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), int(160u * 1024u - 1024u))) { *err = e; return true; } } \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(block), big_lds, stream, args.state, args.actions, SCEN_PTR, args.slip, args.t_dev, \
+                               A | (block << 8), uint32_t(args.t), args.c.seed_lo, args.c.seed_hi, args, n_chunks);                 \
+        }
+#define MAPF_LQ_BIG_Q(QQ)                                                                        \
+        if (Q == QQ) {                                                                            \
+            if (scen && term) MAPF_LQ_BIG(QQ, true, true, args.scen)                              \
+            else if (scen) MAPF_LQ_BIG(QQ, true, false, args.scen)                                \
+            else if (term) MAPF_LQ_BIG(QQ, false, true, no_scen)                                  \
+            else MAPF_LQ_BIG(QQ, false, false, no_scen)                                           \
+            *err = hipGetLastError();                                                             \
+            return true;                                                                          \
+        }
+        MAPF_LQ_BIG_Q(1) MAPF_LQ_BIG_Q(2) MAPF_LQ_BIG_Q(4) MAPF_LQ_BIG_Q(8)
+#undef MAPF_LQ_BIG_Q
+#undef MAPF_LQ_BIG
+    }
     unsigned block = 256u;
     while (block > 64u && lanes < 256u * uint64_t(block)) block /= 2u;   // small batches: spread over the CUs
     const uint64_t per_block = block / unsigned(Q);
     if (args.n_envs == 0 || args.n_envs % per_block != 0) return false;
     const unsigned grid = unsigned(args.n_envs / per_block);
-    const uint32_t A = uint32_t(n_agents);
-    const bool scen = args.scen != nullptr, term = !args.state_not_terminal;
     note_kernel("lq_step_kernel<Q=%d,K=%d%s%s> block=%u (packed layout: %d agents per lane%s)", Q, K, scen ? ",SCEN" : "",
                 term ? "" : ",NO_TERMINAL", block, K, scen ? ", start / goal rows from the scenario table" : "");
 #define MAPF_LQ_LAUNCH(QQ, KK, SS, TT, SCEN_PTR)                                                                                   \
     hipLaunchKernelGGL((lq_step_kernel<QQ, KK, SS, TT>), dim3(grid), dim3(block), 0, stream, args.state, args.actions, SCEN_PTR,       \
-                       args.slip, args.t_dev, A | (block << 8), uint32_t(args.t), args.c.seed_lo, args.c.seed_hi, args)
+                       args.slip, args.t_dev, A | (block << 8), uint32_t(args.t), args.c.seed_lo, args.c.seed_hi, args, grid)
 #define MAPF_LQ_STEP(QQ, KK)                                                                                   \
     if (Q == QQ && K == KK) {                                                                                  \
-        const uint8_t *const no_scen = nullptr;                                                                \
         if (scen && term) MAPF_LQ_LAUNCH(QQ, KK, true, true, args.scen);                                       \
         else if (scen) MAPF_LQ_LAUNCH(QQ, KK, true, false, args.scen);                                         \
         else if (term) MAPF_LQ_LAUNCH(QQ, KK, false, true, no_scen);                                           \

@@ -166,15 +166,20 @@ def test_scenario_table_step_equals_plain_rows(monkeypatch, n_agents, n_envs):
         env.close()
 
 
-def test_single_step_at_a_batch_larger_than_the_device_holds():
-    """393216 envs x 8 agents = 3072 blocks of the packed single step: more than the 2048 an MI355X holds at once (8 waves
-    per SIMD), so blocks are dispatched in waves -- six steps against the C oracle."""
+@pytest.mark.parametrize('big', ['2', '0'])
+def test_single_step_at_a_batch_larger_than_the_device_holds(monkeypatch, big):
+    """393216 envs x 8 agents: more than an MI355X holds at once.  MAPF_STEP_BIG=2 forces the form the library uses from
+    1 M envs on -- a resident grid of 512 blocks of 1024 threads with the move table in LDS, walking 768 chunks (half
+    of the blocks take two) -- MAPF_STEP_BIG=0 the one-block-per-256-lanes form.  Six steps against the C oracle, the
+    first one with the is_terminal test (a state set by the caller), then without."""
+    monkeypatch.setenv('MAPF_STEP_BIG', big)
     E, A = 393216, 8
     grid, _, nbr, start, goal = _c3_tables(E)
     import philox
     ids = np.arange(E)
     env = VecMapfEnv(grid, A, None, None, 0.2, *R, OptimizationCriteria.SoC, seed=3, start_local=start, goal_local=goal)
     co = c_oracle.COracle(nbr, A, start, goal, 0.2, *R, mo.SOC, seed=3)
+    env.set_state(np.ascontiguousarray(start))            # (same cells; the library no longer knows they are not terminal)
     for t in range(6):
         acts = philox.random_actions_np(3, ids, t, A)
         local, reward, done, info = env.step(acts, auto_reset=True)
@@ -182,7 +187,43 @@ def test_single_step_at_a_batch_larger_than_the_device_holds():
         assert np.array_equal(local, ref['local']) and np.array_equal(_bits(reward), _bits(ref['reward'])), t
         assert np.array_equal(_bits(info['prob']), _bits(ref['prob'])) and np.array_equal(done, ref['done']), t
         assert np.array_equal(info['collision'], ref['collision']) and np.array_equal(info['was_terminal'], ref['was_terminal'])
-    assert np.array_equal(env.get_state()[0], co.state) and env.last_kernel('step').startswith('lq_step_kernel<Q=2,K=4,SCEN>')
+        name = env.last_kernel('step')
+        assert name.startswith('lq_step_kernel<Q=2,K=4,SCEN') and (',BIG>' in name) == (big == '2'), name
+        assert ('NO_TERMINAL' in name) == (t > 0), name
+    assert np.array_equal(env.get_state()[0], co.state)
+    env.close()
+
+
+@pytest.mark.parametrize('n_agents,n_envs', [(4, 4096), (16, 1024), (32, 512)])
+def test_big_form_of_the_single_step_at_other_team_sizes(monkeypatch, n_agents, n_envs):
+    """The resident-grid / LDS-table form at 4, 16 and 32 agents (one, four and eight lanes per env), forced on small
+    batches, goal-seeking actions so that episodes end; against the C oracle."""
+    import goal_scenarios
+    monkeypatch.setenv('MAPF_STEP_BIG', '2')
+    A, E = n_agents, n_envs
+    lines, start_loc, goal_loc = goal_scenarios.goal_scenario(A, E, 5150 + A)
+    grid = MapfGrid(lines)
+    valid, l2i, nbr = grid.tables()
+    ids = np.zeros((len(lines), len(lines[0])), np.uint16)
+    for loc, k in l2i.items():
+        ids[loc] = k
+    start = np.ascontiguousarray(ids[start_loc[..., 0], start_loc[..., 1]])
+    goal = np.ascontiguousarray(ids[goal_loc[..., 0], goal_loc[..., 1]])
+    rc = np.asarray([r | (c << 16) for r, c in valid], np.uint32)
+    env = VecMapfEnv(grid, A, None, None, 0.2, *R, OptimizationCriteria.Makespan, seed=21, start_local=start, goal_local=goal)
+    co = c_oracle.COracle(nbr, A, start, goal, 0.2, *R, mo.MAKESPAN, seed=21)
+    n_done = 0
+    for t in range(10):
+        acts = co.greedy_actions(rc)
+        auto = t % 4 != 3
+        local, reward, done, info = env.step(acts, auto_reset=auto)
+        ref = co.step(acts, auto_reset=auto)
+        assert np.array_equal(local, ref['local']) and np.array_equal(_bits(reward), _bits(ref['reward'])), t
+        assert np.array_equal(_bits(info['prob']), _bits(ref['prob'])) and np.array_equal(done, ref['done']), t
+        assert np.array_equal(info['collision'], ref['collision']) and np.array_equal(info['was_terminal'], ref['was_terminal']), t
+        assert np.array_equal(env.get_state()[0], co.state), t
+        n_done += int(done.sum())
+    assert ',BIG>' in env.last_kernel('step') and n_done > 0, env.last_kernel('step')
     env.close()
 
 
