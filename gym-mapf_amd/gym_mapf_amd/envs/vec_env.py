@@ -276,11 +276,16 @@ class VecMapfEnv:
         nat.check(self._lib.mapf_graph_steps(g, ctypes.byref(steps)))
         return StepGraph(self, g, steps.value)
 
+    # one launch addresses every array with 32-bit byte offsets and counts per-launch events in 16 bits (include/mapf_hip.h)
+    _MAX_ARRAY_BYTES = (1 << 32) - 1
+    _MAX_LAUNCH_STEPS = 65535
+
     def rollout(self, n_steps, actions=None, auto_reset=True, record=False, accumulate_into=None):
-        """``n_steps`` fused steps in one launch.  ``actions`` uint8 [T, E, A] or None for the
-        synthetic policy stream.  Returns a dict with ``returns`` f64 [E], ``episodes`` u32 [E],
-        ``collisions`` u32 [E] and, when ``record``, the per-step ``local``/``reward``/``done``/
-        ``collision``/``prob`` trajectories (step-major)."""
+        """``n_steps`` fused steps.  ``actions`` uint8 [T, E, A] or None for the on-device policy.  Returns a dict with
+        ``returns`` f64 [E], ``episodes`` u32 [E], ``collisions`` u32 [E] and, when ``record``, the per-step
+        ``local``/``reward``/``done``/``collision``/``prob`` trajectories (step-major).  One launch when every array
+        of the call stays below 4 GiB and T <= 65535 (the C ABI's limits); otherwise the steps are issued as a few
+        launches over consecutive slices of the same arrays (totals accumulate, the trajectory is identical)."""
         E, A, T = self.n_envs, self.n_agents, int(n_steps)
         actions = self._coerce(actions, np.uint8, (T, E, A), 'actions')
         res = accumulate_into if accumulate_into is not None else {}
@@ -292,21 +297,32 @@ class VecMapfEnv:
                                   ('done', np.uint8, (T, E)), ('collision', np.uint8, (T, E)),
                                   ('prob', np.float64, (T, E))):
                 res[name] = self._empty(shp, dt)
-        io = nat.MapfRolloutIO(
-            struct_size=ctypes.sizeof(nat.MapfRolloutIO), n_steps=T,
-            step_flags=nat.MAPF_STEP_AUTO_RESET if auto_reset else 0,
-            accumulate=1 if accumulate_into is not None else 0,
-            actions=self._ptr(actions, np.uint8, (T, E, A), 'actions'),
-            out_returns=self._ptr(res['returns'], np.float64, (E,), 'returns'),
-            out_episodes=self._ptr(res['episodes'], np.uint32, (E,), 'episodes'),
-            out_collisions=self._ptr(res['collisions'], np.uint32, (E,), 'collisions'),
-            rec_local=self._ptr(res.get('local') if record else None, np.uint16, (T, E, A), 'local'),
-            rec_reward=self._ptr(res.get('reward') if record else None, np.float64, (T, E), 'reward'),
-            rec_done=self._ptr(res.get('done') if record else None, np.uint8, (T, E), 'done'),
-            rec_collision=self._ptr(res.get('collision') if record else None, np.uint8, (T, E), 'collision'),
-            rec_prob=self._ptr(res.get('prob') if record else None, np.float64, (T, E), 'prob'))
-        nat.check(self._lib.mapf_rollout(self._h, ctypes.byref(io)))
-        return res
+        per_step = max(E * A * 2, E * 8) if (record or actions is not None) else 0    # bytes of the widest per-step row
+        t_max = min(self._MAX_LAUNCH_STEPS, self._MAX_ARRAY_BYTES // per_step if per_step else self._MAX_LAUNCH_STEPS)
+        if T > 0 and t_max < 1:
+            raise ValueError('one env-step of this batch exceeds 4 GiB: use fewer envs per handle')
+        first, accumulate = 0, accumulate_into is not None
+        while True:
+            n = min(T - first, t_max) if T else 0
+            sl = slice(first, first + n)
+            part = lambda name: res[name][sl] if record else None
+            io = nat.MapfRolloutIO(
+                struct_size=ctypes.sizeof(nat.MapfRolloutIO), n_steps=n,
+                step_flags=nat.MAPF_STEP_AUTO_RESET if auto_reset else 0, accumulate=1 if accumulate else 0,
+                actions=self._ptr(actions[sl] if actions is not None else None, np.uint8, (n, E, A), 'actions'),
+                out_returns=self._ptr(res['returns'], np.float64, (E,), 'returns'),
+                out_episodes=self._ptr(res['episodes'], np.uint32, (E,), 'episodes'),
+                out_collisions=self._ptr(res['collisions'], np.uint32, (E,), 'collisions'),
+                rec_local=self._ptr(part('local'), np.uint16, (n, E, A), 'local'),
+                rec_reward=self._ptr(part('reward'), np.float64, (n, E), 'reward'),
+                rec_done=self._ptr(part('done'), np.uint8, (n, E), 'done'),
+                rec_collision=self._ptr(part('collision'), np.uint8, (n, E), 'collision'),
+                rec_prob=self._ptr(part('prob'), np.float64, (n, E), 'prob'))
+            nat.check(self._lib.mapf_rollout(self._h, ctypes.byref(io)))
+            first += n
+            accumulate = True
+            if first >= T:
+                return res
 
     def transitions(self, local, actions, max_branches=None, env_index=None, first_branch=0, out=None):
         """``env.P[s][a]`` for N (state, joint action) queries (reference mapf_env.py:448-478): every branch of the

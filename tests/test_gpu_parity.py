@@ -769,6 +769,37 @@ def test_empty_batch_and_single_cell_map():
     one.close()
 
 
+def test_rollout_beyond_one_launch_is_issued_in_slices(monkeypatch):
+    """The C ABI rejects a launch whose largest array exceeds 4 GiB or that has more than 65535 steps; VecMapfEnv.rollout
+    then issues the steps as several launches over consecutive slices of the same arrays.  Forced here with a limit of
+    five steps per launch: 13 recorded steps in three launches == the same 13 steps in one, and == the C oracle."""
+    rs = np.random.RandomState(5)
+    lines = [''.join('@' if rs.rand() < 0.1 else '.' for _ in range(10)) for _ in range(10)]
+    grid = MapfGrid(lines)
+    valid, _, nbr = grid.tables()
+    V, E, A, T = len(valid), 256, 8, 13
+    start = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    goal = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    mk = lambda: VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.SoC, seed=4, start_local=start, goal_local=goal)
+    one, sliced = mk(), mk()
+    acts = np.stack([philox.random_actions_np(4, np.arange(E), t, A) for t in range(T)])
+    whole = one.rollout(T, actions=acts, auto_reset=True, record=True)
+    monkeypatch.setattr(VecMapfEnv, '_MAX_LAUNCH_STEPS', 5)
+    parts = sliced.rollout(T, actions=acts, auto_reset=True, record=True)
+    for k in ('local', 'done', 'collision', 'episodes', 'collisions'):
+        assert np.array_equal(whole[k], parts[k]), k
+    for k in ('reward', 'prob', 'returns'):
+        assert np.array_equal(_bits(whole[k]), _bits(parts[k])), k
+    co = c_oracle.COracle(nbr, A, start, goal, 0.2, -1000.0, 100.0, -1.0, mo.SOC, seed=4)
+    ref = co.rollout(T, actions=acts, auto_reset=True)
+    assert np.array_equal(_bits(parts['returns']), _bits(ref['returns'])) and np.array_equal(parts['episodes'], ref['episodes'])
+    assert sliced.t == one.t == T and np.array_equal(sliced.get_state()[0], co.state)
+    more = sliced.rollout(7, auto_reset=True, accumulate_into={k: parts[k] for k in ('returns', 'episodes', 'collisions')})   # policy, no arrays: one launch
+    ref2 = co.rollout(7, auto_reset=True)
+    assert np.array_equal(more['episodes'], ref['episodes'] + ref2['episodes'])
+    one.close(), sliced.close()
+
+
 def test_out_of_range_actions_are_stay_and_device_pointers_must_be_aligned():
     import torch
     grid = MapfGrid(['....', '....'])
