@@ -248,11 +248,11 @@ def measured_valu(kernel, n_envs, n_agents, steps_per_launch):
     return None
 
 
-def spawn_ranks(n, deadline_s):
+def spawn_ranks(n, deadline_s, command=None):
     """`python bench.py --gpus N` with no launcher: start one child per GPU (before this process makes any GPU
     call -- it makes none at all), wait for them, and exit with the first failure's code.  Rank 0 prints the line.
     A rank that has not finished `deadline_s` seconds after the start (stuck in a collective, a hung device) takes
-    every rank down with it: exit code 124."""
+    every rank down with it: exit code 124.  (`command` replaces the rank's command line: tests.)"""
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
@@ -261,7 +261,7 @@ def spawn_ranks(n, deadline_s):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        procs.append(subprocess.Popen(command or [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     pending = list(procs)
     t_end = time.monotonic() + deadline_s

@@ -270,6 +270,50 @@ def test_step_drops_is_terminal_only_when_no_env_can_be_terminal():
     env.close()
 
 
+def test_recording_with_the_callers_own_kernels_on_a_shared_stream():
+    """INTEGRATION.md's loop: the env enqueues on a stream the caller owns (a torch stream), the caller's policy -- torch
+    kernels reading the zero-copy state view and writing the action tensor in place -- and ONE mapf_step are recorded
+    together and replayed 40 times; every replay must see the state the previous one left and draw fresh random
+    numbers.  The same policy in numpy drives the C oracle."""
+    import torch
+    E, A = 4096, 8
+    grid, _, nbr, start, goal = _c3_tables(E)
+    stream = torch.cuda.Stream()
+    env = VecMapfEnv(grid, A, None, None, 0.2, *R, OptimizationCriteria.Makespan, seed=13, device_arrays=True,
+                     start_local=start, goal_local=goal, stream=stream.cuda_stream)
+    co = c_oracle.COracle(nbr, A, start, goal, 0.2, *R, mo.MAKESPAN, seed=13)
+    with torch.cuda.stream(stream):
+        obs = env.state_view()
+        actions = torch.zeros((E, A), dtype=torch.uint8, device='cuda')
+        tmp = torch.zeros((E, A), dtype=torch.int32, device='cuda')
+        lane = (torch.arange(E * A, dtype=torch.int32, device='cuda') % 7).view(E, A)
+        total = torch.zeros(E, dtype=torch.float64, device='cuda')
+        stream.synchronize()
+        env.graph_begin()
+        tmp.copy_(obs)                               # the "policy": a = (cell + lane pattern) mod 5, all in place
+        tmp.add_(lane)
+        tmp.remainder_(5)
+        actions.copy_(tmp)
+        call, out = env.prepare_step(actions, auto_reset=True, write_local=False)
+        call()
+        total.add_(out['reward'])                    # a consumer of the step's outputs, recorded as well
+        graph = env.graph_end()
+        lane_host = lane.cpu().numpy()
+        ref_total = np.zeros(E)
+        for rep in range(40):
+            graph.launch(1)
+            stream.synchronize()
+            acts = ((co.state.astype(np.int32) + lane_host) % 5).astype(np.uint8)
+            assert np.array_equal(actions.cpu().numpy(), acts), rep
+            ref = co.step(acts, auto_reset=True)
+            _check(out, ref, 'replay %d' % rep, local=False)
+            assert np.array_equal(obs.cpu().numpy(), co.state), rep
+            ref_total = ref_total + ref['reward']
+        assert np.array_equal(_bits(total.cpu().numpy()), _bits(ref_total)) and env.t == 40
+        graph.close()
+    env.close()
+
+
 def test_recording_is_refused_where_it_cannot_work():
     grid = MapfGrid(['....', '....'])
     kw = dict(start_local=np.array([[0, 5]], np.uint16).repeat(64, 0), goal_local=np.array([[7, 2]], np.uint16).repeat(64, 0))

@@ -111,3 +111,29 @@ def test_bench_workloads_depend_on_global_env_ids_only():
     b = bench.workload_tables(bench.CONFIGS['c3'], 24, 98304)
     assert np.array_equal(a[3], b[3][7:19]) and np.array_equal(a[4], b[4][7:19])
     assert bench.bytes_per_agent_step(8) == 7.25 and bench.bytes_per_agent_step(32) == 5.5625
+
+
+def test_self_launched_ranks_share_a_deadline_and_the_first_failure_stops_the_rest(tmp_path):
+    """bench.spawn_ranks (`python bench.py --gpus N` without a launcher): every child gets RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_*; a rank still running at the deadline has ALL ranks terminated and the parent exits 124; a failing rank
+    stops the others and its exit code is the parent's; all ranks succeeding exits 0."""
+    import time
+    import pytest
+    sys.path.insert(0, ROOT)
+    import bench
+    stamp = str(tmp_path / 'rank')
+    child = ("import os, sys, time; open(%r + os.environ['RANK'], 'w').write(os.environ['WORLD_SIZE'] + ' ' + os.environ['LOCAL_RANK'] + ' ' "
+             "+ os.environ['MASTER_ADDR']); mode = sys.argv[1]; r = int(os.environ['RANK']); "
+             "time.sleep(60 if mode == 'hang' and r == 1 else 0.2); sys.exit(7 if mode == 'fail' and r == 0 else 0)" % stamp)
+    t0 = time.monotonic()
+    with pytest.raises(SystemExit) as done:
+        bench.spawn_ranks(3, 2.0, [sys.executable, '-c', child, 'hang'])
+    assert done.value.code == 124 and time.monotonic() - t0 < 20                      # rank 1 did not get its 60 s
+    for r in range(3):
+        assert open(stamp + str(r)).read() == '3 %d 127.0.0.1' % r
+    with pytest.raises(SystemExit) as done:
+        bench.spawn_ranks(2, 30.0, [sys.executable, '-c', child, 'fail'])
+    assert done.value.code == 7
+    with pytest.raises(SystemExit) as done:
+        bench.spawn_ranks(2, 30.0, [sys.executable, '-c', child, 'ok'])
+    assert done.value.code == 0
