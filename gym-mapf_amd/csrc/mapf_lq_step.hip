@@ -4,11 +4,10 @@
 // counts, ragged batches) stays with lg_step_kernel (mapf_lg_kernels.hip), whose semantics this kernel reproduces
 // line by line.
 //
-// A single step is launch- and latency-bound (three dependent round trips: state/actions -> table row -> stores), so
-// nothing is staged into LDS: the 16-byte table rows are gathered from global memory (L2-resident), the sampled
-// probability is rebuilt from the slot's members (no read of the slip rows on the common path), the reward is
-// computed in registers.  What the packed layout buys is fewer waves and fewer replicated per-env instructions -- it
-// shows at large batches (profiles/r02_single_step_scaling.txt).
+// A single step is launch- and latency-bound (argument block -> state / actions -> table rows -> stores, with ~290 vector
+// instructions in between and ~1 us of dispatch overhead around it): what the kernel is built around is described at its
+// template below; the measurements behind every choice are profiles/r03_step_stamps_*.txt, r03_single_step_scaling.txt,
+// r03_step_index_costs.txt and r03_kernel_end_costs.txt.
 #include "mapf_lq.hpp"
 
 #include <type_traits>
@@ -87,13 +86,16 @@ constexpr uint32_t kStepSlipAt = 0, kStepOutcomeAt = sizeof(SlipRow) * 8, kStepL
 //     lanes: the table rows become ds_read_b128 (a quarter of the cost), and the argument block, the LDS image and the
 //     barrier are paid once per block instead of once per chunk.
 constexpr uint32_t kStepMoveAt = 1024;
+// offset of the StepArgs block in the kernel's argument segment: five pointers and four 32-bit scalars precede it
+constexpr uint32_t kStepArgsOffset = 5 * 8 + 4 * 4;
+static_assert(kStepArgsOffset % alignof(StepArgs) == 0, "the block follows the leading scalars without padding");
 static_assert(kStepLds <= kStepMoveAt, "LDS image of the BIG form: slip rows, outcome rows, then the move table");
 
 template <int Q, int K, bool SCEN, bool TERM, bool BIG = false>
 __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *const state, const uint8_t *const actions, const uint8_t *const scen,
                                                       const SlipRow *const slip_rows, const uint64_t *const t_dev,
                                                       const uint32_t agents_block, const uint32_t t_lo, const uint32_t seed_lo,
-                                                      const uint32_t seed_hi, const StepArgs p, const uint32_t n_chunks) {
+                                                      const uint32_t seed_hi, const StepArgs p_block, const uint32_t n_chunks) {
     constexpr int P = K / 2;
 #ifdef MAPF_STEP_STAMPS
     unsigned long long stamp_[8] = {}, real0_, cyc0_;
@@ -112,22 +114,34 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
     if (uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lds_image)) != 0u) __builtin_trap();
     const uint32_t n_agents = agents_block & 0xFFu, block_threads = agents_block >> 8;
     if (BIG) {   // move table -> LDS (16-byte rows, five columns), four independent loads per thread and round
-        const uint32_t n_rows = p.c.n_cells * 5u;
+        const uint32_t n_rows = p_block.c.n_cells * 5u;
         MoveEntry *const dst = reinterpret_cast<MoveEntry *>(lds_image + kStepMoveAt);
         for (uint32_t w0 = threadIdx.x; w0 < n_rows; w0 += 4u * block_threads) {
             const uint32_t w1 = w0 + block_threads, w2 = w1 + block_threads, w3 = w2 + block_threads, last = n_rows - 1u;
-            const MoveEntry r0 = p.mv[w0], r1 = p.mv[min(w1, last)], r2 = p.mv[min(w2, last)], r3 = p.mv[min(w3, last)];
+            const MoveEntry r0 = p_block.mv[w0], r1 = p_block.mv[min(w1, last)], r2 = p_block.mv[min(w2, last)], r3 = p_block.mv[min(w3, last)];
             dst[w0] = r0;
             if (w1 < n_rows) dst[w1] = r1;
             if (w2 < n_rows) dst[w2] = r2;
             if (w3 < n_rows) dst[w3] = r3;
         }
         // ... and the slip / outcome rows, behind ONE barrier: every chunk of the block then finds the whole image in place
-        stage_outcome_table(p.c, reinterpret_cast<OutcomeRow *>(lds_image + kStepOutcomeAt));
+        stage_outcome_table(p_block.c, reinterpret_cast<OutcomeRow *>(lds_image + kStepOutcomeAt));
         stage_slip_table(slip_rows, reinterpret_cast<SlipRow *>(lds_image + kStepSlipAt));   // ends with __syncthreads()
     }
     // (!BIG: one block per 256 lanes, one pass.  A resident grid WITHOUT the LDS table was measured 6-8 % slower than that.)
     auto one_chunk = [&](const uint32_t chunk, auto first_tag) __attribute__((always_inline)) {
+    // BIG: the loop would keep every field of the argument block live in SGPRs across iterations (106 of them, one block per
+    // CU); the fields are re-read from the kernarg segment through a pointer the optimiser cannot see through, so that they
+    // are fetched where an iteration uses them, as in the straight-line form (scalar cache hits).
+    union { StepArgs args; uint32_t words[sizeof(StepArgs) / 4]; } reread;
+    if constexpr (BIG) {
+        using KernWord = const __attribute__((address_space(4))) uint32_t;
+        KernWord *ka = (KernWord *)((const __attribute__((address_space(4))) char *)__builtin_amdgcn_kernarg_segment_ptr() + kStepArgsOffset);
+        asm volatile("" : "+s"(ka));
+#pragma unroll
+        for (uint32_t i = 0; i < sizeof(StepArgs) / 4; ++i) reread.words[i] = ka[i];
+    }
+    const StepArgs &p = BIG ? reread.args : p_block;
     constexpr bool first_pass = decltype(first_tag)::value;   // !BIG: the LDS image is written behind the chunk's first loads
     LaneCtx<Q> x;
     x.lane = threadIdx.x & 63u;
@@ -351,7 +365,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
     } else {
         one_chunk(blockIdx.x, std::true_type{});
     }
-    signal_step_done(p.done_flag, p.done_seq);
+    signal_step_done(p_block.done_flag, p_block.done_seq);
 }
 
 }  // namespace
