@@ -3,6 +3,7 @@
 #include "mapf_hip.h"
 #include "mapf_kernels.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -118,7 +119,7 @@ struct mapf_handle_s {
     uint64_t *t_dev = nullptr;
     uint64_t t_dev_value = 0, cap_steps = 0;
     bool capturing = false;
-    int live_graphs = 0;
+    std::vector<struct mapf_graph_s *> graphs;   // recordings that are still alive (destroyed with the handle at the latest)
 };
 
 struct mapf_graph_s {
@@ -143,6 +144,19 @@ int check_handle(mapf_handle_t h) {
 // cannot run between mapf_graph_begin and mapf_graph_end
 int check_not_recording(mapf_handle_t h, const char *what) {
     if (h->capturing) return fail(MAPF_EINVAL, std::string(what) + ": not allowed while a graph is being recorded (call mapf_graph_end first)");
+    return MAPF_OK;
+}
+
+// A step or rollout enqueued while somebody ELSE is capturing the stream (a caller-owned stream under torch.cuda.graph /
+// hipStreamBeginCapture) would bake the handle's current step index into the captured launch: every replay would reuse
+// the same random numbers, silently.  Only mapf_graph_begin knows how to record a launch (device-side step index).
+int check_foreign_capture(mapf_handle_t h, const char *what) {
+    if (h->capturing || h->own_stream) return MAPF_OK;        // (nobody else can capture a stream the handle created)
+    hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &status) != hipSuccess) { (void)hipGetLastError(); return MAPF_OK; }
+    if (status != hipStreamCaptureStatusNone)
+        return fail(MAPF_EINVAL, std::string(what) + ": the stream is being captured outside mapf_graph_begin -- the launch would bake its "
+                                 "step index (and random numbers) into the graph; record it between mapf_graph_begin and mapf_graph_end");
     return MAPF_OK;
 }
 
@@ -248,6 +262,12 @@ void destroy_impl(mapf_handle_t h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (mapf_graph_s *g : h->graphs) {   // recordings name the handle's buffers: they go first
+        if (g->exec) (void)hipGraphExecDestroy(g->exec);
+        if (g->graph) (void)hipGraphDestroy(g->graph);
+        delete g;
+    }
+    h->graphs.clear();
     for (DeviceBuf *b : {&h->s_actions, &h->s_uniforms, &h->s_local, &h->s_reward, &h->s_prob, &h->s_done,
                          &h->s_coll, &h->s_term, &h->s_mask, &h->s_ret, &h->s_epi, &h->s_ncoll, &h->x_local, &h->x_reward,
                          &h->x_prob, &h->x_done, &h->x_coll, &h->q_local, &h->q_actions, &h->q_env, &h->q_count, &h->q_next,
@@ -523,6 +543,7 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     if (int rc = check_handle(h)) return rc;
     if (!actions) return fail(MAPF_EINVAL, "actions is null");
     if (step_flags & ~MAPF_STEP_AUTO_RESET) return fail(MAPF_EINVAL, "unknown step flag");
+    if (int rc = check_foreign_capture(h, "mapf_step")) return rc;
     if (int rc = check_extent(h, h->E, uniforms != nullptr)) return rc;
     const size_t E = size_t(h->E), EA = E * h->A;
     mapf::StepArgs a{};
@@ -631,6 +652,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     if (int rc = check_handle(h)) return rc;
     if (!io || io->struct_size != sizeof(mapf_rollout_io)) return fail(MAPF_EINVAL, "bad mapf_rollout_io");
     if (io->step_flags & ~MAPF_STEP_AUTO_RESET) return fail(MAPF_EINVAL, "unknown step flag");
+    if (int rc = check_foreign_capture(h, "mapf_rollout")) return rc;
     if (int rc = check_extent(h, uint64_t(h->E) * io->n_steps, false)) return rc;
     const size_t E = size_t(h->E), T = io->n_steps, TE = T * E, TEA = TE * h->A;
     mapf::RolloutArgs a{};
@@ -700,7 +722,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
 int mapf_set_policy(mapf_handle_t h, int policy, const uint32_t *cell_rc) {
     if (int rc = check_handle(h)) return rc;
     if (int rc = check_not_recording(h, "mapf_set_policy")) return rc;
-    if (h->live_graphs > 0) return fail(MAPF_EINVAL, "set_policy: recorded graphs hold the current policy table (destroy them first)");
+    if (!h->graphs.empty()) return fail(MAPF_EINVAL, "set_policy: recorded graphs hold the current policy table (destroy them first)");
     if (policy != MAPF_POLICY_RANDOM && policy != MAPF_POLICY_GREEDY) return fail(MAPF_EINVAL, "set_policy: unknown policy");
     HIP_TRY(hipStreamSynchronize(h->stream));   // no launch may still be reading the old table
     if (policy == MAPF_POLICY_RANDOM) {
@@ -900,7 +922,7 @@ int mapf_graph_end(mapf_handle_t h, mapf_graph_t *out_graph) {
     g->ends_may_be_terminal = h->cap_may_be_terminal;
     const hipError_t inst = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
     if (inst != hipSuccess) { (void)hipGraphDestroy(graph); delete g; return hip_fail(inst, "hipGraphInstantiate"); }
-    h->live_graphs += 1;
+    h->graphs.push_back(g);
     *out_graph = g;
     return MAPF_OK;
 }
@@ -908,7 +930,7 @@ int mapf_graph_end(mapf_handle_t h, mapf_graph_t *out_graph) {
 int mapf_graph_launch(mapf_handle_t h, mapf_graph_t g, uint32_t n_replays) {
     if (int rc = check_handle(h)) return rc;
     if (int rc = check_not_recording(h, "mapf_graph_launch")) return rc;
-    if (!g || g->owner != h) return fail(MAPF_EINVAL, "graph_launch: not a graph of this handle");
+    if (!g || std::find(h->graphs.begin(), h->graphs.end(), g) == h->graphs.end()) return fail(MAPF_EINVAL, "graph_launch: not a live graph of this handle");
     // the device-side index must hold the handle's step index when the first recorded launch reads it
     if (h->t_dev_value != h->t) {
         HIP_TRY(mapf::launch_set_step_index(h->t_dev, h->t, h->stream));
@@ -929,11 +951,12 @@ int mapf_graph_steps(mapf_graph_t g, uint64_t *out_steps) {
 
 int mapf_graph_destroy(mapf_handle_t h, mapf_graph_t g) {
     if (int rc = check_handle(h)) return rc;
-    if (!g || g->owner != h) return fail(MAPF_EINVAL, "graph_destroy: not a graph of this handle");
+    const auto it = g ? std::find(h->graphs.begin(), h->graphs.end(), g) : h->graphs.end();
+    if (it == h->graphs.end()) return fail(MAPF_EINVAL, "graph_destroy: not a live graph of this handle");
     HIP_TRY(hipStreamSynchronize(h->stream));   // no replay may still be running
     if (g->exec) (void)hipGraphExecDestroy(g->exec);
     if (g->graph) (void)hipGraphDestroy(g->graph);
-    h->live_graphs -= 1;
+    h->graphs.erase(it);
     delete g;
     return MAPF_OK;
 }

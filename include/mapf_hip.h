@@ -227,7 +227,10 @@ int mapf_state_view(mapf_handle_t h, const uint16_t **out_state);
  * fresh random numbers: K replays of an N-step recording produce exactly the results of K*N mapf_step calls with the same
  * arguments.  The arrays named in recorded calls must stay allocated while the graph lives.  Calls that wait for the
  * stream or move the step index from the host (mapf_sync, mapf_timer_*, mapf_get_state, mapf_set_state, mapf_set_policy)
- * fail with MAPF_EINVAL while recording, as does recording on a host-pointer handle.
+ * fail with MAPF_EINVAL while recording, as does recording on a host-pointer handle.  A mapf_step / mapf_rollout enqueued while
+ * the CALLER captures the stream it gave the handle (hipStreamBeginCapture, torch.cuda.graph) is refused too: it would
+ * bake its step index -- and random numbers -- into the caller's graph; record it here instead.  Recordings that are
+ * still alive are destroyed with their handle.
  */
 typedef struct mapf_graph_s *mapf_graph_t;
 int mapf_graph_begin(mapf_handle_t h);

@@ -337,3 +337,25 @@ def test_recording_is_refused_where_it_cannot_work():
     assert dev.t == 0
     g.close()
     dev.close()
+    # a stream the CALLER captures (torch.cuda.graph): a step enqueued there would bake its step index into the graph and
+    # replay the same random numbers for ever -- refused, loudly
+    import torch
+    stream = torch.cuda.Stream()
+    ext = VecMapfEnv(grid, 2, None, None, 0.2, -1.0, 1.0, -1.0, OptimizationCriteria.SoC, device_arrays=True,
+                     stream=stream.cuda_stream, **kw)
+    acts = torch.zeros((64, 2), dtype=torch.uint8, device='cuda')
+    call, out = ext.prepare_step(acts)
+    call()                                           # fine outside a capture
+    ext.sync()
+    foreign = torch.cuda.CUDAGraph()
+    with pytest.raises(nat.MapfNativeError) as err:
+        with torch.cuda.graph(foreign, stream=stream):
+            call()
+    assert 'mapf_graph_begin' in str(err.value)
+    ext.graph_begin()                                # the library's own recording on that stream still works
+    call()
+    own = ext.graph_end()
+    own.launch(2)
+    ext.sync()
+    assert ext.t == 3
+    ext.close()                                      # (destroys the recording with the handle)
