@@ -157,8 +157,10 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
     // the slip rows (96 eight-byte words) for the LDS copy
     uint32_t c[P], g[P], sc[P];
     const Packed<P> cells = Packed<P>::load(at(state, lane_cell));
-    const uint32_t raw = K == 4 ? *reinterpret_cast<const uint32_t *>(at(actions, lane_cell))
-                                : uint32_t(*reinterpret_cast<const uint16_t *>(at(actions, lane_cell)));
+    uint64_t raw;                                                   // one action byte per agent of the lane
+    if constexpr (K == 8) raw = *reinterpret_cast<const uint64_t *>(at(actions, lane_cell));
+    else raw = K == 4 ? uint64_t(*reinterpret_cast<const uint32_t *>(at(actions, lane_cell)))
+                      : uint64_t(*reinterpret_cast<const uint16_t *>(at(actions, lane_cell)));
     uint32_t scen_id = 0u;
     Packed<P> gl{}, sl{};
     if (SCEN) scen_id = *at(scen, e);
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         cur[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu;
-        const uint32_t byte = (raw >> (8 * k)) & 0xFFu;
+        const uint32_t byte = uint32_t(raw >> (8 * k)) & 0xFFu;
         act[k] = byte > 4u ? 0u : byte;
         if (BIG) entry[k] = lds_entry_at(kStepMoveAt + (__umul24(min(cur[k], p.c.n_cells - 1u), 5u) + act[k]) * 16u);
         else entry[k] = move_entry<true>(p.mv, p.c.n_cells, cur[k], act[k]);
@@ -388,14 +390,47 @@ bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning 
     const uint32_t A = uint32_t(n_agents);
     const bool scen = args.scen != nullptr, term = !args.state_not_terminal;
     const uint8_t *const no_scen = nullptr;
-    // The BIG form (resident grid, move table in LDS): batches of at least four times what the device holds at once (8 agents:
-    // from 1 M envs; measured break-even at 0.5 M, +5 % at 1 M, +13 % at 2 M, +33 % at 4 M -- profiles/r03_single_step_scaling.txt),
-    // four agents per lane, a table that leaves room for two 1024-thread blocks per CU.  MAPF_STEP_BIG=0 never, =2 whenever it fits.
+    // The BIG form (resident grid, move table in LDS): batches several times what the device holds at once
+    // (profiles/r03_single_step_scaling.txt), a table that leaves room for two 1024-thread blocks per CU.
+    // MAPF_STEP_BIG=0 never, =2 whenever it fits.
     const size_t big_lds = kStepMoveAt + size_t(args.c.n_cells) * 5u * sizeof(MoveEntry);
     int n_cu = 256, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
-    const bool big = K == 4 && Q <= 8 && tune.step_big != 0 && args.n_envs > 0 && args.n_envs % (1024u / unsigned(Q)) == 0 &&
-                     2u * big_lds <= 160u * 1024u && (tune.step_big == 2 || lanes >= 4u * uint64_t(n_cu) * 2048u);
+    const uint64_t resident_lanes = uint64_t(n_cu) * 2048u;
+    const bool big_fits = K == 4 && Q <= 8 && tune.step_big != 0 && args.n_envs > 0 && args.n_envs % (1024u / unsigned(Q)) == 0 &&
+                          2u * big_lds <= 160u * 1024u;
+    const bool big = big_fits && (tune.step_big == 2 || lanes >= 4u * resident_lanes);
+    // ... with EIGHT agents per lane where the team allows it (8, 16, 32 agents): the large-batch step is bound by its vector
+    // instructions once the gathers are gone, and what a lane does once per env (lane context, flags, outcome row, stores,
+    // the hand-over of the probability product) is then paid for 64 envs per wave instead of 32
+    // (measured, 8 agents: 0.289 against 0.262 at 0.5 M envs, 0.35 / 0.41 / 0.42 at 1 / 2 / 4 M -- this form from TWICE the
+    // device's resident lanes on, the four-agents-per-lane form below from four times)
+    if (big_fits && (tune.step_big == 2 || lanes >= 2u * resident_lanes) && Q >= 2 && args.n_envs % (1024u / unsigned(Q / 2)) == 0 &&
+        tune.force_k != 4) {
+        const int Q8 = Q / 2;
+        const unsigned block = 1024u, n_chunks = unsigned(args.n_envs * uint64_t(Q8) / block), grid = n_chunks < unsigned(n_cu) ? n_chunks : unsigned(n_cu);
+        note_kernel("lq_step_kernel<Q=%d,K=8%s%s,BIG> block=1024 resident grid (packed layout: 8 agents per lane, move table in LDS%s)", Q8,
+                    scen ? ",SCEN" : "", term ? "" : ",NO_TERMINAL", scen ? ", start / goal rows from the scenario table" : "");
+#define MAPF_LQ_BIG8(QQ, SS, TT, SCEN_PTR)                                                                                          \
+        {                                                                                                                           \
+            auto kern = lq_step_kernel<QQ, 8, SS, TT, true>;                                                                        \
+            if (big_lds > 32u * 1024u) { if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), int(160u * 1024u - 1024u))) { *err = e; return true; } } \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(block), big_lds, stream, args.state, args.actions, SCEN_PTR, args.slip, args.t_dev, \
+                               A | (block << 8), uint32_t(args.t), args.c.seed_lo, args.c.seed_hi, args, n_chunks);                 \
+        }
+#define MAPF_LQ_BIG8_Q(QQ)                                                                       \
+        if (Q8 == QQ) {                                                                           \
+            if (scen && term) MAPF_LQ_BIG8(QQ, true, true, args.scen)                             \
+            else if (scen) MAPF_LQ_BIG8(QQ, true, false, args.scen)                               \
+            else if (term) MAPF_LQ_BIG8(QQ, false, true, no_scen)                                 \
+            else MAPF_LQ_BIG8(QQ, false, false, no_scen)                                          \
+            *err = hipGetLastError();                                                             \
+            return true;                                                                          \
+        }
+        MAPF_LQ_BIG8_Q(1) MAPF_LQ_BIG8_Q(2) MAPF_LQ_BIG8_Q(4)
+#undef MAPF_LQ_BIG8_Q
+#undef MAPF_LQ_BIG8
+    }
     if (big) {
         const unsigned block = 1024u, n_chunks = unsigned(lanes / block), grid = n_chunks < 2u * unsigned(n_cu) ? n_chunks : 2u * unsigned(n_cu);
         note_kernel("lq_step_kernel<Q=%d,K=%d%s%s,BIG> block=1024 resident grid (packed layout: 4 agents per lane, move table in LDS%s)", Q, K,

@@ -166,13 +166,16 @@ def test_scenario_table_step_equals_plain_rows(monkeypatch, n_agents, n_envs):
         env.close()
 
 
-@pytest.mark.parametrize('big', ['2', '0'])
+@pytest.mark.parametrize('big', ['2', '2k4', '0'])
 def test_single_step_at_a_batch_larger_than_the_device_holds(monkeypatch, big):
     """393216 envs x 8 agents: more than an MI355X holds at once.  MAPF_STEP_BIG=2 forces the form the library uses from
     1 M envs on -- a resident grid of 512 blocks of 1024 threads with the move table in LDS, walking 768 chunks (half
     of the blocks take two) -- MAPF_STEP_BIG=0 the one-block-per-256-lanes form.  Six steps against the C oracle, the
     first one with the is_terminal test (a state set by the caller), then without."""
-    monkeypatch.setenv('MAPF_STEP_BIG', big)
+    monkeypatch.setenv('MAPF_STEP_BIG', big[0])
+    if big == '2k4':
+        monkeypatch.setenv('MAPF_LQ_K', '4')                      # (the BIG form prefers eight agents per lane: pin four)
+    expect = {'2': 'lq_step_kernel<Q=1,K=8,SCEN', '2k4': 'lq_step_kernel<Q=2,K=4,SCEN', '0': 'lq_step_kernel<Q=2,K=4,SCEN'}[big]
     E, A = 393216, 8
     grid, _, nbr, start, goal = _c3_tables(E)
     import philox
@@ -188,7 +191,7 @@ def test_single_step_at_a_batch_larger_than_the_device_holds(monkeypatch, big):
         assert np.array_equal(_bits(info['prob']), _bits(ref['prob'])) and np.array_equal(done, ref['done']), t
         assert np.array_equal(info['collision'], ref['collision']) and np.array_equal(info['was_terminal'], ref['was_terminal'])
         name = env.last_kernel('step')
-        assert name.startswith('lq_step_kernel<Q=2,K=4,SCEN') and (',BIG>' in name) == (big == '2'), name
+        assert name.startswith(expect) and (',BIG>' in name) == (big != '0'), name
         assert ('NO_TERMINAL' in name) == (t > 0), name
     assert np.array_equal(env.get_state()[0], co.state)
     env.close()
