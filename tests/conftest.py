@@ -12,10 +12,6 @@ for p in (os.path.join(ROOT, 'gym-mapf_amd'), os.path.join(ROOT, 'oracle'), ROOT
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# The packed rollout layout uses four agents per lane only for batches that put a wave on every SIMD (>= 65536 lanes on
-# an MI355X); the parity tests reach it with small batches by lifting that threshold (read whenever a handle is created).
-os.environ.setdefault('MAPF_QUAD_MIN_LANES', '0')
-
 TRAJECTORY_SETS = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith('.npz'))
 
 

@@ -544,7 +544,7 @@ def test_config3_room32_8agents_65536_envs():
 
 def test_config4_share_32768_envs_under_default_dispatch(monkeypatch):
     """BASELINE configs[3]: 262144 room-32-32-4 envs over 8 GPUs -- rank 3's share (global env ids 98304 .. 131071)
-    with the library's DEFAULT layout choice (the suite otherwise lifts the quad-layout threshold, conftest.py)."""
+    with the library's DEFAULT layout choice (as every test since round 3: layouts are forced only where a test names one)."""
     import bench
     from gym_mapf_amd import sharding
     monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
