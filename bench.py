@@ -58,6 +58,7 @@ import numpy as np  # noqa: E402
 
 R_CLASH, R_GOAL, R_LIVING = -1000.0, 100.0, -1.0
 SEED = 42
+SHARD_GRANULE = 1024           # strong-scaling shards are multiples of this many envs (whole blocks of every packed kernel form)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.3 TB/s achievable)
 
 CONFIGS = {
@@ -307,6 +308,9 @@ def main():
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' + --share-device rehearses the N > 1 path on a one-GPU box")
     ap.add_argument('--share-device', action='store_true', help='every rank uses cuda:0 (rehearsal only)')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise torch.distributed and run the collective legs (MAX all-reduce, gather of the returns) even '
+                         'with --gpus 1: with --dist-backend nccl this is RCCL at world size 1 -- what a one-GPU box can verify')
     ap.add_argument('--repeats', type=int, default=5, help='timed blocks of --steps steps each; value = their median')
     ap.add_argument('--rank-timeout', type=float, default=900.0,
                     help='self-launched ranks (--gpus N without a launcher) are all terminated after this many seconds')
@@ -330,9 +334,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if world == 1:   # --force-dist without a launcher
+            os.environ.setdefault('MASTER_PORT', str(29500 + os.getpid() % 2000))
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         if args.dist_backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
@@ -352,7 +360,7 @@ def main():
         offset, E = sharding.shard_offset(cfg['envs'], rank), cfg['envs']
         total_envs = cfg['envs'] * world
     else:
-        offset, E = sharding.split_evenly(cfg['envs'], rank, world)
+        offset, E = sharding.split_evenly(cfg['envs'], rank, world, granule=SHARD_GRANULE)
         total_envs = cfg['envs']
     grid, _, nbr, start, goal = workload_tables(cfg, E, offset)
     env = VecMapfEnv(grid, A, None, None, cfg['fail_prob'], R_CLASH, R_GOAL, R_LIVING, OptimizationCriteria.Makespan,
@@ -503,7 +511,7 @@ def main():
     if dist is not None:
         # the one collective of the path: gather per-env episode returns
         env.sync()
-        counts = [sharding.split_evenly(cfg['envs'], r, world)[1] for r in range(world)] if scaling == 'strong' else [E] * world
+        counts = [sharding.split_evenly(cfg['envs'], r, world, granule=SHARD_GRANULE)[1] for r in range(world)] if scaling == 'strong' else [E] * world
         gathered = sharding.gather_returns(acc['returns'] if coll_dev == 'cuda' else acc['returns'].cpu(), counts=counts)
         torch.cuda.synchronize()
         assert gathered.numel() == total_envs, (gathered.numel(), total_envs)
@@ -582,6 +590,13 @@ def main():
                                  "in registers, so it moves fewer bytes than the per-step contract credits)"},
             "parity": parity,
         }
+        if args.share_device and world > 1:
+            # every rank ran on cuda:0: a plumbing rehearsal of the N > 1 path, NOT a multi-GPU measurement -- the counters
+            # under profiles/ describe one process alone on the device and do not apply
+            line["rehearsal"] = True
+            line["physical_gpus"] = 1
+            for key in ("traffic", "traffic_frac", "valu_frac", "valu_insts_per_launch"):
+                line["roofline"][key] = None
         if gather_info is not None:
             line["gather"] = gather_info
         if single is not None:

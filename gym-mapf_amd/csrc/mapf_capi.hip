@@ -86,6 +86,7 @@ struct mapf_handle_s {
     uint64_t E = 0, env_id_offset = 0, t = 0;
     mapf::EnvConsts c{};
     bool start_broadcast = false, goal_broadcast = false, device_ptrs = false, own_stream = false;
+    bool stream_exposed = false;   // mapf_get_stream was called: somebody else may capture the stream (check_foreign_capture)
     bool lane_group = false;   // kernel family
     // The thread-per-env rollout specialisations for A >= 8 need SGPR spills (the pointer-heavy argument block
     // plus A-wide unrolling); only spill-free kernels are dispatched, so those sizes use the lane-group rollout.
@@ -151,7 +152,8 @@ int check_not_recording(mapf_handle_t h, const char *what) {
 // hipStreamBeginCapture) would bake the handle's current step index into the captured launch: every replay would reuse
 // the same random numbers, silently.  Only mapf_graph_begin knows how to record a launch (device-side step index).
 int check_foreign_capture(mapf_handle_t h, const char *what) {
-    if (h->capturing || h->own_stream) return MAPF_OK;        // (nobody else can capture a stream the handle created)
+    // (nobody else can capture a stream the handle created -- until mapf_get_stream has handed it out)
+    if (h->capturing || (h->own_stream && !h->stream_exposed)) return MAPF_OK;
     hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(h->stream, &status) != hipSuccess) { (void)hipGetLastError(); return MAPF_OK; }
     if (status != hipStreamCaptureStatusNone)
@@ -295,7 +297,7 @@ extern "C" {
 
 const char *mapf_last_error(void) { return g_last_error.c_str(); }
 
-const char *mapf_version(void) { return "mapf_hip 0.3.0 (abi 3, gfx950)"; }
+const char *mapf_version(void) { return "mapf_hip 0.4.0 (abi 4, gfx950)"; }
 
 int mapf_device_count(int *out_count) {
     if (!out_count) return fail(MAPF_EINVAL, "out_count is null");
@@ -505,6 +507,7 @@ const char *mapf_last_kernel(mapf_handle_t h, int which) {
 int mapf_get_stream(mapf_handle_t h, void **out_stream) {
     if (!h || !out_stream) return fail(MAPF_EINVAL, "null handle or output");
     *out_stream = static_cast<void *>(h->stream);
+    h->stream_exposed = true;
     return MAPF_OK;
 }
 
@@ -637,13 +640,23 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
 namespace {
 // The recording rollout kernels write all five trajectory arrays (no per-array branches in the step loop): when
 // the caller asked for only some of them, the others go to handle-owned scratch.
+// A stand-in buffer that a RECORDED rollout node names must not move: DeviceBuf::reserve() frees and reallocates on growth,
+// and the next replay of that node would write into freed memory.  So while a graph is being recorded or recorded graphs
+// of the handle are alive, a stand-in may be allocated (nothing names it yet) but not grown.
+int reserve_stand_in(mapf_handle_t h, DeviceBuf &buf, size_t bytes, const char *name) {
+    if (buf.ptr && bytes > buf.cap && (h->capturing || !h->graphs.empty()))
+        return fail(MAPF_EINVAL, std::string("rollout: the handle's stand-in for ") + name + " would have to grow while a recorded graph names it -- pass all "
+                                 "five rec_* arrays, record the longest rollout first, or destroy the handle's graphs");
+    HIP_TRY(buf.reserve(bytes));
+    return MAPF_OK;
+}
 int complete_recording(mapf_handle_t h, mapf::RolloutArgs &a, size_t TE, size_t TEA) {
     if (!(a.rec_local || a.rec_reward || a.rec_prob || a.rec_done || a.rec_collision)) return MAPF_OK;
-    if (!a.rec_local) { HIP_TRY(h->x_local.reserve(TEA * sizeof(uint16_t))); a.rec_local = static_cast<uint16_t *>(h->x_local.ptr); }
-    if (!a.rec_reward) { HIP_TRY(h->x_reward.reserve(TE * sizeof(double))); a.rec_reward = static_cast<double *>(h->x_reward.ptr); }
-    if (!a.rec_prob) { HIP_TRY(h->x_prob.reserve(TE * sizeof(double))); a.rec_prob = static_cast<double *>(h->x_prob.ptr); }
-    if (!a.rec_done) { HIP_TRY(h->x_done.reserve(TE)); a.rec_done = static_cast<uint8_t *>(h->x_done.ptr); }
-    if (!a.rec_collision) { HIP_TRY(h->x_coll.reserve(TE)); a.rec_collision = static_cast<uint8_t *>(h->x_coll.ptr); }
+    if (!a.rec_local) { if (int rc = reserve_stand_in(h, h->x_local, TEA * sizeof(uint16_t), "rec_local")) return rc; a.rec_local = static_cast<uint16_t *>(h->x_local.ptr); }
+    if (!a.rec_reward) { if (int rc = reserve_stand_in(h, h->x_reward, TE * sizeof(double), "rec_reward")) return rc; a.rec_reward = static_cast<double *>(h->x_reward.ptr); }
+    if (!a.rec_prob) { if (int rc = reserve_stand_in(h, h->x_prob, TE * sizeof(double), "rec_prob")) return rc; a.rec_prob = static_cast<double *>(h->x_prob.ptr); }
+    if (!a.rec_done) { if (int rc = reserve_stand_in(h, h->x_done, TE, "rec_done")) return rc; a.rec_done = static_cast<uint8_t *>(h->x_done.ptr); }
+    if (!a.rec_collision) { if (int rc = reserve_stand_in(h, h->x_coll, TE, "rec_collision")) return rc; a.rec_collision = static_cast<uint8_t *>(h->x_coll.ptr); }
     return MAPF_OK;
 }
 }  // namespace
@@ -887,6 +900,14 @@ int mapf_state_view(mapf_handle_t h, const uint16_t **out_state) {
     if (int rc = check_handle(h)) return rc;
     if (!out_state) return fail(MAPF_EINVAL, "out_state is null");
     *out_state = h->state;
+    return MAPF_OK;
+}
+
+int mapf_invalidate_state(mapf_handle_t h) {
+    if (int rc = check_handle(h)) return rc;
+    h->may_be_terminal = true;
+    h->cap_may_be_terminal = true;
+    for (mapf_graph_s *g : h->graphs) g->ends_may_be_terminal = true;   // (conservative: a replay may run over edited state too)
     return MAPF_OK;
 }
 

@@ -33,12 +33,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-// Two calls that share the key and differ only in the last counter word, advanced in lockstep: the round's four
-// multiplies are independent of each other (one call alone is a chain of dependent multiply -> xor pairs, and the
-// scalar launder below is a scheduling fence, so two separate calls would run back to back).
-__device__ __forceinline__ void philox4x32_10_x2(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3a, uint32_t c3b,
+// Two calls that share the key and the env words of the counter (they differ in the last two words), advanced in
+// lockstep: the round's four multiplies are independent of each other (one call alone is a chain of dependent
+// multiply -> xor pairs, and the scalar launder below is a scheduling fence, so two separate calls would run back to back).
+__device__ __forceinline__ void philox4x32_10_x2(uint32_t c0, uint32_t c1, uint32_t c2a, uint32_t c3a, uint32_t c2b, uint32_t c3b,
                                                  uint32_t k0, uint32_t k1, uint32_t (&outa)[4], uint32_t (&outb)[4]) {
-    uint32_t a0 = c0, a1 = c1, a2 = c2, a3 = c3a, b0 = c0, b1 = c1, b2 = c2, b3 = c3b;
+    uint32_t a0 = c0, a1 = c1, a2 = c2a, a3 = c3a, b0 = c0, b1 = c1, b2 = c2b, b3 = c3b;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t pa0 = uint64_t(0xD2511F53u) * a0, pa1 = uint64_t(0xCD9E8D57u) * a2;
@@ -196,40 +196,52 @@ __device__ __forceinline__ void slip_move_exact_members(const EnvConsts &c, cons
     q = idx == 0u ? qs[0] : (idx == 1u ? qs[1] : qs[2]);
 }
 
-// Slip stream (oracle/philox.py): one call with rslot = refine = 0 yields the four words that serve agents
-// (2*pair, 2*pair+1) at steps 4h .. 4h+3 -- word (t & 3): low half = top 16 bits of agent 2*pair's uniform, high
-// half = agent 2*pair+1's.  The low 37 bits of a slot's uniform come from a separate call (refine = 1, rslot =
-// 2*(t & 3) + (agent & 1)), needed only when the top 16 bits tie with a threshold.
+// Slip stream (oracle/philox.py): one call with rslot = refine = 0 yields the four words that serve the agent QUAD
+// (4*quad .. 4*quad+3) at steps 2h and 2h+1 -- word 2 * (t & 1) + j serves the quad's pair j (agents 4*quad + 2j, + 2j+1):
+// low half = top 16 bits of the even agent's uniform, high half = the odd agent's.  The low 37 bits of a slot's uniform
+// come from a separate call (refine = 1, rslot = 4 * (t & 1) + (agent & 3)), needed only when the top 16 bits tie with a
+// threshold.
 struct Words4 { uint32_t w0, w1, w2, w3; };
 
-__device__ __forceinline__ Words4 slip_words(const EnvConsts &c, uint64_t env_id, uint64_t h, uint32_t pair, uint32_t rslot,
+__device__ __forceinline__ Words4 slip_words(const EnvConsts &c, uint64_t env_id, uint64_t h, uint32_t quad, uint32_t rslot,
                                              uint32_t refine) {
-    const uint32_t c3 = (uint32_t(h >> 32) & 0xFFFFu) | (pair << 16) | (rslot << 23) | (refine << 31);
+    const uint32_t c3 = (uint32_t(h >> 32) & 0xFFFFu) | (quad << 16) | (rslot << 23) | (refine << 31);
     uint32_t w[4];
     philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(h), c3, c.seed_lo, c.seed_hi, w);
     return Words4{w[0], w[1], w[2], w[3]};
 }
 
-// the calls of two pairs of the same (env, h) in lockstep
-__device__ __forceinline__ void slip_words_x2(const EnvConsts &c, uint64_t env_id, uint64_t h, uint32_t pair_a, uint32_t pair_b,
-                                              Words4 &wa, Words4 &wb) {
-    const uint32_t hi = uint32_t(h >> 32) & 0xFFFFu;
+// two calls of the same env in lockstep: (h_a, quad_a) and (h_b, quad_b)
+__device__ __forceinline__ void slip_words_x2(const EnvConsts &c, uint64_t env_id, uint64_t h_a, uint32_t quad_a, uint64_t h_b,
+                                              uint32_t quad_b, Words4 &wa, Words4 &wb) {
     uint32_t a[4], b[4];
-    philox4x32_10_x2(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(h), hi | (pair_a << 16), hi | (pair_b << 16),
-                     c.seed_lo, c.seed_hi, a, b);
+    philox4x32_10_x2(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(h_a), (uint32_t(h_a >> 32) & 0xFFFFu) | (quad_a << 16),
+                     uint32_t(h_b), (uint32_t(h_b >> 32) & 0xFFFFu) | (quad_b << 16), c.seed_lo, c.seed_hi, a, b);
     wa = Words4{a[0], a[1], a[2], a[3]};
     wb = Words4{b[0], b[1], b[2], b[3]};
 }
 
-// word (t & 3) of a call
-__device__ __forceinline__ uint32_t step_word(const Words4 &w, uint64_t t) {
-    const uint32_t k = uint32_t(t) & 3u;
+// word k of a call (k = 0..3, run-time)
+__device__ __forceinline__ uint32_t pick_word(const Words4 &w, uint32_t k) {
     return k == 0u ? w.w0 : (k == 1u ? w.w1 : (k == 2u ? w.w2 : w.w3));
 }
+// A fused rollout keeps, per agent pair, the words of the FOUR-step block 4m .. 4m+3 (two calls: h = 2m, 2m+1) in step
+// order: word (t & 3) of that
+__device__ __forceinline__ uint32_t step_word(const Words4 &w, uint64_t t) { return pick_word(w, uint32_t(t) & 3u); }
+// ... built from the block's two calls for pair j (0 / 1) of the quad
+__device__ __forceinline__ Words4 block_words(const Words4 &a, const Words4 &b, uint32_t j) {
+    return j == 0u ? Words4{a.w0, a.w2, b.w0, b.w2} : Words4{a.w1, a.w3, b.w1, b.w3};
+}
+// this step's word of pair j of a quad, from the call of (t >> 1)
+__device__ __forceinline__ uint32_t quad_step_word(const Words4 &w, uint64_t t, uint32_t j) {
+    return pick_word(w, 2u * (uint32_t(t) & 1u) + j);
+}
+// first call index of the four-step block that contains step t
+__device__ __forceinline__ uint64_t block_first_call(uint64_t t) { return (t >> 1) & ~uint64_t(1); }
 
 // full 53-bit mantissa of (t, agent) given the top 16 bits: one refinement call
 __device__ __forceinline__ uint64_t refine_mantissa(const EnvConsts &c, uint64_t env_id, uint64_t t, uint32_t agent, uint32_t hi16) {
-    const Words4 r = slip_words(c, env_id, t >> 2, agent >> 1, 2u * (uint32_t(t) & 3u) + (agent & 1u), 1u);
+    const Words4 r = slip_words(c, env_id, t >> 1, agent >> 2, 4u * (uint32_t(t) & 1u) + (agent & 3u), 1u);
     return (uint64_t(hi16) << 37) | (uint64_t(r.w0 & 0x1Fu) << 32) | uint64_t(r.w1);
 }
 
@@ -294,8 +306,8 @@ __device__ __forceinline__ void env_transition(const EnvConsts &c, const MoveEnt
         Words4 w{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < A; ++i) {
-            if ((i & 1) == 0 && c.need_rng) w = slip_words(c, env_id, t >> 2, uint32_t(i >> 1), 0u, 0u);
-            const uint32_t word = step_word(w, t);
+            if ((i & 3) == 0 && c.need_rng) w = slip_words(c, env_id, t >> 1, uint32_t(i >> 2), 0u, 0u);
+            const uint32_t word = quad_step_word(w, t, uint32_t(i >> 1) & 1u);
             hi[i] = (i & 1) ? (word >> 16) : (word & 0xFFFFu);
             double pr;
             uint32_t dist;

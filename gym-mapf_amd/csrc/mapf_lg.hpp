@@ -49,6 +49,26 @@ __device__ __forceinline__ uint32_t dpp_mov(uint32_t v) {
     return uint32_t(__builtin_amdgcn_mov_dpp(int(v), CTRL, 0xF, 0xF, true));
 }
 
+// The slip words of a lane that owns ONE agent pair (pair `g` of its env: the lane-group layout, the packed layout with two
+// agents per lane) for the four-step block that contains step t, in step order (step_word).  The block's two calls belong
+// to the QUAD, i.e. to this lane and its neighbour g ^ 1: the even lane computes the first call, the odd lane the second,
+// and they trade the halves the other one needs (two DPP moves) -- one call per lane per four steps.  PAIRED = false (a
+// group of one lane has no neighbour of the same env): both calls, in lockstep.  All lanes must be active.
+template <bool PAIRED>
+__device__ __forceinline__ Words4 pair_block_words(const EnvConsts &c, uint64_t env_id, uint64_t t, uint32_t g) {
+    const uint64_t h0 = block_first_call(t);
+    if constexpr (!PAIRED) {
+        Words4 a, b;
+        slip_words_x2(c, env_id, h0, g >> 1, h0 | 1u, g >> 1, a, b);
+        return block_words(a, b, g & 1u);
+    } else {
+        const bool odd = (g & 1u) != 0u;
+        const Words4 w = slip_words(c, env_id, h0 | uint64_t(g & 1u), g >> 1, 0u, 0u);
+        const uint32_t r0 = dpp_mov<0xB1>(odd ? w.w0 : w.w1), r1 = dpp_mov<0xB1>(odd ? w.w2 : w.w3);   // quad_perm [1,0,3,2]
+        return odd ? Words4{r0, r1, w.w1, w.w3} : Words4{w.w0, w.w2, r0, r1};
+    }
+}
+
 // value held by lane (g + S) mod L of my group
 template <int L, int S>
 __device__ __forceinline__ uint32_t group_rot(uint32_t v, const LaneCtx<L> &x) {
@@ -350,7 +370,7 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const MoveEntr
                                               const LaneCtx<L> &x, uint32_t n_agents,
                                               uint32_t cur0, uint32_t cur1, uint32_t goal0, uint32_t goal1,
                                               uint32_t act0_in, uint32_t act1_in, double u0, double u1,
-                                              uint64_t env_id, uint64_t t, const Words4 rng, bool prev_terminal,
+                                              uint64_t env_id, uint64_t t, const uint32_t word, bool prev_terminal,
                                               uint32_t &next0, uint32_t &next1, EnvOut &out STAMP_PARAM) {
     const uint32_t act0 = act0_in > 4u ? 0u : act0_in, act1 = act1_in > 4u ? 0u : act1_in;
     const bool v0 = FULL || x.v0, v1 = FULL || x.v1;
@@ -363,8 +383,7 @@ __device__ __forceinline__ void lg_transition(const EnvConsts &c, const MoveEntr
         slip_move<true>(lds_slip, entry0, 0, u0, next0, q0);
         slip_move<true>(lds_slip, entry1, 0, u1, next1, q1);
     } else {
-        // this step's word of the call shared by steps 4h .. 4h+3: low half for agent 2g, high half for agent 2g+1
-        const uint32_t word = step_word(rng, t);
+        // `word` = this step's slip word of my pair: low half for agent 2g, high half for agent 2g+1
         const uint32_t hi0 = word & 0xFFFFu, hi1 = word >> 16;
         STAMP(1);   // philox + gather issue
         uint32_t tie0, tie1;

@@ -29,11 +29,11 @@ __global__ void __launch_bounds__(256) lg_step_kernel(const StepArgs p, const ui
 #ifdef MAPF_STAMPS
     StampCtx st{};
 #endif
-    Words4 rng{0u, 0u, 0u, 0u};
+    uint32_t word = 0u;   // this step's slip word of my pair: the call of my quad (g >> 1), word 2 * (t & 1) + (g & 1)
     const uint64_t t = first_step_index(p);
-    if (!EXT_UNIFORMS && p.c.need_rng) rng = slip_words(p.c, p.env_id_offset + e, t >> 2, x.g, 0u, 0u);
+    if (!EXT_UNIFORMS && p.c.need_rng) word = quad_step_word(slip_words(p.c, p.env_id_offset + e, t >> 1, x.g >> 1, 0u, 0u), t, x.g & 1u);
     lg_transition<L, FULL, EXT_UNIFORMS, false, false, false, !EXT_UNIFORMS>(p.c, p.mv, rows, nullptr, x, n_agents, cur0, cur1, goal0, goal1, act0, act1,
-                                                u0, u1, p.env_id_offset + e, t, rng, false, next0, next1, o STAMP_ARG);
+                                                u0, u1, p.env_id_offset + e, t, word, false, next0, next1, o STAMP_ARG);
     if (!live) return;
 
     if (p.out_local) store_cells(p.out_local, e, n_agents, x.g, x.v0, x.v1, next0, next1);

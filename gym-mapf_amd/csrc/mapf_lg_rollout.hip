@@ -202,10 +202,11 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
         uint32_t next0, next1;
         EnvOut o;
         STAMP(0);   // loop top: action fetch / policy / delayed stores
-        // one slip-stream call serves four steps: refresh when t is a multiple of 4 (and at the first step)
-        if (p.c.need_rng && ((t & 3u) == 0u || s == 0u)) rng = slip_words(p.c, env_id, t >> 2, x.g, 0u, 0u);
+        // my pair's words of a four-step block (one slip-stream call per lane, traded with the neighbour lane): refresh when
+        // t is a multiple of 4 (and at the first step)
+        if (p.c.need_rng && ((t & 3u) == 0u || s == 0u)) rng = pair_block_words<(L > 1)>(p.c, env_id, t, x.g);
         lg_transition<L, FULL, false, true, MV_LDS, true>(p.c, mv, slip, outcome, x, n_agents, cur0, cur1, goal0, goal1, act0, act1, 0.0, 0.0,
-                                            env_id, t, rng, terminal != 0u, next0, next1, o STAMP_ARG);
+                                            env_id, t, step_word(rng, t), terminal != 0u, next0, next1, o STAMP_ARG);
         STAMP(6);   // reward / selects
         ret = __dadd_rn(ret, o.reward);
         episodes += o.status & 0xFFu;

@@ -10,9 +10,9 @@
 // At the sizes that matter only one or two waves share a SIMD, and a wave alone issues ONE instruction per ~4.6 cycles
 // whatever its kind or dependences; a scalar branch costs ~12 cycles when it falls through and ~25 when taken, and a
 // vector compare whose mask goes through a scalar AND/OR back into a vector select ~15 on top.  So the loop
-//   * is unrolled by FOUR steps aligned to the slip stream's call granularity: which of a call's four words a step
-//     uses, and whether it refreshes the call, are compile-time facts there (generic steps run before / after the
-//     aligned part of a launch);
+//   * is unrolled by FOUR steps aligned to the slip stream's call blocks (two calls of two steps each, refreshed
+//     together in lockstep): which word a step uses, and whether it refreshes the calls, are compile-time facts there
+//     (generic steps run before / after the aligned part of a launch);
 //   * derives the per-env facts with integer arithmetic in vector registers (zero-half-word tests, min / shifts)
 //     and feeds selects from VCC written by the instruction before them -- no scalar mask algebra in the loop;
 //   * keeps the auto-reset / terminal bookkeeping as one integer code = vertex | swap << 1 | off_goal << 2 |
@@ -352,14 +352,25 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
 #pragma unroll
             for (int k = 0; k < K; ++k) entry[k] = make_uint4(cells_code[k].x, cells_code[k].y, th[k], row_off[k]);
         }
-        // one slip-stream call per pair serves four steps
+        // A slip-stream call serves an agent quad for two steps: every four steps a lane refreshes the two calls of the
+        // block (h0, h0 + 1) for each of its quads, in lockstep, and files their words per pair in step order (rng[i] =
+        // pair i's words of steps 4m .. 4m+3: register renaming, no instructions).  Two agents per lane: the quad is shared
+        // with the neighbour lane -- one call each, halves traded (pair_block_words).
         const bool refresh = FIRST || W == 0 || (W < 0 && (t & 3u) == 0u);
         if (refresh && p.c.need_rng) {
-            if constexpr (P == 4) {
-                slip_words_x2(p.c, env_id, t >> 2, 4u * x.g, 4u * x.g + 1u, rng[0], rng[1]);
-                slip_words_x2(p.c, env_id, t >> 2, 4u * x.g + 2u, 4u * x.g + 3u, rng[2], rng[3]);
-            } else if constexpr (P == 2) slip_words_x2(p.c, env_id, t >> 2, 2u * x.g, 2u * x.g + 1u, rng[0], rng[1]);
-            else rng[0] = slip_words(p.c, env_id, t >> 2, x.g, 0u, 0u);
+            const uint64_t h0 = block_first_call(t);
+            if constexpr (P == 1) {
+                rng[0] = pair_block_words<true>(p.c, env_id, t, x.g);
+            } else {
+#pragma unroll
+                for (int j = 0; j < P / 2; ++j) {
+                    const uint32_t quad = uint32_t(P / 2) * x.g + uint32_t(j);
+                    Words4 a, b;
+                    slip_words_x2(p.c, env_id, h0, quad, h0 | 1u, quad, a, b);
+                    rng[2 * j] = block_words(a, b, 0u);
+                    rng[2 * j + 1] = block_words(a, b, 1u);
+                }
+            }
         }
         STAMP(2);   // slip Philox (1 step in 4)
         double q[K];

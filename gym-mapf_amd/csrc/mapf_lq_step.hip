@@ -175,18 +175,20 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
     __builtin_amdgcn_sched_barrier(0);
     if (!SCEN) gl = Packed<P>::load(at(p.goal, p.goal_broadcast ? fixed_cell : lane_cell));
 
-    // ---- the slip call of my pair(s) for steps 4h .. 4h+3 (one call per pair per step: a single step cannot amortise
-    // it), first six rounds while the loads are in flight
+    // ---- the slip call of my quad(s) for steps 2h, 2h+1 (ONE call per four agents: the stream's call unit is what a lane
+    // of this kernel owns, so a single step pays one call per lane and uses half of its words; with two agents per lane the
+    // neighbour lane repeats the call), first six rounds while the loads are in flight
     // (p.t's low word is preloaded; the high word -- zero for the first 2^32 steps of a handle -- comes with the block)
     const uint64_t env_id = p.env_id_offset + e;
     const uint64_t t = ((p.t & 0xFFFFFFFF00000000ull) | t_lo) + t_base;
-    PhiloxRounds<P> rng_state;
+    constexpr int NQ = K >= 4 ? K / 4 : 1;   // calls per lane
+    PhiloxRounds<NQ> rng_state;
     {
-        const uint32_t hi16 = uint32_t((t >> 2) >> 32) & 0xFFFFu;
+        const uint32_t hi16 = uint32_t((t >> 1) >> 32) & 0xFFFFu;
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            rng_state.c[i][0] = uint32_t(env_id); rng_state.c[i][1] = uint32_t(env_id >> 32); rng_state.c[i][2] = uint32_t(t >> 2);
-            rng_state.c[i][3] = hi16 | ((uint32_t(P) * x.g + uint32_t(i)) << 16);   // pair index; rslot = refine = 0 (slip_words)
+        for (int i = 0; i < NQ; ++i) {
+            rng_state.c[i][0] = uint32_t(env_id); rng_state.c[i][1] = uint32_t(env_id >> 32); rng_state.c[i][2] = uint32_t(t >> 1);
+            rng_state.c[i][3] = hi16 | ((K >= 4 ? uint32_t(NQ) * x.g + uint32_t(i) : x.g >> 1) << 16);   // quad index; rslot = refine = 0 (slip_words)
         }
         rng_state.k0 = seed_lo; rng_state.k1 = seed_hi;
     }
@@ -244,7 +246,11 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
     uint32_t n[P], word[P], d[K], tie_all = 0u;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
-        word[i] = p.c.need_rng ? step_word(Words4{rng_state.c[i][0], rng_state.c[i][1], rng_state.c[i][2], rng_state.c[i][3]}, t) : 0u;
+        {   // pair i of the lane: word 2 * (t & 1) + (pair's place in its quad) of the quad's call
+            const uint32_t (&cw)[4] = rng_state.c[K >= 4 ? i / 2 : 0];
+            const uint32_t place = K >= 4 ? uint32_t(i & 1) : (x.g & 1u);
+            word[i] = p.c.need_rng ? quad_step_word(Words4{cw[0], cw[1], cw[2], cw[3]}, t, place) : 0u;
+        }
         const uint32_t biased = word[i] ^ kHalfBias;                 // low half: agent 2i's uniform, high half: agent 2i+1's
         uint32_t q_at[2], cell[2];
         MoveEntry e0 = entry[2 * i], e1 = entry[2 * i + 1];

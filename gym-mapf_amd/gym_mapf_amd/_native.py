@@ -59,6 +59,7 @@ SIGNATURES = {
     'mapf_get_state': (c_int, [c_void_p, c_void_p, POINTER(c_uint64)]),
     'mapf_set_state': (c_int, [c_void_p, c_void_p, c_uint64]),
     'mapf_state_view': (c_int, [c_void_p, POINTER(c_void_p)]),
+    'mapf_invalidate_state': (c_int, [c_void_p]),
     'mapf_graph_begin': (c_int, [c_void_p]),
     'mapf_graph_end': (c_int, [c_void_p, POINTER(c_void_p)]),
     'mapf_graph_launch': (c_int, [c_void_p, c_void_p, c_uint32]),

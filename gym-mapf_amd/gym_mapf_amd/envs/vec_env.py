@@ -257,12 +257,20 @@ class VecMapfEnv:
     def state_view(self):
         """The handle's own state buffer as a uint16 [E, A] CUDA tensor (device mode only; no copy): ``env.s`` of every
         env as per-agent cells -- after an auto-reset step the state the NEXT step starts from (a finished episode
-        shows its start cells).  Its contents change with every step / rollout / reset enqueued on the env's stream."""
+        shows its start cells).  Its contents change with every step / rollout / reset enqueued on the env's stream.
+        READ-ONLY by contract (the C API returns a const pointer; torch cannot import a read-only CUDA array, so the
+        tensor itself is writable): change the state through ``set_state``, or call ``invalidate_state()`` after writing
+        the tensor -- the library otherwise assumes that no env is terminal after an auto-reset step and skips
+        ``is_terminal(prev)`` (reference mapf_env.py:238-240) in the next one."""
         if not self.device_arrays:
             raise ValueError('state_view() needs device_arrays=True (use get_state() in host mode)')
         ptr = ctypes.c_void_p()
         nat.check(self._lib.mapf_state_view(self._h, ctypes.byref(ptr)))
         return self._torch.as_tensor(_DeviceView(ptr.value, (self.n_envs, self.n_agents), '<u2', self), device=self._tdev)
+
+    def invalidate_state(self):
+        """Tell the library that the state buffer was written behind its back (see ``state_view``)."""
+        nat.check(self._lib.mapf_invalidate_state(self._h))
 
     def graph_begin(self):
         """Start recording ``step`` / ``prepare_step`` calls / ``rollout`` / ``reset`` into a hipGraph (device mode only)."""

@@ -13,13 +13,18 @@ def shard_offset(envs_per_rank, rank):
     return int(rank) * int(envs_per_rank)
 
 
-def split_evenly(n_total, rank, world):
+def split_evenly(n_total, rank, world, granule=1):
     """(offset, count) of rank's slice when ``n_total`` envs are divided over ``world`` ranks
-    (strong scaling, e.g. BASELINE config 4: 262144 envs over 8 GPUs); the remainder goes to the
-    lowest ranks."""
-    base, rem = divmod(int(n_total), int(world))
-    count = base + (1 if rank < rem else 0)
-    offset = rank * base + min(rank, rem)
+    (strong scaling, e.g. BASELINE config 4: 262144 envs over 8 GPUs).  Shards are whole multiples of
+    ``granule`` envs -- the packed kernels take a launch only when the batch fills their blocks (64 to
+    1024 envs per block depending on the form), and a ragged shard would fall back to the guarded
+    lane-group kernel on EVERY rank of a world size that does not divide the population -- with the
+    remaining granules going to the lowest ranks and the last ``n_total % granule`` envs to the last rank."""
+    n_total, rank, world, granule = int(n_total), int(rank), int(world), max(1, int(granule))
+    blocks, tail = divmod(n_total, granule)
+    base, rem = divmod(blocks, world)
+    count = (base + (1 if rank < rem else 0)) * granule + (tail if rank == world - 1 else 0)
+    offset = (rank * base + min(rank, rem)) * granule
     return offset, count
 
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MAPF_ABI_VERSION 3
+#define MAPF_ABI_VERSION 4
 
 /* status codes */
 #define MAPF_OK            0
@@ -217,6 +217,15 @@ int mapf_set_state(mapf_handle_t h, const uint16_t *local, uint64_t t);
  * the handle's stream (read it on that stream or after mapf_sync).  No reference counterpart: MapfEnv.s (mapf_env.py:265).
  */
 int mapf_state_view(mapf_handle_t h, const uint16_t **out_state);
+
+/*
+ * The view is READ-ONLY (const): the library tracks on the host whether some env can be terminal (after a step that
+ * auto-reset every finished episode none can) and then runs the step instance without is_terminal(prev)
+ * (mapf_env.py:238-240).  A caller that writes the state buffer itself (custom reset, curriculum) -- through a
+ * cast of this pointer, or a framework tensor that wraps it -- must say so BEFORE the next step / rollout:
+ * mapf_invalidate_state makes the next launches test is_terminal(prev) again, as mapf_set_state does.  (ABI 4.)
+ */
+int mapf_invalidate_state(mapf_handle_t h);
 
 /*
  * Recording the caller-side loop around MapfEnv.step (mapf_env.py:237-266) into a hipGraph.  Between mapf_graph_begin and

@@ -33,9 +33,9 @@ static void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
 }
 
 static double slip_uniform(uint64_t seed, uint64_t env_id, uint64_t t, uint32_t agent) {
-    const uint64_t h = t >> 2;
-    const uint32_t slot = 2u * (uint32_t)(t & 3) + (agent & 1u);
-    const uint32_t c3 = ((uint32_t)(h >> 32) & 0xFFFFu) | (((agent >> 1) & 0x7Fu) << 16);
+    const uint64_t h = t >> 1;                                     /* one call: four agents, two steps */
+    const uint32_t slot = 4u * (uint32_t)(t & 1) + (agent & 3u);
+    const uint32_t c3 = ((uint32_t)(h >> 32) & 0xFFFFu) | (((agent >> 2) & 0x1Fu) << 16);
     uint32_t w[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)h, c3};
     uint32_t r[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)h, c3 | (slot << 23) | 0x80000000u};
     philox4x32_10(w, (uint32_t)seed, (uint32_t)(seed >> 32));

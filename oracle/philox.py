@@ -18,22 +18,27 @@ vectors in tests/test_philox.py.
 Stream layout (shared with include/mapf_hip.h):
 
     key   = (seed & 0xffffffff, seed >> 32)
-    h     = t >> 2                                  # one Philox call serves FOUR consecutive steps of an agent pair
-    slot  = 2 * (t & 3) + (agent & 1)               # 0..7
+    h     = t >> 1                                  # one Philox call serves TWO consecutive steps of an agent quad
+    quad  = agent >> 2
+    slot  = 4 * (t & 1) + (agent & 3)               # 0..7: which of the call's eight half-words
     ctr   = (env_id & 0xffffffff,
              env_id >> 32,
              h & 0xffffffff,
-             ((h >> 32) & 0xffff) | ((agent >> 1) << 16) | (rslot << 23) | (refine << 31))
+             ((h >> 32) & 0xffff) | (quad << 16) | (rslot << 23) | (refine << 31))
     W     = philox4x32_10(ctr with rslot = 0, refine = 0, key)
-    hi16  = (W[slot >> 1] >> (16 * (slot & 1))) & 0xffff          # word t & 3: low half agent 2p, high half agent 2p+1
+    hi16  = (W[slot >> 1] >> (16 * (slot & 1))) & 0xffff          # word 2 * (t & 1) + ((agent >> 1) & 1): low half = the
+                                                                  # even agent of the pair, high half = the odd one
     R     = philox4x32_10(ctr with rslot = slot, refine = 1, key)
     lo37  = ((R[0] & 0x1f) << 32) | R[1]
     u     = (hi16 * 2**37 + lo37) / 2**53            # 53-bit, in [0, 1) -- the resolution of RandomState.rand()
 
 A 53-bit uniform is thus split over two counters.  The kernel compares hi16 against the top 16 bits of its
 thresholds and evaluates the refine = 1 call only in the (probability ~2^-15 per agent-step) case where those
-bits tie, so the common path costs one Philox call per agent pair per FOUR steps while the value compared is
-exactly the u above.  The CPU oracle simply computes both calls every time.
+bits tie, so the value compared is exactly the u above while the common path costs ONE Philox call per four agents
+per two steps: a single `step` of a lane that owns four agents needs one call (two of its words), a fused rollout
+needs one call per lane per two steps.  (Rounds 1-3 used counter = (env, t >> 2, agent PAIR): the same cost per
+rollout step, but a single step of a four-agent lane then needed two calls and used one word of each.)  The CPU
+oracle simply computes both calls every time.
 
 ``t`` is the handle-global step index (number of ``step`` calls so far), so a terminal-state step simply
 leaves its counters unused -- equivalent to the reference's "no draw on terminal steps" because nothing
@@ -88,12 +93,12 @@ def philox4x32_10_np(c0, c1, c2, c3, k0, k1):
 
 
 def _ctr_words(env_id, t, agent, refine):
-    h = t >> 2
-    slot = 2 * (t & 3) + (agent & 1)
+    h = t >> 1
+    slot = 4 * (t & 1) + (agent & 3)
     c0 = env_id & MASK32
     c1 = (env_id >> 32) & MASK32
     c2 = h & MASK32
-    c3 = ((h >> 32) & 0xFFFF) | (((agent >> 1) & 0x7F) << 16)
+    c3 = ((h >> 32) & 0xFFFF) | (((agent >> 2) & 0x1F) << 16)
     if refine:
         c3 |= (slot << 23) | (1 << 31)
     return c0, c1, c2, c3
@@ -103,7 +108,7 @@ def slip_uniform(seed, env_id, t, agent):
     """The 53-bit uniform the slip model of (env_id, step t, agent) consumes."""
     key = (seed & MASK32, (seed >> 32) & MASK32)
     t, agent = int(t), int(agent)
-    slot = 2 * (t & 3) + (agent & 1)
+    slot = 4 * (t & 1) + (agent & 3)
     w = philox4x32_10(_ctr_words(int(env_id), t, agent, 0), key)
     r = philox4x32_10(_ctr_words(int(env_id), t, agent, 1), key)
     hi16 = (w[slot >> 1] >> (16 * (slot & 1))) & 0xFFFF
@@ -116,14 +121,14 @@ def slip_uniforms_np(seed, env_ids, t, n_agents):
     env_ids = np.asarray(env_ids, dtype=np.uint64).reshape(-1, 1)
     E = env_ids.shape[0]
     agents = np.arange(n_agents, dtype=np.uint64).reshape(1, -1)
-    pairs = agents >> np.uint64(1)
+    quads = agents >> np.uint64(2)
     t = int(t)
-    h = t >> 2
-    slot = np.uint64(2 * (t & 3)) + (agents & np.uint64(1))                    # [1, A]
+    h = t >> 1
+    slot = np.uint64(4 * (t & 1)) + (agents & np.uint64(3))                    # [1, A]
     c0 = env_ids & np.uint64(MASK32)
     c1 = env_ids >> np.uint64(32)
     c2 = np.uint64(h & MASK32)
-    c3 = np.uint64((h >> 32) & 0xFFFF) | (pairs << np.uint64(16))
+    c3 = np.uint64((h >> 32) & 0xFFFF) | (quads << np.uint64(16))
     k0, k1 = seed & MASK32, (seed >> 32) & MASK32
     w = philox4x32_10_np(c0, c1, c2, c3, k0, k1)
     word = np.choose(np.broadcast_to((slot >> np.uint64(1)).astype(np.int64), (E, n_agents)), w)

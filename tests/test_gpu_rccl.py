@@ -1,0 +1,73 @@
+"""RCCL where a one-GPU box can run it: world size 1.  `init_process_group('nccl', device_id=cuda:0)`, the padded
+`all_gather_into_tensor` of sharding.gather_returns on CUDA tensors (with `counts`) and the MAX all-reduce bench.py uses
+for its max-over-ranks timing -- the branches that gloo rehearsals never execute.  Each case runs in a
+child process with a deadline: a collective that hangs must fail the test, not the suite."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return env
+
+
+_CHILD = r'''
+import os, sys
+sys.path.insert(0, os.path.join(%(root)r, 'gym-mapf_amd'))
+import torch
+import torch.distributed as dist
+from gym_mapf_amd import sharding
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(29600 + os.getpid() %% 1000), RANK='0', WORLD_SIZE='1')
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', device_id=torch.device('cuda', 0))
+assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
+x = torch.arange(1000, dtype=torch.float64, device='cuda') * 0.5 - 3.0
+out = sharding.gather_returns(x, counts=[1000])                 # all_gather_into_tensor (CUDA branch), counts given
+assert out.is_cuda and out.dtype == torch.float64 and torch.equal(out, x)
+out = sharding.gather_returns(x)                                # ... and without
+assert torch.equal(out, x)
+try:
+    sharding.gather_returns(x, counts=[999])
+    raise SystemExit('counts that do not describe the shard must be refused')
+except ValueError:
+    pass
+t = torch.tensor([1.25], dtype=torch.float64, device='cuda')
+dist.all_reduce(t, op=dist.ReduceOp.MAX)                        # bench.py block(): max-over-ranks wall time
+assert float(t.item()) == 1.25
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print('RCCL_WORLD1_OK')
+'''
+
+
+def test_rccl_collectives_of_the_path_at_world_size_one():
+    proc = subprocess.run([sys.executable, '-c', _CHILD % {'root': ROOT}], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                          timeout=420, env=_clean_env())
+    assert proc.returncode == 0 and b'RCCL_WORLD1_OK' in proc.stdout, proc.stderr.decode('utf-8', 'replace')[-3000:]
+
+
+def test_bench_with_the_rccl_legs_forced_on_at_one_gpu():
+    """`bench.py --gpus 1 --dist-backend nccl --force-dist`: the bench's own init_process_group('nccl', device_id=...),
+    barrier, MAX all-reduce of the block times and the gather of the returns, end to end, one JSON line."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--dist-backend', 'nccl', '--force-dist',
+           '--steps', '2', '--warmup', '1', '--repeats', '1', '--preroll-ms', '10', '--no-side-legs', '--no-cpu-baseline',
+           '--envs', '4096']
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420, env=_clean_env())
+    assert proc.returncode == 0, proc.stderr.decode('utf-8', 'replace')[-3000:]
+    lines = [l for l in proc.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 1 and line['parity']['bit_exact'] is True
+    assert line['gather'] == {'backend': 'nccl', 'elements': 4096, 'shards': [4096], 'collective': 'all_gather_into_tensor'}
+    assert 'rehearsal' not in line and line['value'] > 0

@@ -362,3 +362,110 @@ def test_recording_is_refused_where_it_cannot_work():
     ext.sync()
     assert ext.t == 3
     ext.close()                                      # (destroys the recording with the handle)
+
+
+def _partial_record_io(env, n_steps, rec_reward):
+    """mapf_rollout_io that asks for the reward trajectory only: the library substitutes its own stand-ins for the other four."""
+    import ctypes
+    return nat.MapfRolloutIO(struct_size=ctypes.sizeof(nat.MapfRolloutIO), n_steps=n_steps, step_flags=nat.MAPF_STEP_AUTO_RESET,
+                             accumulate=0, rec_reward=rec_reward.data_ptr())
+
+
+def test_stand_in_trajectory_buffers_cannot_move_under_a_recorded_rollout():
+    """A recorded rollout that leaves some rec_* arrays out names handle-owned stand-ins.  Growing a stand-in frees and
+    reallocates it, and the next replay of the recorded node would write into freed memory: a later rollout that needs
+    larger stand-ins is refused (inside the recording and after it) while the graph lives; the replay still matches."""
+    import ctypes
+    import torch
+    E, A = 1024, 8
+    grid, _, nbr, start, goal = _c3_tables(E)
+    env = VecMapfEnv(grid, A, None, None, 0.2, *R, OptimizationCriteria.Makespan, seed=5, device_arrays=True,
+                     start_local=start, goal_local=goal)
+    co = c_oracle.COracle(nbr, A, start, goal, 0.2, *R, mo.MAKESPAN, seed=5)
+    small = torch.zeros((8, E), dtype=torch.float64, device='cuda')
+    large = torch.zeros((16, E), dtype=torch.float64, device='cuda')
+    io8, io16 = _partial_record_io(env, 8, small), _partial_record_io(env, 16, large)
+    env.graph_begin()
+    nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(io8)))
+    with pytest.raises(nat.MapfNativeError) as err:          # same recording: the first node already names the stand-ins
+        nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(io16)))
+    assert 'stand-in' in str(err.value)
+    graph = env.graph_end()
+    assert graph.steps == 8
+    with pytest.raises(nat.MapfNativeError):                 # ... and after it, while the graph is alive
+        nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(io16)))
+    nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(io8)))   # the same size is fine (plain launch: steps 0..7)
+    env.sync()
+    first = small.cpu().numpy().copy()
+    graph.launch(1)                                          # steps 8..15 through the recorded node
+    env.sync()
+    import philox
+    ref = np.stack([co.step(philox.random_actions_np(5, np.arange(E), t, A), auto_reset=True)['reward'] for t in range(16)])
+    assert np.array_equal(_bits(first), _bits(ref[:8]))
+    assert np.array_equal(_bits(small.cpu().numpy()), _bits(ref[8:]))
+    assert env.t == 16
+    graph.close()
+    nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(io16)))   # no graph left: the stand-ins may grow again
+    env.sync()
+    env.close()
+
+
+def test_own_stream_capture_is_refused_once_the_stream_was_handed_out():
+    """A handle that created its own stream cannot be captured by anybody else -- until mapf_get_stream hands the stream
+    out (torch ExternalStream interop).  From then on a step enqueued under a foreign capture is refused like on a
+    caller-owned stream: it would bake its step index into the caller's graph."""
+    import torch
+    grid = MapfGrid(['....', '....'])
+    kw = dict(start_local=np.array([[0, 5]], np.uint16).repeat(64, 0), goal_local=np.array([[7, 2]], np.uint16).repeat(64, 0))
+    env = VecMapfEnv(grid, 2, None, None, 0.2, -1.0, 1.0, -1.0, OptimizationCriteria.SoC, device_arrays=True, **kw)
+    acts = torch.zeros((64, 2), dtype=torch.uint8, device='cuda')
+    call, out = env.prepare_step(acts)
+    call()
+    env.sync()
+    ext = torch.cuda.ExternalStream(env.stream)
+    foreign = torch.cuda.CUDAGraph()
+    with pytest.raises(nat.MapfNativeError) as err:
+        with torch.cuda.graph(foreign, stream=ext):
+            call()
+    assert 'mapf_graph_begin' in str(err.value)
+    call()                                                   # outside the capture the handle works as before
+    env.sync()
+    assert env.t == 2
+    env.close()
+
+
+def test_invalidate_state_restores_the_terminal_test_after_a_write_through_the_view():
+    """After an auto-reset step the library knows no env can be terminal and runs the step instance without
+    is_terminal(prev) (mapf_env.py:238-240).  A caller that writes the state buffer through the view must call
+    invalidate_state(): the next step then reports the terminal envs exactly like the reference."""
+    import torch
+    E, A = 1024, 8
+    grid, _, nbr, start, goal = _c3_tables(E)
+    env = VecMapfEnv(grid, A, None, None, 0.2, *R, OptimizationCriteria.Makespan, seed=3, device_arrays=True,
+                     start_local=start, goal_local=goal)
+    co = c_oracle.COracle(nbr, A, start, goal, 0.2, *R, mo.MAKESPAN, seed=3)
+    actions = env.fill_random_actions(0, 3)
+    env.sync()
+    acts = actions.cpu().numpy()
+    local, reward, done, info = env.step(actions[0], auto_reset=True)
+    env.sync()
+    _check(dict(local=local, reward=reward, done=done, **info), co.step(acts[0], auto_reset=True), 'step 0')
+    local, reward, done, info = env.step(actions[1], auto_reset=True)
+    env.sync()
+    _check(dict(local=local, reward=reward, done=done, **info), co.step(acts[1], auto_reset=True), 'step 1')
+    assert 'NO_TERMINAL' in env.last_kernel('step'), env.last_kernel('step')
+    # every fourth env is put on its goal cells (terminal), behind the library's back
+    view = env.state_view()
+    goal_t = torch.as_tensor(goal.astype(np.int32), device='cuda').to(torch.uint16) if goal.ndim == 2 else None
+    assert goal_t is not None
+    view[::4] = goal_t[::4]
+    torch.cuda.synchronize()
+    co.state[::4] = goal[::4]
+    env.invalidate_state()
+    local, reward, done, info = env.step(actions[2], auto_reset=True)
+    env.sync()
+    assert 'NO_TERMINAL' not in env.last_kernel('step'), env.last_kernel('step')
+    ref = co.step(acts[2], auto_reset=True)
+    assert ref['was_terminal'][::4].all() and not ref['was_terminal'][1::4].any()
+    _check(dict(local=local, reward=reward, done=done, **info), ref, 'step 2')
+    env.close()

@@ -90,6 +90,24 @@ def test_split_evenly_covers_every_env_once():
     assert sharding.shard_offset(65536, 3) == 196608
 
 
+def test_split_evenly_keeps_shards_on_block_boundaries():
+    """bench.py splits a fixed population in multiples of 1024 envs: with a world size that does not divide it (3, 5, 6,
+    7 GPUs) every rank would otherwise get a ragged shard and lose the packed kernels (round-3 advisor finding)."""
+    import bench
+    for n in (262144, 131072, 100000, 1023):
+        for world in (1, 2, 3, 5, 6, 7, 8):
+            spans = [sharding.split_evenly(n, r, world, granule=bench.SHARD_GRANULE) for r in range(world)]
+            assert sum(c for _, c in spans) == n
+            pos = 0
+            for r, (off, cnt) in enumerate(spans):
+                assert off == pos and off % bench.SHARD_GRANULE == 0
+                assert cnt % bench.SHARD_GRANULE == 0 or r == world - 1
+                pos += cnt
+            if n % bench.SHARD_GRANULE == 0:
+                assert max(c for _, c in spans) - min(c for _, c in spans) <= bench.SHARD_GRANULE
+    assert [sharding.split_evenly(262144, r, 3, granule=1024)[1] for r in range(3)] == [88064, 87040, 87040]
+
+
 def test_bench_workloads_depend_on_global_env_ids_only():
     """bench.py --config c4 / c5 split a fixed env population over the ranks (sharding.split_evenly): whatever the
     rank count, env e gets the same scenario -- here for the per-env seeded cells of the synthetic C5 workload and
