@@ -260,6 +260,20 @@ bool build_slip_table(double fail_prob, mapf::SlipRow (&rows)[8], double (&cand_
     return any_multi;
 }
 
+// The sixteen outcome rows of the table image (mapf_kernels.hpp TableImage; device twin: stage_outcome_rows in mapf_lg.hpp):
+// rows 0..7 = f = vertex | swap << 1 | off_goal << 2, rows 8..15 = the state was terminal (mapf_env.py:239-240).  Makespan's
+// reward is a function of f: r_clash + living / r_goal + living / living (calc_transition_reward_from_local_states,
+// mapf_env.py:225-235; one float64 addition each, as the reference's `reward + living_reward`).
+void build_outcome_rows(const mapf::EnvConsts &c, mapf::OutcomeRow (&rows)[16]) {
+    for (uint32_t i = 0; i < 16; ++i) {
+        const uint32_t st = mapf::outcome_status(i & 7u);
+        const double r = (st & 0x100u) ? c.r_clash + c.r_living : ((st & 1u) ? c.r_goal + c.r_living : c.r_living);
+        rows[i].reward = i < 8u ? r : 0.0;
+        rows[i].status = i < 8u ? st : mapf::kTerminalStatus;
+        rows[i].pad = (rows[i].status & 1u) | ((rows[i].status & 0x100u) << 8);
+    }
+}
+
 void destroy_impl(mapf_handle_t h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
@@ -429,8 +443,13 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->state), (E ? E : 1) * row));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->start), (sb ? 1 : (E ? E : 1)) * row));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->goal), (gb ? 1 : (E ? E : 1)) * row));
-    CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->slip), sizeof(slip_host)));
-    CREATE_TRY(hipMemcpy(h->slip, slip_host, sizeof(slip_host), hipMemcpyHostToDevice));
+    {   // the 1 KB table image: slip rows, then the outcome rows
+        mapf::TableImage image;
+        std::memcpy(image.slip, slip_host, sizeof(slip_host));
+        build_outcome_rows(h->c, image.outcome);
+        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->slip), sizeof(image)));
+        CREATE_TRY(hipMemcpy(h->slip, &image, sizeof(image), hipMemcpyHostToDevice));
+    }
     CREATE_TRY(hipMemcpy(h->mv, packed.data(), packed.size() * sizeof(mapf::MoveEntry), hipMemcpyHostToDevice));
     if (n_start) CREATE_TRY(hipMemcpy(h->start, d->start, n_start * sizeof(uint16_t), hipMemcpyHostToDevice));
     if (n_goal) CREATE_TRY(hipMemcpy(h->goal, d->goal, n_goal * sizeof(uint16_t), hipMemcpyHostToDevice));

@@ -83,7 +83,8 @@ __device__ __forceinline__ void store_row(T *base, uint64_t row, const Row<T, N>
 // step index of a launch's first step (StepArgs::t_dev): one scalar load when the launch was recorded into a graph
 template <typename ArgsT>
 __device__ __forceinline__ uint64_t first_step_index(const ArgsT &p) {
-    return p.t_dev ? p.t + *p.t_dev : p.t;
+    // (constant address space: a scalar load -- nothing writes *t_dev while a kernel that reads it runs)
+    return p.t_dev ? p.t + *(const __attribute__((address_space(4))) uint64_t *)(uintptr_t)p.t_dev : p.t;
 }
 
 // end-of-step signal of a ONE-WAVE launch (StepArgs::done_flag): every store of the wave is older than this release

@@ -43,6 +43,32 @@ struct EnvConsts {
     uint32_t pol_lo, pol_hi;       // policy-stream Philox key (seed + 1)
 };
 
+// Outcome of a transition as a function of the group's reduced facts f = vertex | swap << 1 | off_goal_next << 2
+// (calc_transition_reward_from_local_states, mapf_env.py:225-235: collision before goal; is_terminal,
+// :210-223: a swap alone leaves a non-terminal state): done | collision << 8 | next_terminal << 16 (EnvOut::status).
+__host__ __device__ constexpr uint32_t outcome_status(uint32_t f) {
+    const bool vertex = (f & 1u) != 0u, coll = (f & 3u) != 0u, goal_next = (f & 4u) == 0u;
+    return ((coll || goal_next) ? 1u : 0u) | (coll ? 0x100u : 0u) | ((vertex || goal_next) ? 0x10000u : 0u);
+}
+constexpr uint32_t kTerminalStatus = 0x10001u;   // a step from a terminal state: done, no collision, still terminal
+
+// LDS outcome table of the rollout kernel (Makespan: the living reward is a constant, so the whole reward is a
+// function of f): rows 0..7 = f, rows 8..15 = "the state was terminal" (mapf_env.py:239-240: reward 0, done).
+struct OutcomeRow {
+    double reward;
+    uint32_t status, pad;   // pad: done | collision << 16 (the packed rollout sums it and stores its bytes)
+};
+static_assert(sizeof(OutcomeRow) == 16, "read as one 16-byte LDS word");
+// The 1 KB table image every step / rollout kernel keeps in LDS: the eight slip rows, then the sixteen outcome rows.  The
+// handle's device copy (StepArgs::slip, RolloutArgs::slip) holds exactly this image -- the outcome rows built on the host
+// with the same float64 additions (build_outcome_rows in mapf_capi.hip) -- so a wave can stage it with one 16-byte load
+// and one 16-byte LDS write per lane.
+struct TableImage {
+    SlipRow slip[8];
+    OutcomeRow outcome[16];
+};
+static_assert(sizeof(TableImage) == 1024, "64 lanes x 16 bytes");
+
 struct StepArgs {
     EnvConsts c;
     const MoveEntry *mv;           // [V*5] move table (see MoveEntry)

@@ -333,24 +333,7 @@ struct EnvOut {
     __device__ __forceinline__ bool collision() const { return (status & 0xFF00u) != 0u; }
 };
 
-// Outcome of a transition as a function of the group's reduced facts f = vertex | swap << 1 | off_goal_next << 2
-// (calc_transition_reward_from_local_states, mapf_env.py:225-235: collision before goal; is_terminal,
-// :210-223: a swap alone leaves a non-terminal state): done | collision << 8 | next_terminal << 16 (EnvOut::status).
-__host__ __device__ constexpr uint32_t outcome_status(uint32_t f) {
-    const bool vertex = (f & 1u) != 0u, coll = (f & 3u) != 0u, goal_next = (f & 4u) == 0u;
-    return ((coll || goal_next) ? 1u : 0u) | (coll ? 0x100u : 0u) | ((vertex || goal_next) ? 0x10000u : 0u);
-}
-constexpr uint32_t kTerminalStatus = 0x10001u;   // a step from a terminal state: done, no collision, still terminal
-
-// LDS outcome table of the rollout kernel (Makespan: the living reward is a constant, so the whole reward is a
-// function of f): rows 0..7 = f, rows 8..15 = "the state was terminal" (mapf_env.py:239-240: reward 0, done).
-struct OutcomeRow {
-    double reward;
-    uint32_t status, pad;   // pad: done | collision << 16 (the packed rollout sums it and stores its bytes)
-};
-static_assert(sizeof(OutcomeRow) == 16, "read as one 16-byte LDS word");
-__device__ __forceinline__ void stage_outcome_table(const EnvConsts &c, OutcomeRow *lds) {   // before a __syncthreads()
-    const uint32_t i = threadIdx.x;
+__device__ __forceinline__ void stage_outcome_rows(const EnvConsts &c, OutcomeRow *lds, const uint32_t i) {   // lanes i = 0..15 write
     if (i < 16u) {
         const uint32_t st = outcome_status(i & 7u);
         const double r = (st & 0x100u) ? __dadd_rn(c.r_clash, c.r_living) : ((st & 1u) ? __dadd_rn(c.r_goal, c.r_living) : c.r_living);
@@ -358,6 +341,9 @@ __device__ __forceinline__ void stage_outcome_table(const EnvConsts &c, OutcomeR
         lds[i].status = i < 8u ? st : kTerminalStatus;
         lds[i].pad = (lds[i].status & 1u) | ((lds[i].status & 0x100u) << 8);   // done | collision << 16: summed as two 16-bit counts
     }
+}
+__device__ __forceinline__ void stage_outcome_table(const EnvConsts &c, OutcomeRow *lds) {   // before a __syncthreads()
+    stage_outcome_rows(c, lds, threadIdx.x);
 }
 
 // One transition for the group's env.  cur0/cur1: my agents' cells (ghost slots hold 0).  Every lane of the

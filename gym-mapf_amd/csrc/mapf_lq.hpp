@@ -46,12 +46,29 @@ template <> struct Packed<2> {
     }
 };
 
-// The kernel's LDS image starts at LDS address 0 (it is the kernel's only LDS object; checked once at kernel entry), so
-// an LDS location is named by its BYTE ADDRESS: plain integer arithmetic ending in one v_lshl_add_u32, the constant
-// part of the address folded into the ds instruction's offset field.
-template <typename T>
-__device__ __forceinline__ T lds_at(uint32_t byte_address) {
-    return *(const __attribute__((address_space(3))) T *)(uintptr_t(byte_address));
+// An LDS location is named by its BYTE OFFSET inside the kernel's LDS image: plain integer arithmetic ending in one
+// v_lshl_add_u32, the constant part folded into the ds instruction's offset field.  Two kinds of image:
+//   * LdsObject -- a static __shared__ object (the plain single step's 1 KB table image): every access goes THROUGH the
+//     object, whose address the compiler knows and folds;
+//   * LdsAbsolute -- the kernel's dynamic LDS segment used as a raw scratchpad that starts at LDS address 0 (the kernel
+//     has no static LDS object: checked against the compiled code objects by tests/test_cabi_and_host.py): EVERY access,
+//     staging stores included, is an integer address turned into an LDS pointer.  (Going through the `extern __shared__`
+//     object costs one vector add per access -- its address is resolved after instruction selection -- and mixing the two
+//     forms is what rounds 2-3 did: stores through the object, loads from integer addresses, i.e. dead stores in the
+//     optimiser's eyes, which a build without -fPIC indeed deleted.)
+using lds_ptr = __attribute__((address_space(3))) unsigned char *;
+struct LdsAbsolute {};
+struct LdsObject { lds_ptr base; };
+__device__ __forceinline__ lds_ptr lds_addr(LdsAbsolute, uint32_t byte_offset) { return (lds_ptr)(uintptr_t(byte_offset)); }
+__device__ __forceinline__ lds_ptr lds_addr(LdsObject image, uint32_t byte_offset) { return image.base + byte_offset; }
+template <typename T, typename Image>
+__device__ __forceinline__ T lds_at(Image image, uint32_t byte_offset) {
+    return *(const __attribute__((address_space(3))) T *)lds_addr(image, byte_offset);
+}
+// a generic pointer to the image's bytes from `byte_offset` on, for staging code written against ordinary pointers
+template <typename T, typename Image>
+__device__ __forceinline__ T *lds_generic(Image image, uint32_t byte_offset) {
+    return (T *)lds_addr(image, byte_offset);
 }
 // half-word H of x times a wave-uniform factor: ONE v_mul_u32_u24 with a word select (the compiler prefers to extract
 // the half-word first and fold the multiply into a v_mad: one instruction more per agent)
@@ -63,8 +80,9 @@ __device__ __forceinline__ uint32_t half_times(uint32_t x, uint32_t factor) {
     return r;
 }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ MoveEntry lds_entry_at(uint32_t byte_address) {   // one ds_read_b128
-    const u32x4 v = lds_at<u32x4>(byte_address);
+template <typename Image>
+__device__ __forceinline__ MoveEntry lds_entry_at(Image image, uint32_t byte_offset) {   // one ds_read_b128
+    const u32x4 v = lds_at<u32x4>(image, byte_offset);
     return make_uint4(v.x, v.y, v.z, v.w);
 }
 
@@ -201,8 +219,8 @@ __device__ __forceinline__ uint32_t group_reduce_min(uint32_t v) {
     return v;
 }
 using lds_u32 = __attribute__((address_space(3))) uint32_t *;
-template <int Q, int K>
-__device__ __forceinline__ PairAcc<true> bitmap_pair_tests(const LaneCtx<Q> &x, uint32_t bitmap_at, const uint32_t (&c)[K / 2],
+template <int Q, int K, typename Image>
+__device__ __forceinline__ PairAcc<true> bitmap_pair_tests(const LaneCtx<Q> &x, Image image, uint32_t bitmap_at, const uint32_t (&c)[K / 2],
                                                            const uint32_t (&n)[K / 2]) {
     static_assert(Q <= 16 && K <= 8, "a group is at most one 16-lane row");
     uint32_t cur[K], nxt[K], wc[K], wn[K], sn[K];
@@ -215,12 +233,12 @@ __device__ __forceinline__ PairAcc<true> bitmap_pair_tests(const LaneCtx<Q> &x, 
         sn[k] = (nxt[k] & 15u) << 1;
     }
 #pragma unroll
-    for (int k = 0; k < K; ++k) __hip_atomic_fetch_or((lds_u32)(uintptr_t(wc[k])), 1u << ((cur[k] & 15u) << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int k = 0; k < K; ++k) __hip_atomic_fetch_or((lds_u32)lds_addr(image, wc[k]), 1u << ((cur[k] & 15u) << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     uint32_t old[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) old[k] = __hip_atomic_fetch_or((lds_u32)(uintptr_t(wn[k])), 2u << sn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int k = 0; k < K; ++k) old[k] = __hip_atomic_fetch_or((lds_u32)lds_addr(image, wn[k]), 2u << sn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-    for (int k = 0; k < K; ++k) { *(lds_u32)(uintptr_t(wc[k])) = 0u; *(lds_u32)(uintptr_t(wn[k])) = 0u; }
+    for (int k = 0; k < K; ++k) { *(lds_u32)lds_addr(image, wc[k]) = 0u; *(lds_u32)lds_addr(image, wn[k]) = 0u; }
     uint32_t cand = 0u, vertex_hit = 0u;
 #pragma unroll
     for (int k = 0; k < K; ++k) {

@@ -64,12 +64,12 @@ template <int Q, int K, bool RECORD, bool STREAM, bool SOC, bool COMPACT, bool T
 __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents, const uint32_t bitmap_base) {
     constexpr int P = K / 2;   // packed dwords per lane
     static_assert(K == 2 || K == 4 || K == 8, "two, four or eight agents per lane");
-    // the kernel's only LDS object, so it sits at LDS address 0 and every offset below is an instruction immediate
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_image[];
-    SlipRow *slip = reinterpret_cast<SlipRow *>(lds_image + kSlipAt);
-    OutcomeRow *outcome = reinterpret_cast<OutcomeRow *>(lds_image + kOutcomeAt);
-    MoveEntry *lds_mv = reinterpret_cast<MoveEntry *>(lds_image + kMoveAt);
-    if (uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lds_image)) != 0u) __builtin_trap();
+    // the kernel's LDS image is its dynamic segment, used as a raw scratchpad from LDS address 0 (LdsAbsolute, mapf_lq.hpp: no
+    // static LDS object exists in this kernel): every offset below is an instruction immediate
+    const LdsAbsolute lds;
+    SlipRow *slip = lds_generic<SlipRow>(lds, kSlipAt);
+    OutcomeRow *outcome = lds_generic<OutcomeRow>(lds, kOutcomeAt);
+    MoveEntry *lds_mv = lds_generic<MoveEntry>(lds, kMoveAt);
     LaneCtx<Q> x;
     x.lane = threadIdx.x & 63u;
     x.g = x.lane & uint32_t(Q - 1);
@@ -120,7 +120,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         const uint32_t stride = (((p.c.n_cells + 15u) >> 4) * 4u + 15u) & ~15u;    // bytes per env: two bits per cell
         bitmap_at = bitmap_base + (threadIdx.x / uint32_t(Q)) * stride;
         const uint32_t n_words = (blockDim.x / uint32_t(Q)) * (stride >> 2);
-        for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) *(lds_u32)(uintptr_t(bitmap_base + 4u * w)) = 0u;
+        for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) *(lds_u32)lds_addr(lds, bitmap_base + 4u * w) = 0u;
     }
     stage_outcome_table(p.c, outcome);
     stage_slip_table(p.slip, slip);   // ends with __syncthreads()
@@ -314,9 +314,9 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         for (int k = 0; k < K; ++k) asm volatile("" : "+v"(cell_at[k]));
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (COMPACT && BITMAP) cells_code[k] = lds_at<u32x2>(kMoveAt - kCompactEntry + (act[k] << 3) + cell_at[k]);   // column act - 1 (STAY: see below)
-            else if (COMPACT) cells_code[k] = lds_at<u32x2>(kMoveAt + (act[k] << 3) + cell_at[k]);
-            else entry[k] = lds_entry_at(kMoveAt + (act[k] << 4) + cell_at[k]);
+            if (COMPACT && BITMAP) cells_code[k] = lds_at<u32x2>(lds, kMoveAt - kCompactEntry + (act[k] << 3) + cell_at[k]);   // column act - 1 (STAY: see below)
+            else if (COMPACT) cells_code[k] = lds_at<u32x2>(lds, kMoveAt + (act[k] << 3) + cell_at[k]);
+            else entry[k] = lds_entry_at(lds, kMoveAt + (act[k] << 4) + cell_at[k]);
         }
         STAMP(0);   // loop top: action fetch / policy, table read issue
         // --- ... then the previous step is finished while they are in flight
@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 row_off[k] = cells_code[k].y >> 16;
-                th[k] = lds_at<uint32_t>(kSlipAt + uint32_t(offsetof(SlipRow, th)) + 8u + row_off[k]);   // th[0] | th[1] << 16
+                th[k] = lds_at<uint32_t>(lds, kSlipAt + uint32_t(offsetof(SlipRow, th)) + 8u + row_off[k]);   // th[0] | th[1] << 16
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) entry[k] = make_uint4(cells_code[k].x, cells_code[k].y, th[k], row_off[k]);
@@ -384,8 +384,8 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
                                           sel_base, q_at[0], cell[0]);
             d[2 * i + 1] = sample_slot_packed(entry[2 * i + 1], __builtin_amdgcn_perm(biased, biased, 0x03020302u), pk_eights, pk_steps,
                                               sel_base, q_at[1], cell[1]);
-            q[2 * i] = lds_at<double>(kSlipAt + 16u + q_at[0]);
-            q[2 * i + 1] = lds_at<double>(kSlipAt + 16u + q_at[1]);
+            q[2 * i] = lds_at<double>(lds, kSlipAt + 16u + q_at[0]);
+            q[2 * i + 1] = lds_at<double>(lds, kSlipAt + 16u + q_at[1]);
             n[i] = cell[0] | (cell[1] << 16);
             tie_all = i == 0 ? pk_min_u16(d[0], d[1]) : pk_min_u16(tie_all, pk_min_u16(d[2 * i], d[2 * i + 1]));
         }
@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
 
         // --- pair tests, then the per-env facts as ONE integer: f = vertex | swap << 1 | off_goal << 2
         PairAcc<true> acc;
-        if constexpr (BITMAP) acc = bitmap_pair_tests<Q, K>(x, bitmap_at, c, n);
+        if constexpr (BITMAP) acc = bitmap_pair_tests<Q, K>(x, lds, bitmap_at, c, n);
         else acc = packed_pair_tests<Q, P, false, true>(x, c, n);
         STAMP(4);   // pair tests
         uint32_t away = n[0] ^ g[0];
@@ -439,7 +439,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         // --- outcome: the row (status for both criteria, reward for Makespan) is only REQUESTED here; everything the
         // next step's table address depends on is derived from `code` without waiting for it
         static_assert(sizeof(OutcomeRow) == 16, "code16 addresses the outcome rows");
-        const u32x4 row = lds_at<u32x4>(kOutcomeAt + code16);   // {reward lo, hi, status, pad}
+        const u32x4 row = lds_at<u32x4>(lds, kOutcomeAt + code16);   // {reward lo, hi, status, pad}
         const uint32_t row_status = row.w;                     // done | collision << 16
         double reward = __hiloint2double(int(row.y), int(row.x));
         const bool was_terminal = MAYBE_TERMINAL && code16 > 7u * 16u;

@@ -67,13 +67,14 @@ struct PhiloxRounds {
 //     first loads, the agent count and the block size (reading blockDim.x would be a scalar load in front of the address
 //     arithmetic) let those loads go out before any s_load of the argument block has come back; the step index's
 //     device-side base (StepArgs::t_dev) is requested at once as well;
-//   * state, actions, the scenario byte and (first lanes of the block) the slip rows are requested together; the
-//     scenario's rows and the move-table rows are the second trip; the Philox rounds are split over the two waits;
-//   * the slip rows and the 16-row outcome table live in 1 KB of LDS (written while the table gathers are in flight, one
-//     barrier), so sampling and the per-env outcome are the fused rollout's code: packed 16-bit threshold compares
-//     (sample_slot_packed), one integer outcome code per env, reward / flags read from the code's LDS row;
+//   * state, actions, the scenario byte and the 1 KB table image (slip rows + outcome rows: one 16-byte load per lane, every
+//     wave for itself) are requested together; the scenario's rows and the move-table rows are the second trip; the Philox
+//     rounds are split over the two waits;
+//   * the image lives in LDS (written while the table gathers are in flight; no barrier: see the staging code), so sampling
+//     and the per-env outcome are the fused rollout's code: packed 16-bit threshold compares (sample_slot_packed), one
+//     integer outcome code per env, reward / flags read from the code's LDS row;
 //   * a 16-bit tie is resolved by register arithmetic alone (slip_move_exact_members), only for the slots that tie.
-constexpr uint32_t kStepSlipAt = 0, kStepOutcomeAt = sizeof(SlipRow) * 8, kStepLds = kStepOutcomeAt + sizeof(OutcomeRow) * 16;
+constexpr uint32_t kStepSlipAt = offsetof(TableImage, slip), kStepOutcomeAt = offsetof(TableImage, outcome), kStepLds = sizeof(TableImage);
 
 //   * TERM = an env may be terminal when the step begins.  The host knows when none can (StepArgs::state_not_terminal:
 //     the previous call auto-reset every finished episode and no START state is itself terminal) -- the usual training
@@ -87,6 +88,7 @@ constexpr uint32_t kStepSlipAt = 0, kStepOutcomeAt = sizeof(SlipRow) * 8, kStepL
 //     barrier are paid once per block instead of once per chunk.
 constexpr uint32_t kStepMoveAt = 1024;
 // offset of the StepArgs block in the kernel's argument segment: five pointers and four 32-bit scalars precede it
+// (compared with the .args metadata of every compiled instance by tests/test_cabi_and_host.py: a wrong value fails the CPU suite)
 constexpr uint32_t kStepArgsOffset = 5 * 8 + 4 * 4;
 static_assert(kStepArgsOffset % alignof(StepArgs) == 0, "the block follows the leading scalars without padding");
 static_assert(kStepLds <= kStepMoveAt, "LDS image of the BIG form: slip rows, outcome rows, then the move table");
@@ -101,21 +103,18 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
     unsigned long long stamp_[8] = {}, real0_, cyc0_;
     asm volatile("s_memrealtime %0\n\ts_memtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(real0_), "=s"(cyc0_) :: "memory");
 #endif
-    // the kernel's only LDS object, so it sits at LDS address 0 (lds_at() names LDS locations by their byte address):
-    // 1 KB static (slip rows, outcome rows); the BIG form owns a dynamic image with the move table behind them
-    unsigned char *lds_image;
-    if constexpr (BIG) {
-        extern __shared__ __attribute__((aligned(16))) unsigned char lds_dynamic[];
-        lds_image = lds_dynamic;
-    } else {
+    // the kernel's LDS image (mapf_lq.hpp): 1 KB static (the table image: slip rows, outcome rows) reached through the
+    // object; the BIG form's image is the dynamic segment -- the move table behind those 1 KB -- used as a raw scratchpad
+    using Image = std::conditional_t<BIG, LdsAbsolute, LdsObject>;
+    Image lds;
+    if constexpr (!BIG) {
         __shared__ __attribute__((aligned(16))) unsigned char lds_static[kStepLds];
-        lds_image = lds_static;
+        lds.base = (lds_ptr)lds_static;
     }
-    if (uint32_t(uintptr_t((__attribute__((address_space(3))) unsigned char *)lds_image)) != 0u) __builtin_trap();
     const uint32_t n_agents = agents_block & 0xFFu, block_threads = agents_block >> 8;
     if (BIG) {   // move table -> LDS (16-byte rows, five columns), four independent loads per thread and round
         const uint32_t n_rows = p_block.c.n_cells * 5u;
-        MoveEntry *const dst = reinterpret_cast<MoveEntry *>(lds_image + kStepMoveAt);
+        MoveEntry *const dst = lds_generic<MoveEntry>(lds, kStepMoveAt);
         for (uint32_t w0 = threadIdx.x; w0 < n_rows; w0 += 4u * block_threads) {
             const uint32_t w1 = w0 + block_threads, w2 = w1 + block_threads, w3 = w2 + block_threads, last = n_rows - 1u;
             const MoveEntry r0 = p_block.mv[w0], r1 = p_block.mv[min(w1, last)], r2 = p_block.mv[min(w2, last)], r3 = p_block.mv[min(w3, last)];
@@ -125,8 +124,8 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
             if (w3 < n_rows) dst[w3] = r3;
         }
         // ... and the slip / outcome rows, behind ONE barrier: every chunk of the block then finds the whole image in place
-        stage_outcome_table(p_block.c, reinterpret_cast<OutcomeRow *>(lds_image + kStepOutcomeAt));
-        stage_slip_table(slip_rows, reinterpret_cast<SlipRow *>(lds_image + kStepSlipAt));   // ends with __syncthreads()
+        stage_outcome_table(p_block.c, lds_generic<OutcomeRow>(lds, kStepOutcomeAt));
+        stage_slip_table(slip_rows, lds_generic<SlipRow>(lds, kStepSlipAt));   // ends with __syncthreads()
     }
     // (!BIG: one block per 256 lanes, one pass.  A resident grid WITHOUT the LDS table was measured 6-8 % slower than that.)
     auto one_chunk = [&](const uint32_t chunk, auto first_tag) __attribute__((always_inline)) {
@@ -164,14 +163,16 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
     uint32_t scen_id = 0u;
     Packed<P> gl{}, sl{};
     if (SCEN) scen_id = *at(scen, e);
-    uint64_t slip_w0 = 0u, slip_w1 = 0u;
-    const bool stager = threadIdx.x < 64u && first_pass;
-    if (stager) {
-        const uint64_t *src = reinterpret_cast<const uint64_t *>(slip_rows);
-        slip_w0 = src[threadIdx.x];
-        if (threadIdx.x < 32u) slip_w1 = src[64u + threadIdx.x];
-    }
-    const uint64_t t_base = t_dev ? *t_dev : 0ull;
+    // (!BIG) EVERY wave fetches the 1 KB table image (slip rows + outcome rows, built on the host: TableImage) with one
+    // 16-byte load per lane and writes it to LDS itself: the waves of a block write identical bytes to identical addresses
+    // and a wave's LDS operations execute in order, so each wave may read the image right after its own write -- no barrier
+    // couples the block's waves (the barrier made all four wait for the slowest one's loads)
+    u32x4 image_word = {0u, 0u, 0u, 0u};
+    const bool stager = first_pass;
+    if (stager) image_word = reinterpret_cast<const u32x4 *>(slip_rows)[x.lane];
+    // the recording's first step index: a SCALAR load (constant address space: nothing writes it while this kernel runs).
+    // As a vector load + readfirstlane it put an s_waitcnt vmcnt(0) -- i.e. the whole first trip -- in front of the Philox rounds
+    const uint64_t t_base = t_dev ? *(const __attribute__((address_space(4))) uint64_t *)(uintptr_t)t_dev : 0ull;
     __builtin_amdgcn_sched_barrier(0);
     if (!SCEN) gl = Packed<P>::load(at(p.goal, p.goal_broadcast ? fixed_cell : lane_cell));
 
@@ -217,19 +218,13 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
         cur[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu;
         const uint32_t byte = uint32_t(raw >> (8 * k)) & 0xFFu;
         act[k] = byte > 4u ? 0u : byte;
-        if (BIG) entry[k] = lds_entry_at(kStepMoveAt + (__umul24(min(cur[k], p.c.n_cells - 1u), 5u) + act[k]) * 16u);
+        if (BIG) entry[k] = lds_entry_at(lds, kStepMoveAt + (__umul24(min(cur[k], p.c.n_cells - 1u), 5u) + act[k]) * 16u);
         else entry[k] = move_entry<true>(p.mv, p.c.n_cells, cur[k], act[k]);
     }
     // the LDS image, while the gathers are in flight: slip rows (fetched with the first trip) and the outcome table
-    if (stager) {
-        uint64_t *dst = reinterpret_cast<uint64_t *>(lds_image + kStepSlipAt);
-        dst[threadIdx.x] = slip_w0;
-        if (threadIdx.x < 32u) dst[64u + threadIdx.x] = slip_w1;
-    }
-    if (first_pass) stage_outcome_table(p.c, reinterpret_cast<OutcomeRow *>(lds_image + kStepOutcomeAt));
+    if (stager) *(__attribute__((address_space(3))) u32x4 *)lds_addr(lds, 16u * x.lane) = image_word;
     __builtin_amdgcn_sched_barrier(0);
     if (p.c.need_rng) rng_state.template run<4>();
-    if (first_pass) __syncthreads();
 #ifdef MAPF_STEP_STAMPS
     { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); stamp_[3] = t_ - cyc0_; __builtin_amdgcn_sched_barrier(0); }   // gathers issued, four rounds done
     STEP_STAMP(4);   // gathers arrived
@@ -257,8 +252,8 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
         e0.z ^= kHalfBias; e1.z ^= kHalfBias;                        // (the rollout's LDS copy of the table carries this bias)
         d[2 * i] = sample_slot_packed(e0, __builtin_amdgcn_perm(biased, biased, 0x01000100u), pk_eights, pk_steps, sel_base, q_at[0], cell[0]);
         d[2 * i + 1] = sample_slot_packed(e1, __builtin_amdgcn_perm(biased, biased, 0x03020302u), pk_eights, pk_steps, sel_base, q_at[1], cell[1]);
-        q[2 * i] = lds_at<double>(kStepSlipAt + 16u + q_at[0]);
-        q[2 * i + 1] = lds_at<double>(kStepSlipAt + 16u + q_at[1]);
+        q[2 * i] = lds_at<double>(lds, kStepSlipAt + 16u + q_at[0]);
+        q[2 * i + 1] = lds_at<double>(lds, kStepSlipAt + 16u + q_at[1]);
         n[i] = cell[0] | (cell[1] << 16);
         tie_all = i == 0 ? pk_min_u16(d[0], d[1]) : pk_min_u16(tie_all, pk_min_u16(d[2 * i], d[2 * i + 1]));
     }
@@ -294,7 +289,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
     const uint32_t term = TERM ? ((flags >> 3) | (~flags >> 4)) & 1u : 0u;
     const uint32_t code16 = ((flags & 7u) | (term << 3)) << 4;
     const bool was_terminal = TERM && code16 > 7u * 16u;
-    const u32x4 row = lds_at<u32x4>(kStepOutcomeAt + code16);      // {reward lo, hi, status, done | collision << 16}
+    const u32x4 row = lds_at<u32x4>(lds, kStepOutcomeAt + code16);      // {reward lo, hi, status, done | collision << 16}
     double reward = __hiloint2double(int(row.y), int(row.x));
     if (p.c.criteria == 1u) {
         // _living_reward: mapf_env.py:436-446

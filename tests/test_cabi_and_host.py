@@ -101,17 +101,17 @@ def _kernel_resources(asm_text):
     return out
 
 
-def test_every_dispatchable_kernel_is_free_of_register_spills(tmp_path):
-    """No code object the launchers can reach may spill registers: a spilling thread-per-env rollout kernel is the
-    one place a wrong result was ever observed on the GPU (DESIGN.md, compiler notes), and spills cost time.  Covers
-    the lane-group and packed-layout families, the transition kernels AND the thread-per-env family (mapf_kernels.hip,
-    compiled once per agent-count group like the Makefile does); of the latter's rollout kernels only those
-    launch_rollout_g* dispatches (A <= kTpeRolloutMaxAgents) are held to it -- the others are never launched."""
+@pytest.fixture(scope='module')
+def device_listings(tmp_path_factory):
+    """hipcc -S listings (gfx950 device code + .amdgpu_metadata) of every translation unit that holds dispatchable kernels,
+    compiled with the Makefile's flags: {listing name: text}."""
+    tmp_path = tmp_path_factory.mktemp('listings')
     jobs = []
     flags = ['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-I' + os.path.join(ROOT, 'include'),
              '-S', '--cuda-device-only']
-    for unit in ('mapf_lg_kernels', 'mapf_lg_rollout', 'mapf_lq_step', 'mapf_transitions'):
+    for unit in ('mapf_lg_kernels', 'mapf_lg_rollout', 'mapf_transitions'):
         jobs.append((unit, [], tmp_path / (unit + '.s')))
+    jobs.append(('mapf_lq_step', ['-mllvm', '-amdgpu-kernarg-preload-count=14'], tmp_path / 'mapf_lq_step.s'))   # (as the Makefile)
     for k in (8, 4, 2):                                           # packed-layout rollout: one object per (K, RECORD)
         for r in (1, 0):
             jobs.append(('mapf_lq_rollout', ['-DMAPF_LQ_K=%d' % k, '-DMAPF_LQ_RECORD=%d' % r], tmp_path / ('mapf_lq_k%d_r%d.s' % (k, r))))
@@ -119,10 +119,22 @@ def test_every_dispatchable_kernel_is_free_of_register_spills(tmp_path):
         jobs.append(('mapf_kernels', ['-DMAPF_GROUP=%d' % g], tmp_path / ('mapf_kernels_g%d.s' % g)))
     procs = [(out, subprocess.Popen(flags + extra + [os.path.join(CSRC, unit + '.hip'), '-o', str(out)],
                                     stderr=subprocess.DEVNULL)) for unit, extra, out in jobs]
-    resources = {}
+    listings = {}
     for out, proc in procs:
-        assert proc.wait() == 0
-        resources.update(_kernel_resources(out.read_text()))
+        assert proc.wait() == 0, out
+        listings[out.name] = out.read_text()
+    return listings
+
+
+def test_every_dispatchable_kernel_is_free_of_register_spills(device_listings):
+    """No code object the launchers can reach may spill registers: a spilling thread-per-env rollout kernel is the
+    one place a wrong result was ever observed on the GPU (DESIGN.md, compiler notes), and spills cost time.  Covers
+    the lane-group and packed-layout families, the transition kernels AND the thread-per-env family (mapf_kernels.hip,
+    compiled once per agent-count group like the Makefile does); of the latter's rollout kernels only those
+    launch_rollout_g* dispatches (A <= kTpeRolloutMaxAgents) are held to it -- the others are never launched."""
+    resources = {}
+    for text in device_listings.values():
+        resources.update(_kernel_resources(text))
     assert len(resources) >= 200
     max_tpe_rollout = int(re.search(r'#define MAPF_TPE_ROLLOUT_MAX\s+(\d+)', open(os.path.join(CSRC, 'mapf_kernels.hpp')).read()).group(1))
     checked = tpe_step = tpe_rollout = 0
@@ -135,3 +147,54 @@ def test_every_dispatchable_kernel_is_free_of_register_spills(tmp_path):
         assert (sgpr, vgpr, scratch) == (0, 0, 0), (name, sgpr, vgpr, scratch)
         checked += 1
     assert tpe_step == 32 and tpe_rollout == max_tpe_rollout and checked >= 130
+
+
+def _kernel_metadata_blocks(asm_text):
+    """{kernel symbol: its block of the .amdgpu_metadata kernel list}"""
+    return {re.search(r'\.name:\s+(\S+)', block).group(1): block for block in asm_text.split('  - .agpr_count:')[1:]}
+
+
+def test_packed_kernels_layout_assumptions_hold_in_the_compiled_objects(device_listings):
+    """The packed kernels hard-code two facts about their own code objects; a compiler update that moves either must fail
+    HERE (a build-time check on the CPU), not as a wrong address on the GPU:
+      * lq_step_kernel<BIG> re-reads its StepArgs block from the kernarg segment at kStepArgsOffset (mapf_lq_step.hip):
+        the by-value StepArgs argument must sit at exactly that offset, behind the 14 preloaded dwords;
+      * lds_at() names LDS locations by ABSOLUTE byte address (mapf_lq.hpp): the kernel's table image must be the kernel's
+        only LDS object, i.e. start at LDS address 0 -- static LDS of exactly sizeof(TableImage) for the plain step (one
+        object of the whole fixed size), none at all for the kernels whose image is the dynamic segment."""
+    src = open(os.path.join(CSRC, 'mapf_lq_step.hip')).read()
+    m = re.search(r'constexpr uint32_t kStepArgsOffset = ([0-9 *+]+);', src)
+    args_offset = eval(m.group(1))                                # "5 * 8 + 4 * 4": plain integer arithmetic
+    text = device_listings['mapf_lq_step.s']
+    blocks = _kernel_metadata_blocks(text)
+    step = {n: b for n, b in blocks.items() if 'lq_step_kernel' in n}
+    assert len(step) >= 60                                        # 9 plain (Q, K) x 4 + BIG forms
+    n_big = 0
+    for name, block in step.items():
+        args = [(int(o), int(z), k) for o, z, k in re.findall(r'\.offset:\s+(\d+)\n\s+\.size:\s+(\d+)\n\s+\.value_kind:\s+(\w+)', block)]
+        by_value = [a for a in args if a[2] == 'by_value']
+        leading = [a for a in args if a[0] < args_offset]
+        assert [a[0] for a in leading] == [0, 8, 16, 24, 32, 40, 44, 48, 52], (name, leading)   # five pointers, four dwords = 14 dwords
+        block_arg = [a for a in by_value if a[1] > 64]
+        assert len(block_arg) == 1 and block_arg[0][0] == args_offset, (name, block_arg, args_offset)
+        lds = int(re.search(r'\.group_segment_fixed_size:\s+(\d+)', block).group(1))
+        big = re.search(r'lq_step_kernelILi\d+ELi\d+ELb[01]ELb[01]ELb1E', name) is not None
+        n_big += big
+        assert lds == (0 if big else 1024), (name, lds)
+        # the descriptor asks the command processor for the 14 leading dwords
+        desc = text[text.index('.amdhsa_kernel ' + name):]
+        desc = desc[:desc.index('.end_amdhsa_kernel')]
+        assert re.search(r'\.amdhsa_user_sgpr_kernarg_preload_length\s+14\b', desc), name
+    assert n_big >= 20
+    n_rollout = 0
+    for listing, text in device_listings.items():
+        if not listing.startswith('mapf_lq_k'):
+            continue
+        for name, block in _kernel_metadata_blocks(text).items():
+            if 'lq_rollout_kernel' in name:
+                assert int(re.search(r'\.group_segment_fixed_size:\s+(\d+)', block).group(1)) == 0, name
+                n_rollout += 1
+    assert n_rollout >= 100
+    # ... and no trap instruction stands in for these checks in the shipped kernels any more
+    for unit in ('mapf_lq_step.hip', 'mapf_lq_rollout.hip'):
+        assert '__builtin_trap' not in open(os.path.join(CSRC, unit)).read(), unit

@@ -482,7 +482,11 @@ def test_goal_reaching_episodes_against_c_oracle(n_agents, n_envs, layout, env_v
 
 
 # ----------------------------------------------------------------------- BASELINE.json full sizes
-def _full_size_check(grid, nbr, A, start, goal, fail_prob, crit, ocrit, n_step, n_roll, kernel='auto', env_id_offset=0):
+def _full_size_check(grid, nbr, A, start, goal, fail_prob, crit, ocrit, n_step, n_roll, kernel='auto', env_id_offset=0,
+                     want_step=None, want_rollout=None, n_streamed=0):
+    """Every env, every step against the C oracle: n_step single steps, an n_roll-step recorded rollout driven by the in-kernel
+    policy stream and (n_streamed > 0) a recorded rollout with streamed actions.  want_step / want_rollout: substrings the
+    dispatched kernel names must contain (the test is ABOUT that kernel instance)."""
     E = start.shape[0]
     env = VecMapfEnv(grid, A, None, None, fail_prob, -1000.0, 100.0, -1.0, crit, seed=42, start_local=start,
                      goal_local=goal, kernel=kernel, env_id_offset=env_id_offset)
@@ -495,6 +499,20 @@ def _full_size_check(grid, nbr, A, start, goal, fail_prob, crit, ocrit, n_step, 
         assert np.array_equal(local, ref['local']), t
         assert np.array_equal(_bits(reward), _bits(ref['reward'])) and np.array_equal(_bits(info['prob']), _bits(ref['prob']))
         assert np.array_equal(done, ref['done']) and np.array_equal(info['collision'], ref['collision'])
+    if want_step is not None:
+        assert want_step in env.last_kernel('step'), env.last_kernel('step')
+    if n_streamed:
+        t0 = n_step
+        acts = np.stack([philox.random_actions_np(43, ids, t0 + k, A) for k in range(n_streamed)])   # (not the policy stream's key)
+        res = env.rollout(n_streamed, actions=acts, auto_reset=True, record=True)
+        if want_rollout is not None:
+            assert want_rollout in env.last_kernel('rollout'), env.last_kernel('rollout')
+        for k in range(n_streamed):
+            ref = co.step(acts[k], auto_reset=True)
+            assert np.array_equal(res['local'][k], ref['local']), k
+            assert np.array_equal(_bits(res['reward'][k]), _bits(ref['reward'])) and np.array_equal(_bits(res['prob'][k]), _bits(ref['prob'])), k
+            assert np.array_equal(res['done'][k], ref['done']) and np.array_equal(res['collision'][k], ref['collision']), k
+        assert np.array_equal(env.get_state()[0], co.state)
     res = env.rollout(n_roll, auto_reset=True, record=True)          # in-kernel policy stream, recorded
     ref = co.rollout(n_roll, auto_reset=True)
     assert np.array_equal(_bits(res['returns']), _bits(ref['returns']))
@@ -510,6 +528,54 @@ def _full_size_check(grid, nbr, A, start, goal, fail_prob, crit, ocrit, n_step, 
     assert np.all(res['collision'] <= res['done'])                    # a collision always ends the episode
     env.close()
     return int(res['episodes'].sum())
+
+
+def _scen_tables(map_name, scen_ids, A, E):
+    from gym_mapf_amd.envs import map_name_to_files
+    from gym_mapf_amd.envs.utils import parse_map_file, parse_scen_file
+    grid = MapfGrid(parse_map_file(map_name_to_files(map_name, scen_ids[0])[0]))
+    _, l2i, nbr = grid.tables()
+    per = [parse_scen_file(map_name_to_files(map_name, sid)[1], A) for sid in scen_ids]
+    which = np.arange(E) % len(scen_ids)
+    start = np.asarray([[l2i[l] for l in p[0]] for p in per], np.uint16)[which]
+    goal = np.asarray([[l2i[l] for l in p[1]] for p in per], np.uint16)[which]
+    return grid, nbr, np.ascontiguousarray(start), np.ascontiguousarray(goal)
+
+
+@pytest.mark.parametrize('criteria', ['Makespan', 'SoC'])
+def test_large_map_maze128_32agents_16384_envs(monkeypatch, criteria):
+    """The reference's LARGE maps at batch (its own grid test opens them: mapf_grid_tests.py:22-32; mapf_env.py:142-143
+    builds valid_locations for any size).  maze-128-128-10, scen 18 (the only scenario that constructs with 32 agents),
+    14818 free cells: a 1.2 MB move table, i.e. the kernels that gather rows from GLOBAL memory -- the lane-group rollout
+    <L=16,FULL,MV_GLOBAL,...,DENSE> and the packed single step <Q=8,K=4,SCEN> -- under default dispatch, every env of
+    every step against the C oracle (round 3 only TIMED these instances)."""
+    monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    grid, nbr, start, goal = _scen_tables('maze-128-128-10', [18], 32, 16384)
+    assert nbr.shape[0] == 14818
+    crit, ocrit = (OptimizationCriteria.SoC, mo.SOC) if criteria == 'SoC' else (OptimizationCriteria.Makespan, mo.MAKESPAN)
+    n = _full_size_check(grid, nbr, 32, start, goal, 0.2, crit, ocrit, 6, 24, want_step='lq_step_kernel<Q=8,K=4,SCEN',
+                         want_rollout='lg_rollout_kernel<L=16,FULL,MV_GLOBAL,RECORD,STREAM,DENSE>', n_streamed=16)
+    assert n > 100                                                # (32 agents leaving one scenario's start cells do collide)
+
+
+@pytest.mark.parametrize('criteria', ['Makespan', 'SoC'])
+def test_large_map_berlin256_4agents_65536_envs(monkeypatch, criteria):
+    """Berlin_1_256 (47540 free cells, a 3.8 MB move table; the map mapf_grid_tests.py:22-32 opens), scen 11, 4 agents,
+    65536 envs: packed single step <Q=1,K=4,SCEN> at V = 47540 and the lane-group rollout <L=2,FULL,MV_GLOBAL,...,DENSE>."""
+    monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    grid, nbr, start, goal = _scen_tables('Berlin_1_256', [11], 4, 65536)
+    assert nbr.shape[0] == 47540
+    crit, ocrit = (OptimizationCriteria.SoC, mo.SOC) if criteria == 'SoC' else (OptimizationCriteria.Makespan, mo.MAKESPAN)
+    _full_size_check(grid, nbr, 4, start, goal, 0.2, crit, ocrit, 8, 32, want_step='lq_step_kernel<Q=1,K=4,SCEN',
+                     want_rollout='lg_rollout_kernel<L=2,FULL,MV_GLOBAL,RECORD,STREAM,DENSE>', n_streamed=24)
+
+
+def test_large_map_berlin256_2agents_eight_scenarios_65536_envs():
+    """Berlin_1_256 with 2 agents over eight scenario ids (the thread-per-env family is the default at A <= 2): step and
+    rollout at V = 47540, slip 0.1."""
+    grid, nbr, start, goal = _scen_tables('Berlin_1_256', [2, 4, 8, 11, 14, 18, 22, 24], 2, 65536)
+    _full_size_check(grid, nbr, 2, start, goal, 0.1, OptimizationCriteria.Makespan, mo.MAKESPAN, 6, 24, want_step='step_kernel<A=2',
+                     want_rollout='rollout_kernel<A=2>', n_streamed=12)
 
 
 def test_config2_empty16_4agents_4096_envs():
