@@ -521,9 +521,9 @@ def main():
     # ---- second leg: env-steps as single-step mapf_step launches (one kernel launch per env-step)
     single = None
     if not args.no_side_legs:
-        # recorded once, replayed: 64 mapf_step nodes; the step writes its cells once (the next observation is the
+        # recorded once, replayed: 256 mapf_step nodes; the step writes its cells once (the next observation is the
         # handle's state view) and every other output to HBM
-        n_nodes = min(64, ring)
+        n_nodes = min(256, ring)                                     # (a replay boundary costs ~5 us: hipGraphLaunch + the advance node)
         out = None
         env.reset()
         env.graph_begin()
@@ -531,7 +531,7 @@ def main():
             call, out = env.prepare_step(actions[r], auto_reset=True, out=out, write_local=False)
             call()
         graph = env.graph_end()
-        K1 = 32                                                      # replays per timed block = 2048 env-steps
+        K1 = 8                                                       # replays per timed block = 2048 env-steps
         g_blocks, _ = timed(lambda k: graph.launch(1), 4, K1, min(args.repeats, 3))
         wall1, gpu_ms1 = median_block(g_blocks)
         step_kernel = env.last_kernel('step')

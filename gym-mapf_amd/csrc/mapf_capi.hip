@@ -102,6 +102,7 @@ struct mapf_handle_s {
     hipStream_t stream = nullptr;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     mapf::MoveEntry *mv = nullptr;
+    mapf::CompactEntry *mv8 = nullptr;   // the 8-byte-row form of the move table (the packed single step gathers from it)
     mapf::SlipRow *slip = nullptr;
     std::vector<uint16_t> nbr;        // host copy of the neighbour table (policy tables are derived from it)
     uint2 *policy_cells = nullptr;    // greedy policy table (mapf_set_policy); null = random policy stream
@@ -222,14 +223,14 @@ bool build_slip_table(double fail_prob, mapf::SlipRow (&rows)[8], double (&cand_
         // representative cells realising the pattern (inconsistent codes cannot occur at run time)
         const int m = 0, r = (code & 1u) ? 0 : 1, l = (code & 2u) ? 0 : ((code & 4u) ? r : 2);
         const int cand_cell[3] = {m, r, l};
-        int cells[3] = {-1, -1, -1}, src[3] = {0, 0, 0}, members[3] = {0, 0, 0}, n = 0;
+        int cells[3] = {-1, -1, -1}, members[3] = {0, 0, 0}, n = 0;
         double q[3] = {0, 0, 0};
         for (int k = 0; k < 3; ++k) {
             if (!(cand_p[k] > 0)) continue;
             int hit = -1;
             for (int j = 0; j < n; ++j) if (cells[j] == cand_cell[k]) { hit = j; break; }
             if (hit >= 0) { q[hit] = q[hit] + cand_p[k]; members[hit] |= 1 << k; }
-            else { cells[n] = cand_cell[k]; src[n] = k; q[n] = cand_p[k]; members[n] = 1 << k; ++n; }
+            else { cells[n] = cand_cell[k]; q[n] = cand_p[k]; members[n] = 1 << k; ++n; }
         }
         mapf::SlipRow &row = rows[code];
         std::memset(&row, 0, sizeof(row));
@@ -243,7 +244,6 @@ bool build_slip_table(double fail_prob, mapf::SlipRow (&rows)[8], double (&cand_
                 const double scaled = std::ceil(std::ldexp(run, 53));          // exact: power-of-two scaling
                 row.thr[k] = scaled >= 9007199254740992.0 ? (uint64_t(1) << 53) : (scaled <= 0 ? 0 : uint64_t(scaled));
                 row.th[k] = uint32_t(row.thr[k] >> 37) > 65535u ? 65535u : uint32_t(row.thr[k] >> 37);   // saturated (see SlipRow)
-                row.src |= uint32_t(src[k]) << (8 * k);
                 row.members |= uint32_t(members[k]) << (3 * k);
             } else {
                 row.cum[k] = -HUGE_VAL;
@@ -255,6 +255,7 @@ bool build_slip_table(double fail_prob, mapf::SlipRow (&rows)[8], double (&cand_
         // th[2] is never compared against (a list's last threshold is 65535 by construction): it carries th[0] | th[1] << 16,
         // the word MoveEntry::z holds, for kernels that keep only the cells of a row in LDS (mapf_lq_rollout.hip COMPACT)
         row.th[2] = row.th[0] | (row.th[1] << 16);
+        row.th_biased = row.th[2] ^ 0x80008000u;   // (sample_slot_packed compares bias-shifted half-words)
         any_multi |= n > 1;
     }
     return any_multi;
@@ -294,6 +295,7 @@ void destroy_impl(mapf_handle_t h) {
     if (h->scen_rows) (void)hipFree(h->scen_rows);
     if (h->t_dev) (void)hipFree(h->t_dev);
     if (h->mv) (void)hipFree(h->mv);
+    if (h->mv8) (void)hipFree(h->mv8);
     if (h->policy_cells) (void)hipFree(h->policy_cells);
     if (h->slip) (void)hipFree(h->slip);
     if (h->state) (void)hipFree(h->state);
@@ -413,10 +415,11 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
     const double rf_ = d->fail_prob / 2, lf_ = d->fail_prob / 2;
     const bool keep[3] = {((1 - rf_) - lf_) > 0, rf_ > 0, lf_ > 0};
     static const uint8_t kSlipRight[5] = {0, 2, 3, 4, 1}, kSlipLeft[5] = {0, 4, 1, 2, 3};   // __init__.py:19-25
-    std::vector<mapf::MoveEntry> packed(size_t(V) * 5);
+    std::vector<mapf::MoveEntry> packed(size_t(V) * mapf::kMvCols);   // column 5 = STAY again (kMvCols)
     for (uint32_t v = 0; v < V; ++v) {
         const uint16_t *r = d->nbr + uint64_t(v) * 5;
-        for (uint32_t a = 0; a < 5; ++a) {
+        for (uint32_t col = 0; col < mapf::kMvCols; ++col) {
+            const uint32_t a = col < 5 ? col : 0;
             const uint16_t cand[3] = {r[a], r[kSlipRight[a]], r[kSlipLeft[a]]};
             const uint64_t code = (cand[0] == cand[1] ? 1u : 0u) | (cand[0] == cand[2] ? 2u : 0u) | (cand[1] == cand[2] ? 4u : 0u);
             uint16_t cells[3] = {0, 0, 0};
@@ -432,7 +435,7 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
             // (past the list end: 65535 as well -- `hi < 65535` only fails in a tie, and an earlier slot has matched by then)
             for (int k = 0; k < 3; ++k)
                 t16[k] = slip_host[code].th[k];
-            packed[size_t(v) * 5 + a] = make_uint4(uint32_t(cells[0]) | (uint32_t(cells[1]) << 16),
+            packed[size_t(v) * mapf::kMvCols + col] = make_uint4(uint32_t(cells[0]) | (uint32_t(cells[1]) << 16),
                                                     uint32_t(cells[2]) | (uint32_t(code) << 16) | (slip_host[code].members << 19),
                                                     t16[0] | (t16[1] << 16), uint32_t(code * sizeof(mapf::SlipRow)));
         }
@@ -451,6 +454,12 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
         CREATE_TRY(hipMemcpy(h->slip, &image, sizeof(image), hipMemcpyHostToDevice));
     }
     CREATE_TRY(hipMemcpy(h->mv, packed.data(), packed.size() * sizeof(mapf::MoveEntry), hipMemcpyHostToDevice));
+    {
+        std::vector<mapf::CompactEntry> compact(packed.size());
+        for (size_t i = 0; i < packed.size(); ++i) compact[i] = make_uint2(packed[i].x, (packed[i].y & 0xFFFFu) | (packed[i].w << 16));
+        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->mv8), compact.size() * sizeof(mapf::CompactEntry)));
+        CREATE_TRY(hipMemcpy(h->mv8, compact.data(), compact.size() * sizeof(mapf::CompactEntry), hipMemcpyHostToDevice));
+    }
     if (n_start) CREATE_TRY(hipMemcpy(h->start, d->start, n_start * sizeof(uint16_t), hipMemcpyHostToDevice));
     if (n_goal) CREATE_TRY(hipMemcpy(h->goal, d->goal, n_goal * sizeof(uint16_t), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->t_dev), sizeof(uint64_t)));
@@ -569,7 +578,7 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     if (int rc = check_extent(h, h->E, uniforms != nullptr)) return rc;
     const size_t E = size_t(h->E), EA = E * h->A;
     mapf::StepArgs a{};
-    a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
+    a.c = h->c; a.mv = h->mv; a.mv8 = h->mv8; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
     a.n_envs = h->E; a.env_id_offset = h->env_id_offset;
     // a recorded launch: offset inside the recording + the device-side index (see StepArgs::t_dev)
     a.t = h->capturing ? h->cap_steps : h->t;

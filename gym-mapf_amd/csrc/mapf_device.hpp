@@ -252,7 +252,7 @@ __device__ __forceinline__ MoveEntry move_entry(const MoveEntry *__restrict__ mv
                                                 uint32_t action) {
     // CLAMP = false only for an LDS-resident table: an out-of-range LDS read returns zeros instead of faulting
     const uint32_t c = (!CLAMP || cell < n_cells) ? cell : n_cells - 1u;
-    uint32_t row = __umul24(c, 5u) + action;   // cells are 16-bit: one v_mad_u32_u24
+    uint32_t row = __umul24(c, kMvCols) + action;   // cells are 16-bit: one v_mad_u32_u24
     asm volatile("" : "+v"(row));             // keep row * 16 + base as one shift-add (not c * 80 + action * 16 + base)
     return mv[row];
 }

@@ -19,6 +19,16 @@ namespace mapf {
 //       65535 is a tie and is resolved by the exact 53-bit path;
 //   w = code * sizeof(SlipRow) : byte offset of the code's row (the sampled probability is q[slot] at its start).
 using MoveEntry = uint4;
+// Columns per cell: the five actions (STAY, UP, RIGHT, DOWN, LEFT).  MAPF_MV_COLS=6 (experiment builds) appends STAY again,
+// so that an action byte is extracted and clamped by ONE v_min_u32 with a byte select -- measured on the packed single step
+// (profiles/r04_step_table_forms.txt): the 20 % larger table costs more (+0.10 us per launch at 65536 envs: every launch
+// re-fetches the table into eight L2s and its gathers are bound by the texture path's line rate) than the two vector
+// instructions per agent save, so the shipped table has five columns.
+#ifndef MAPF_MV_COLS
+#define MAPF_MV_COLS 5
+#endif
+constexpr uint32_t kMvCols = MAPF_MV_COLS;
+static_assert(kMvCols == 5 || kMvCols == 6, "five action columns, optionally STAY again");
 
 struct SlipRow {
     double q[3];                   // merged probabilities, list order
@@ -28,9 +38,16 @@ struct SlipRow {
     uint32_t n;                    // list length, 1..3
     uint64_t thr[3];               // ceil(cum[k] * 2^53): cum[k] > u  <=>  mant(u) < thr[k]; 0 past the list end
     double cum[3];                 // running float64 sums (for caller-supplied uniforms); -inf past the list end
-    uint32_t src;                  // byte k: candidate (0 m, 1 r, 2 l) in list slot k (host bookkeeping)
+    uint32_t th_biased;            // (th[0] | th[1] << 16) ^ 0x80008000: MoveEntry::z as sample_slot_packed wants it, for
+                                   // kernels that gather 8-byte rows and fetch the thresholds from the LDS copy of this row
     uint32_t members;              // bits 3k..3k+2: which candidates (m, r, l) merged into list slot k
 };
+
+// 8-byte form of a move-table row, for kernels that are bound by the rate of their table gathers (the packed single step:
+// half the table bytes to re-fetch per launch, half the bytes per gathered lane):
+//   x = c0 | c1 << 16 (as MoveEntry::x), y = c2 | (code * sizeof(SlipRow)) << 16.
+// The thresholds (MoveEntry::z) are SlipRow::th_biased of the code's row, its members (exact path) SlipRow::members.
+using CompactEntry = uint2;
 
 struct EnvConsts {
     double r_clash, r_goal, r_living;
@@ -71,8 +88,9 @@ static_assert(sizeof(TableImage) == 1024, "64 lanes x 16 bytes");
 
 struct StepArgs {
     EnvConsts c;
-    const MoveEntry *mv;           // [V*5] move table (see MoveEntry)
-    const SlipRow *slip;           // [8] device copy of the slip table
+    const MoveEntry *mv;           // [V*5] move table (see MoveEntry, kMvCols)
+    const uint2 *mv8;              // [V*5] the same table with 8-byte rows (CompactEntry: cells + the code's slip-row offset)
+    const SlipRow *slip;           // [8] device copy of the slip table (the first part of a TableImage)
     uint16_t *state;               // [E*A] persistent env state
     const uint16_t *start, *goal;  // [E*A] or [A]
     const uint8_t *actions;        // [E*A]

@@ -27,7 +27,7 @@ __device__ __forceinline__ uint32_t load_actions_raw(const uint8_t *base, uint32
     return raw;
 }
 
-// MV_LDS: the whole move table (V*5 entries of 16 B) is staged into LDS once per block and the two gathers of
+// MV_LDS: the whole move table (V*6 entries of 16 B) is staged into LDS once per block and the two gathers of
 // every step become ds_read_b128 (a random 64-lane gather through the vector-memory pipe touches up to 64 cache
 // lines).  RECORD: all five trajectory arrays are written every step (the C ABI substitutes scratch for absent
 // ones), STREAM: actions come from memory, else from the in-kernel policy stream.  Both are compile-time so the
@@ -57,7 +57,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     load_pair<uint16_t>(p.goal, p.goal_broadcast ? 0 : e, n_agents, x.g, x.v0, x.v1, goal0, goal1);
     if (p.auto_reset) load_pair<uint16_t>(p.start, p.start_broadcast ? 0 : e, n_agents, x.g, x.v0, x.v1, start0, start1);
     if (MV_LDS) {   // batches of four independent loads per thread, then the four LDS writes (not load-wait-write)
-        const uint32_t n_words = p.c.n_cells * 5u;
+        const uint32_t n_words = p.c.n_cells * kMvCols;
         for (uint32_t w0 = threadIdx.x; w0 < n_words; w0 += 4u * blockDim.x) {
             MoveEntry part[4];
 #pragma unroll
@@ -265,7 +265,7 @@ RolloutTuning default_rollout_tuning(int device) {
 
 template <int L, bool FULL, bool RECORD, bool STREAM>
 static hipError_t launch_rollout_lg_impl(const RolloutArgs &args, uint32_t A, const RolloutTuning &tune, hipStream_t stream) {
-    const size_t mv_bytes = size_t(args.c.n_cells) * 5 * sizeof(MoveEntry);
+    const size_t mv_bytes = size_t(args.c.n_cells) * kMvCols * sizeof(MoveEntry);
     const uint64_t threads = args.n_envs * uint64_t(L);
     if (mv_bytes + kLdsReserve <= tune.mv_lds_max_bytes && mv_bytes + kLdsReserve <= kLdsBytes && threads >= 64 * 256) {
         // block size: as many waves as can share one table copy while >= 16 waves stay resident per CU

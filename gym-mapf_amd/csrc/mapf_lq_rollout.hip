@@ -102,7 +102,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
             for (uint32_t k = 0; k < 4u; ++k) {
                 const uint32_t w = min(w0 + k * blockDim.x, n_words - 1u);
                 const uint32_t cell = w / kCols, col = w - cell * kCols;
-                part[k] = p.mv[!COMPACT ? cell * 5u + (col == 5u ? 0u : col) : (BITMAP ? cell * 5u + col + 1u : w)];
+                part[k] = p.mv[!COMPACT ? cell * kMvCols + (col < kMvCols ? col : 0u) : cell * kMvCols + col + (BITMAP ? 1u : 0u)];
             }
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) {

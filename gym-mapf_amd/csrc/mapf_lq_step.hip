@@ -112,8 +112,8 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
         lds.base = (lds_ptr)lds_static;
     }
     const uint32_t n_agents = agents_block & 0xFFu, block_threads = agents_block >> 8;
-    if (BIG) {   // move table -> LDS (16-byte rows, five columns), four independent loads per thread and round
-        const uint32_t n_rows = p_block.c.n_cells * 5u;
+    if (BIG) {   // move table -> LDS (16-byte rows, six columns: kMvCols), four independent loads per thread and round
+        const uint32_t n_rows = p_block.c.n_cells * kMvCols;
         MoveEntry *const dst = lds_generic<MoveEntry>(lds, kStepMoveAt);
         for (uint32_t w0 = threadIdx.x; w0 < n_rows; w0 += 4u * block_threads) {
             const uint32_t w1 = w0 + block_threads, w2 = w1 + block_threads, w3 = w2 + block_threads, last = n_rows - 1u;
@@ -213,16 +213,25 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
     for (int i = 0; i < P; ++i) c[i] = cells.v[i];
     uint32_t cur[K], act[K];
     MoveEntry entry[K];
+    CompactEntry compact[K];
+    const uint32_t last_cell = p.c.n_cells - 1u;
+    // the LDS image first (it arrived with the first trip): the plain form reads its thresholds from it right behind the gathers
+    if (stager) *(__attribute__((address_space(3))) u32x4 *)lds_addr(lds, 16u * x.lane) = image_word;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        cur[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu;
-        const uint32_t byte = uint32_t(raw >> (8 * k)) & 0xFFu;
-        act[k] = byte > 4u ? 0u : byte;
-        if (BIG) entry[k] = lds_entry_at(lds, kStepMoveAt + (__umul24(min(cur[k], p.c.n_cells - 1u), 5u) + act[k]) * 16u);
-        else entry[k] = move_entry<true>(p.mv, p.c.n_cells, cur[k], act[k]);
+        // cell: half-word extract + clamp (a corrupted state must not turn into a wild read) in one v_min_u32 with a word
+        // select; action: an out-of-range byte is STAY (with a sixth table column -- STAY again -- one v_min_u32, byte select)
+        cur[k] = min((k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu, last_cell);
+        if constexpr (kMvCols == 6) act[k] = min(uint32_t(raw >> (8 * k)) & 0xFFu, 5u);
+        else { const uint32_t byte = uint32_t(raw >> (8 * k)) & 0xFFu; act[k] = byte > 4u ? 0u : byte; }
+        uint32_t row = __umul24(cur[k], kMvCols) + act[k];
+        asm volatile("" : "+v"(row));             // (keep row * 8 + base as one shift-add)
+        // BIG: 16-byte rows from the LDS copy.  Plain: 8-BYTE rows from global memory (CompactEntry) -- a launch's gathers are
+        // bound by the texture path's line rate and every launch re-fetches the table into eight L2s, so half the bytes is
+        // what counts; the code's thresholds then come from the slip row in LDS (profiles/r04_step_table_forms.txt)
+        if (BIG) entry[k] = lds_entry_at(lds, kStepMoveAt + row * 16u);
+        else compact[k] = p.mv8[row];
     }
-    // the LDS image, while the gathers are in flight: slip rows (fetched with the first trip) and the outcome table
-    if (stager) *(__attribute__((address_space(3))) u32x4 *)lds_addr(lds, 16u * x.lane) = image_word;
     __builtin_amdgcn_sched_barrier(0);
     if (p.c.need_rng) rng_state.template run<4>();
 #ifdef MAPF_STEP_STAMPS
@@ -231,6 +240,13 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
 #endif
 #pragma unroll
     for (int i = 0; i < P; ++i) { g[i] = gl.v[i]; sc[i] = sl.v[i]; }
+    if constexpr (!BIG) {   // complete the rows: thresholds (bias-shifted, as the packed sampling compares them) by the code's row offset
+        uint32_t th[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) th[k] = lds_at<uint32_t>(lds, kStepSlipAt + uint32_t(offsetof(SlipRow, th_biased)) + (compact[k].y >> 16));
+#pragma unroll
+        for (int k = 0; k < K; ++k) entry[k] = make_uint4(compact[k].x, compact[k].y, th[k], compact[k].y >> 16);
+    }
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- sampling (the fused rollout's packed form): both threshold compares of an agent in one saturating packed
@@ -249,7 +265,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
         const uint32_t biased = word[i] ^ kHalfBias;                 // low half: agent 2i's uniform, high half: agent 2i+1's
         uint32_t q_at[2], cell[2];
         MoveEntry e0 = entry[2 * i], e1 = entry[2 * i + 1];
-        e0.z ^= kHalfBias; e1.z ^= kHalfBias;                        // (the rollout's LDS copy of the table carries this bias)
+        if (BIG) { e0.z ^= kHalfBias; e1.z ^= kHalfBias; }           // (th_biased / the rollout's LDS copy of the table carry this bias)
         d[2 * i] = sample_slot_packed(e0, __builtin_amdgcn_perm(biased, biased, 0x01000100u), pk_eights, pk_steps, sel_base, q_at[0], cell[0]);
         d[2 * i + 1] = sample_slot_packed(e1, __builtin_amdgcn_perm(biased, biased, 0x03020302u), pk_eights, pk_steps, sel_base, q_at[1], cell[1]);
         q[2 * i] = lds_at<double>(lds, kStepSlipAt + 16u + q_at[0]);
@@ -268,7 +284,10 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
             if (__any(zero_half(d[k]) != 0u)) {
                 const uint32_t hi = (k & 1) ? word[k / 2] >> 16 : word[k / 2] & 0xFFFFu;
                 uint32_t nx;
-                slip_move_exact_members(p.c, entry[k], refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi), nx, q[k]);
+                MoveEntry full = entry[k];
+                // (8-byte rows: the list's members, where slip_move_exact_members looks for them, from the code's slip row)
+                if (!BIG) full.y = (full.y & 0xFFFFu) | (lds_at<uint32_t>(lds, kStepSlipAt + uint32_t(offsetof(SlipRow, members)) + full.w) << 19);
+                slip_move_exact_members(p.c, full, refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi), nx, q[k]);
                 n[k / 2] = (k & 1) ? (n[k / 2] & 0xFFFFu) | (nx << 16) : (n[k / 2] & 0xFFFF0000u) | nx;
             }
         }
@@ -297,7 +316,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             const uint32_t goal_k = (k & 1) ? g[k / 2] >> 16 : g[k / 2] & 0xFFFFu;
-            mine += (cur[k] == goal_k && act[k] == 0u) ? 1u : 0u;
+            mine += (cur[k] == goal_k && (act[k] == 0u || act[k] == 5u)) ? 1u : 0u;   // (5 = an out-of-range byte: STAY)
         }
         const int stayed = int(group_reduce<Q, true>(mine, x));
         const double living = __dmul_rn(double(int(n_agents) - stayed), p.c.r_living);
@@ -394,7 +413,7 @@ bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning 
     // The BIG form (resident grid, move table in LDS): batches several times what the device holds at once
     // (profiles/r03_single_step_scaling.txt), a table that leaves room for two 1024-thread blocks per CU.
     // MAPF_STEP_BIG=0 never, =2 whenever it fits.
-    const size_t big_lds = kStepMoveAt + size_t(args.c.n_cells) * 5u * sizeof(MoveEntry);
+    const size_t big_lds = kStepMoveAt + size_t(args.c.n_cells) * kMvCols * sizeof(MoveEntry);
     int n_cu = 256, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
     const uint64_t resident_lanes = uint64_t(n_cu) * 2048u;

@@ -17,7 +17,7 @@ cfg = bench.CONFIGS['c3']
 A = cfg['agents']
 torch.cuda.set_device(0)
 print('room-32-32-4, %d agents, slip 0.2, auto-reset, uniform-random actions resident in HBM' % A)
-def run(E, ring, mode):
+def run(E, ring, mode, nodes=16):
     grid, _, nbr, start, goal = bench.workload_tables(cfg, E, 0)
     env = VecMapfEnv(grid, A, None, None, cfg['fail_prob'], -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=42,
                      device_arrays=True, start_local=start, goal_local=goal)
@@ -25,7 +25,7 @@ def run(E, ring, mode):
     out, calls = None, []
     if mode == 'graph':
         env.graph_begin()
-    for r in range(16):
+    for r in range(nodes):
         call, out = env.prepare_step(actions[r % ring], auto_reset=True, out=out, write_local=False)
         calls.append(call)
         if mode == 'graph':
@@ -42,11 +42,11 @@ def run(E, ring, mode):
         for _ in range(4):
             launch()
         env.sync()
-    n = (2000 if E <= 262144 else 500) // 16
+    n = max(1, (2000 if E <= 262144 else 500) // nodes)
     env.timer_begin()
     for k in range(n):
         launch()
-    us = env.timer_end() * 1e3 / (n * 16)
+    us = env.timer_end() * 1e3 / (n * nodes)
     byts = E * A * (5 + 18.0 / A)
     touched = E * (A * 2 + 18 + 1 + 1) + ring * E * A     # state + outputs + scenario byte + action ring
     print('E=%8d %5s ring=%2d  %8.2f us per launch  %8.1f G agent-steps/s  %7.1f GB/s algorithmic = %.3f of 8 TB/s   working set %5.0f MB   %s'
@@ -60,7 +60,7 @@ def run(E, ring, mode):
 
 import subprocess
 if len(sys.argv) > 1:        # child: one (E, ring, mode) case under the environment the parent chose
-    run(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3])
+    run(int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 16)
     raise SystemExit(0)
 for E in (4096, 16384, 65536, 131072, 262144, 524288, 1048576, 2097152, 4194304):
     run(E, 16, 'graph')
