@@ -29,11 +29,12 @@ time of that region.  Rank 0 prints ONE JSON line.  Keys beyond the contract:
   roofline      dominant kernel (the fused rollout; `kernel` = what the library reports it dispatched): algorithmic
                 bytes / HIP-event time per launch; `traffic` = HBM bytes per launch from the committed PMC passes
                 (profiles/traffic.json: per-step + fixed part), `traffic_frac` = that / the same time / peak;
-                `valu_frac` = share of the SIMDs' cycles with a vector instruction in flight (4 cycles each): measured
-                by the committed SQ counter pass (profiles/valu.json: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES x waves per
-                SIMD) and scaled by that pass's launch duration / the live one -- the resource that binds the kernel
-                (DESIGN.md 4.1), printed beside the HBM figure
-  single_step_launches   the same env-steps as one mapf_step launch each, recorded ONCE into a hipGraph (64 nodes; the
+                `valu_frac` = the time a SIMD's vector ALU needs for its share of the launch's vector instructions -- the
+                committed SQ counter passes' instruction counts by kind (profiles/valu.json: plain 32-bit, 64-bit integer,
+                float64 multiply / add) x the measured peak issue time of each kind (profiles/r04_valu_issue_cost.txt) --
+                divided by the live launch time; traffic / valu entries made from other kernel sources than this tree's
+                (csrc_hash) are not used: the keys then print null
+  single_step_launches   the same env-steps as one mapf_step launch each, recorded ONCE into a hipGraph (256 nodes; the
                 step index lives in device memory, so every replay draws fresh numbers) and replayed; the next
                 observation is read from the handle's state view (cells written once); `plain_launches` = the same
                 calls issued one by one from the host (host-enqueue bound)
@@ -79,6 +80,34 @@ def bytes_per_agent_step(A):
     return 5.0 + 18.0 / A
 
 
+_CSRC_HASH = None
+
+
+def csrc_hash():
+    """Identity of the kernel sources a committed counter profile belongs to: sha256 (first 16 hex digits) over
+    gym-mapf_amd/csrc/*.hip, *.hpp and include/mapf_hip.h with comments and white space removed.  profiles/traffic.json
+    and profiles/valu.json entries carry it (tools/derive_traffic.py, tools/derive_valu.py); an entry made from other
+    sources than the ones in this tree is NOT used -- `roofline.traffic` / `valu_frac` then print null instead of a stale
+    number that merely shares the kernel's label."""
+    global _CSRC_HASH
+    if _CSRC_HASH is None:
+        import glob
+        import hashlib
+        import re
+        csrc = os.path.join(ROOT, 'gym-mapf_amd', 'csrc')
+        files = sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.hpp'))) + [os.path.join(ROOT, 'include', 'mapf_hip.h')]
+        h = hashlib.sha256()
+        for path in files:
+            with open(path) as f:
+                text = f.read()
+            text = re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)
+            text = re.sub(r'//[^\n]*', ' ', text)
+            h.update(os.path.basename(path).encode())
+            h.update(''.join(text.split()).encode())
+        _CSRC_HASH = h.hexdigest()[:16]
+    return _CSRC_HASH
+
+
 def measured_traffic(kernel, n_envs, n_agents, steps_per_launch):
     """HBM bytes per launch of `kernel` at this batch, from the committed rocprofv3 PMC passes of this same command
     (profiles/traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE doubled as
@@ -90,7 +119,8 @@ def measured_traffic(kernel, n_envs, n_agents, steps_per_launch):
     except (OSError, KeyError, ValueError):
         return None
     for entry in entries if isinstance(entries, list) else ():
-        if entry.get('kernel') == kernel and entry.get('n_envs') == n_envs and entry.get('n_agents') == n_agents:
+        if entry.get('kernel') == kernel and entry.get('n_envs') == n_envs and entry.get('n_agents') == n_agents and \
+                entry.get('csrc_hash') == csrc_hash():
             return entry['fixed_bytes'] + entry['bytes_per_env_step_launch'] * steps_per_launch
     return None
 
@@ -234,9 +264,9 @@ def scalar_env_rate(budget_s=2.0):
 
 
 def measured_valu(kernel, n_envs, n_agents, steps_per_launch):
-    """The committed SQ counter pass of `kernel` at this batch (profiles/valu.json, tools/derive_valu.py): (VALU
-    wave-instructions per launch, share of the SIMDs' cycles with a vector instruction in flight during that pass, mean
-    launch duration of that pass in ms), or None when no such pass is committed."""
+    """The committed SQ counter passes of `kernel` at this batch (profiles/valu.json, tools/derive_valu.py): (VALU
+    wave-instructions per launch, the time in ms a SIMD's vector ALU needs for its share of them at the measured peak issue
+    rates of their kinds -- profiles/r04_valu_issue_cost.txt), or None when no such pass of THESE kernel sources is committed."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'valu.json')) as f:
             entries = json.load(f)['kernels']
@@ -244,8 +274,8 @@ def measured_valu(kernel, n_envs, n_agents, steps_per_launch):
         return None
     for entry in entries:
         if entry.get('kernel') == kernel and entry.get('n_envs') == n_envs and entry.get('n_agents') == n_agents and \
-                entry.get('env_steps_per_launch') == steps_per_launch:
-            return entry['valu_insts_per_launch'], entry['valu_busy_share_of_simd_cycles'], entry['launch_ms_in_pass']
+                entry.get('env_steps_per_launch') == steps_per_launch and entry.get('csrc_hash') == csrc_hash():
+            return entry['valu_insts_per_launch'], entry['valu_ms_per_simd']
     return None
 
 
@@ -581,7 +611,7 @@ def main():
                          "frac": ro_achieved / HBM_PEAK_GBS,
                          "traffic": ro_traffic,
                          "traffic_frac": (ro_traffic / (ro_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if ro_traffic else None,
-                         "valu_frac": min(1.0, ro_valu[1] * ro_valu[2] / ro_launch_ms) if ro_valu else None,
+                         "valu_frac": (ro_valu[1] / ro_launch_ms) if ro_valu else None,
                          "valu_insts_per_launch": ro_valu[0] if ro_valu else None,
                          "kernel": rollout_kernel, "bytes_per_launch": ro_bytes,
                          "ms_per_launch_hip_events": ro_launch_ms,

@@ -124,10 +124,6 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     }
     stage_outcome_table(p.c, outcome);
     stage_slip_table(p.slip, slip);   // ends with __syncthreads()
-    if (COMPACT) {   // the thresholds come from the slip rows' packed word: biased like the full table's
-        if (threadIdx.x < 8u) slip[threadIdx.x].th[2] ^= kHalfBias;
-        __syncthreads();
-    }
 
     uint32_t terminal = packed_is_terminal<Q, P>(x, c, g) ? 1u : 0u;
     const uint32_t start_terminal = (p.auto_reset && packed_is_terminal<Q, P>(x, start_c, g)) ? 1u : 0u;
@@ -347,7 +343,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 row_off[k] = cells_code[k].y >> 16;
-                th[k] = lds_at<uint32_t>(lds, kSlipAt + uint32_t(offsetof(SlipRow, th)) + 8u + row_off[k]);   // th[0] | th[1] << 16
+                th[k] = lds_at<uint32_t>(lds, kSlipAt + uint32_t(offsetof(SlipRow, th_biased)) + row_off[k]);   // (th[0] | th[1] << 16) ^ bias
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) entry[k] = make_uint4(cells_code[k].x, cells_code[k].y, th[k], row_off[k]);

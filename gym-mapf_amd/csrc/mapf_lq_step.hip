@@ -86,7 +86,10 @@ constexpr uint32_t kStepSlipAt = offsetof(TableImage, slip), kStepOutcomeAt = of
 //     1024-thread blocks (two per CU) stages the whole move table into LDS once and walks the batch in chunks of 1024
 //     lanes: the table rows become ds_read_b128 (a quarter of the cost), and the argument block, the LDS image and the
 //     barrier are paid once per block instead of once per chunk.
-constexpr uint32_t kStepMoveAt = 1024;
+#ifndef MAPF_BIG_COLS
+#define MAPF_BIG_COLS 6
+#endif
+constexpr uint32_t kStepMoveAt = 1024, kBigCols = MAPF_BIG_COLS;
 // offset of the StepArgs block in the kernel's argument segment: five pointers and four 32-bit scalars precede it
 // (compared with the .args metadata of every compiled instance by tests/test_cabi_and_host.py: a wrong value fails the CPU suite)
 constexpr uint32_t kStepArgsOffset = 5 * 8 + 4 * 4;
@@ -112,16 +115,24 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
         lds.base = (lds_ptr)lds_static;
     }
     const uint32_t n_agents = agents_block & 0xFFu, block_threads = agents_block >> 8;
-    if (BIG) {   // move table -> LDS (16-byte rows, six columns: kMvCols), four independent loads per thread and round
-        const uint32_t n_rows = p_block.c.n_cells * kMvCols;
+    if (BIG) {   // move table -> LDS: 16-byte rows, SIX columns per cell (kBigCols: column 5 = STAY again, so that an action byte is
+        // extracted and clamped by one v_min_u32 -- in LDS the sixth column costs room, not gather traffic); four independent
+        // loads per thread and round; the thresholds bias-shifted as the packed sampling compares them
+        const uint32_t n_rows = p_block.c.n_cells * kBigCols;
         MoveEntry *const dst = lds_generic<MoveEntry>(lds, kStepMoveAt);
+        auto source = [](uint32_t w) __attribute__((always_inline)) {
+            const uint32_t cell = w / kBigCols, col = w - cell * kBigCols;
+            return cell * kMvCols + (col < kMvCols ? col : 0u);
+        };
+        auto biased = [](MoveEntry r) __attribute__((always_inline)) { r.z ^= kHalfBias; return r; };
         for (uint32_t w0 = threadIdx.x; w0 < n_rows; w0 += 4u * block_threads) {
             const uint32_t w1 = w0 + block_threads, w2 = w1 + block_threads, w3 = w2 + block_threads, last = n_rows - 1u;
-            const MoveEntry r0 = p_block.mv[w0], r1 = p_block.mv[min(w1, last)], r2 = p_block.mv[min(w2, last)], r3 = p_block.mv[min(w3, last)];
-            dst[w0] = r0;
-            if (w1 < n_rows) dst[w1] = r1;
-            if (w2 < n_rows) dst[w2] = r2;
-            if (w3 < n_rows) dst[w3] = r3;
+            const MoveEntry r0 = p_block.mv[source(w0)], r1 = p_block.mv[source(min(w1, last))], r2 = p_block.mv[source(min(w2, last))],
+                            r3 = p_block.mv[source(min(w3, last))];
+            dst[w0] = biased(r0);
+            if (w1 < n_rows) dst[w1] = biased(r1);
+            if (w2 < n_rows) dst[w2] = biased(r2);
+            if (w3 < n_rows) dst[w3] = biased(r3);
         }
         // ... and the slip / outcome rows, behind ONE barrier: every chunk of the block then finds the whole image in place
         stage_outcome_table(p_block.c, lds_generic<OutcomeRow>(lds, kStepOutcomeAt));
@@ -215,6 +226,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
     MoveEntry entry[K];
     CompactEntry compact[K];
     const uint32_t last_cell = p.c.n_cells - 1u;
+    constexpr uint32_t kCols = BIG ? kBigCols : kMvCols;
     // the LDS image first (it arrived with the first trip): the plain form reads its thresholds from it right behind the gathers
     if (stager) *(__attribute__((address_space(3))) u32x4 *)lds_addr(lds, 16u * x.lane) = image_word;
 #pragma unroll
@@ -222,9 +234,9 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
         // cell: half-word extract + clamp (a corrupted state must not turn into a wild read) in one v_min_u32 with a word
         // select; action: an out-of-range byte is STAY (with a sixth table column -- STAY again -- one v_min_u32, byte select)
         cur[k] = min((k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu, last_cell);
-        if constexpr (kMvCols == 6) act[k] = min(uint32_t(raw >> (8 * k)) & 0xFFu, 5u);
+        if constexpr (kCols == 6) act[k] = min(uint32_t(raw >> (8 * k)) & 0xFFu, 5u);
         else { const uint32_t byte = uint32_t(raw >> (8 * k)) & 0xFFu; act[k] = byte > 4u ? 0u : byte; }
-        uint32_t row = __umul24(cur[k], kMvCols) + act[k];
+        uint32_t row = __umul24(cur[k], kCols) + act[k];
         asm volatile("" : "+v"(row));             // (keep row * 8 + base as one shift-add)
         // BIG: 16-byte rows from the LDS copy.  Plain: 8-BYTE rows from global memory (CompactEntry) -- a launch's gathers are
         // bound by the texture path's line rate and every launch re-fetches the table into eight L2s, so half the bytes is
@@ -265,7 +277,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
         const uint32_t biased = word[i] ^ kHalfBias;                 // low half: agent 2i's uniform, high half: agent 2i+1's
         uint32_t q_at[2], cell[2];
         MoveEntry e0 = entry[2 * i], e1 = entry[2 * i + 1];
-        if (BIG) { e0.z ^= kHalfBias; e1.z ^= kHalfBias; }           // (th_biased / the rollout's LDS copy of the table carry this bias)
+        // (the thresholds are bias-shifted already: th_biased / the BIG form's LDS copy of the table)
         d[2 * i] = sample_slot_packed(e0, __builtin_amdgcn_perm(biased, biased, 0x01000100u), pk_eights, pk_steps, sel_base, q_at[0], cell[0]);
         d[2 * i + 1] = sample_slot_packed(e1, __builtin_amdgcn_perm(biased, biased, 0x03020302u), pk_eights, pk_steps, sel_base, q_at[1], cell[1]);
         q[2 * i] = lds_at<double>(lds, kStepSlipAt + 16u + q_at[0]);
@@ -413,7 +425,7 @@ bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning 
     // The BIG form (resident grid, move table in LDS): batches several times what the device holds at once
     // (profiles/r03_single_step_scaling.txt), a table that leaves room for two 1024-thread blocks per CU.
     // MAPF_STEP_BIG=0 never, =2 whenever it fits.
-    const size_t big_lds = kStepMoveAt + size_t(args.c.n_cells) * kMvCols * sizeof(MoveEntry);
+    const size_t big_lds = kStepMoveAt + size_t(args.c.n_cells) * kBigCols * sizeof(MoveEntry);
     int n_cu = 256, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
     const uint64_t resident_lanes = uint64_t(n_cu) * 2048u;

@@ -7,19 +7,32 @@ envs consecutively, which is why runs and not whole groups: env e keeps the glob
 exactly what it would draw alone, whatever its neighbours' maps.  A batch sorted by map needs one handle per map; an
 interleaved one needs more, which costs launches, not correctness.
 
-Host mode only (numpy in, numpy out).  There is no CPU implementation behind it either.
+Two modes, as ``VecMapfEnv``:
+  * host mode (default): numpy in, numpy out, one blocking call per run;
+  * ``device_arrays=True``: torch CUDA tensors in and out, every run's launch enqueued on ONE stream (the caller's, or the
+    one the first handle creates), nothing waits.  A run is a contiguous range of envs, so its slice of an env-major
+    batch tensor is itself contiguous: where the slice is 16-byte aligned (the C ABI's rule for device pointers -- a run
+    that starts at a multiple of 16 envs) the run's handle reads and writes the caller's tensors IN PLACE; other runs go
+    through per-run staging tensors and device-to-device copies on the same stream.
+
+There is no CPU implementation behind it either.
 """
 import numpy as np
 
 from gym_mapf_amd.envs.vec_env import VecMapfEnv
 
+_STEP_SPEC = (('local', np.uint16, True), ('reward', np.float64, False), ('done', np.uint8, False),
+              ('collision', np.uint8, False), ('prob', np.float64, False), ('was_terminal', np.uint8, False))
+
 
 class MultiMapVecEnv:
     def __init__(self, grids, n_agents, start_locations, goal_locations, fail_prob, reward_of_collision, reward_of_goal,
-                 reward_of_living, optimization_criteria, *, seed=42, env_id_offset=0, device=0):
+                 reward_of_living, optimization_criteria, *, seed=42, env_id_offset=0, device=0, device_arrays=False,
+                 stream=None):
         """``grids``: one MapfGrid per env (the same object -- or an equal grid -- may repeat); ``start_locations`` /
         ``goal_locations``: per env, A (row, col) pairs.  The other arguments as ``VecMapfEnv`` / the reference."""
         self.n_envs, self.n_agents = len(grids), int(n_agents)
+        self.device_arrays = bool(device_arrays)
         if len(start_locations) != self.n_envs or len(goal_locations) != self.n_envs:
             raise ValueError('one start / goal row per env')
         distinct = []                                   # [grid]; MapfGrid.__eq__ compares cell contents (reference grid.py:42-46)
@@ -34,6 +47,7 @@ class MultiMapVecEnv:
                 distinct.append(g)
         self.grids = distinct
         self._parts = []                                # (env indices of the run, VecMapfEnv)
+        self._stream = stream
         e = 0
         while e < self.n_envs:
             run_end = e + 1
@@ -44,21 +58,112 @@ class MultiMapVecEnv:
             goals = np.asarray([goal_locations[i] for i in idx]).reshape(len(idx), self.n_agents, 2)
             env = VecMapfEnv(distinct[which[e]], self.n_agents, starts, goals, fail_prob, reward_of_collision, reward_of_goal,
                              reward_of_living, optimization_criteria, seed=seed, env_id_offset=int(env_id_offset) + e,
-                             device=device)
+                             device=device, device_arrays=self.device_arrays, stream=self._stream)
+            if self.device_arrays and self._stream is None:
+                self._stream = env.stream               # every later handle enqueues on the first one's stream
             self._parts.append((idx, env))
             e = run_end
+        self._torch = self._parts[0][1]._torch if self.device_arrays and self._parts else None
 
     @property
     def n_handles(self):
         return len(self._parts)
 
+    @property
+    def stream(self):
+        """The HIP stream every run enqueues on (device mode), as an integer handle."""
+        return self._stream
+
+    # ------------------------------------------------------------------ device-mode plumbing
+    def _torch_stream(self):
+        return self._torch.cuda.stream(self._torch.cuda.ExternalStream(self._stream))
+
+    @staticmethod
+    def _aligned(tensor):
+        return tensor.data_ptr() % 16 == 0
+
+    def _check(self, tensor, dtype, shape, name):
+        t = self._torch
+        want = {np.uint8: t.uint8, np.uint16: t.uint16, np.float64: t.float64, np.uint32: t.uint32}[dtype]
+        if not (isinstance(tensor, t.Tensor) and tensor.is_cuda and tensor.dtype == want and tensor.is_contiguous()
+                and tuple(tensor.shape) == tuple(shape)):
+            raise ValueError('%s must be a contiguous CUDA %s tensor of shape %r' % (name, want, tuple(shape)))
+        return tensor
+
+    def prepare_step(self, actions, uniforms=None, auto_reset=False, out=None, write_local=True):
+        """Device mode: validate once, call many times (``VecMapfEnv.prepare_step`` for the whole batch).  Returns
+        ``(call, out)``: ``call()`` enqueues one ``mapf_step`` per run -- on the caller's tensors in place where a run's
+        slice is 16-byte aligned, through staging copies where it is not -- all on ``self.stream``; nothing is waited for."""
+        if not self.device_arrays:
+            raise ValueError('prepare_step() needs device_arrays=True')
+        E, A, t = self.n_envs, self.n_agents, self._torch
+        self._check(actions, np.uint8, (E, A), 'actions')
+        if uniforms is not None:
+            self._check(uniforms, np.float64, (E, A), 'uniforms')
+        out = dict(out) if out else {}
+        any_env = self._parts[0][1]
+        for name, dt, per_agent in _STEP_SPEC:
+            if name == 'local' and not write_local:
+                continue
+            shape = (E, A) if per_agent else (E,)
+            if name not in out:
+                out[name] = any_env._empty(shape, dt)
+            self._check(out[name], dt, shape, name)
+        calls, copies_in, copies_out, staged_runs = [], [], [], 0
+        for idx, env in self._parts:
+            lo, hi = int(idx[0]), int(idx[-1]) + 1
+            n_before = len(copies_in) + len(copies_out)
+
+            def view(batch, inputs):
+                part = batch[lo:hi]
+                if self._aligned(part):
+                    return part                                      # in place
+                stage = t.empty_like(part)
+                (copies_in if inputs else copies_out).append((stage, part))
+                return stage
+            a = view(actions, True)
+            u = view(uniforms, True) if uniforms is not None else None
+            o = {name: view(out[name], False) for name, _, _ in _STEP_SPEC if name in out}
+            call, _ = env.prepare_step(a, uniforms=u, auto_reset=auto_reset, out=o, write_local=write_local)
+            calls.append(call)
+            staged_runs += (len(copies_in) + len(copies_out)) > n_before
+        ctx = self._torch_stream
+
+        def call_all():
+            if copies_in or copies_out:
+                with ctx():
+                    for stage, part in copies_in:
+                        stage.copy_(part, non_blocking=True)
+                    for c in calls:
+                        c()
+                    for stage, part in copies_out:
+                        part.copy_(stage, non_blocking=True)
+            else:
+                for c in calls:
+                    c()
+            return out
+
+        call_all.in_place_runs = len(self._parts) - staged_runs       # runs that read and write the caller's tensors directly
+        return call_all, out
+
+    # -------------------------------------------------------------------------- API
     def reset(self, mask=None):
         for idx, env in self._parts:
-            env.reset(None if mask is None else np.ascontiguousarray(np.asarray(mask, np.uint8)[idx]))
+            if mask is None:
+                env.reset(None)
+            elif self.device_arrays:
+                with self._torch_stream():
+                    env.reset(mask[int(idx[0]):int(idx[-1]) + 1].clone())   # (an aligned, owned copy of the run's mask bytes)
+            else:
+                env.reset(np.ascontiguousarray(np.asarray(mask, np.uint8)[idx]))
 
-    def step(self, actions, uniforms=None, auto_reset=False):
+    def step(self, actions, uniforms=None, auto_reset=False, out=None):
         """One ``MapfEnv.step()`` per env; arrays as ``VecMapfEnv.step`` (cells are local ids OF EACH ENV'S OWN MAP)."""
         E, A = self.n_envs, self.n_agents
+        if self.device_arrays:
+            call, out = self.prepare_step(actions, uniforms=uniforms, auto_reset=auto_reset, out=out)
+            call()
+            return out['local'], out['reward'], out['done'], {k: out[k] for k in ('prob', 'collision', 'was_terminal')}
         actions = np.ascontiguousarray(actions, np.uint8).reshape(E, A)
         local, reward = np.empty((E, A), np.uint16), np.empty(E, np.float64)
         done = np.empty(E, np.uint8)
@@ -72,8 +177,19 @@ class MultiMapVecEnv:
         return local, reward, done, info
 
     def rollout(self, n_steps, actions=None, auto_reset=True):
-        """``n_steps`` fused steps per env (one launch per handle): ``returns`` / ``episodes`` / ``collisions`` [E]."""
+        """``n_steps`` fused steps per env (one launch per handle): ``returns`` / ``episodes`` / ``collisions`` [E].
+        Device mode: ``actions`` is a CUDA uint8 [T, E, A] tensor (a run's [T, run, A] part is strided, so it is copied
+        once per call) and the results are CUDA tensors; everything is enqueued on ``self.stream``."""
         E = self.n_envs
+        if self.device_arrays:
+            t = self._torch
+            parts = []
+            with self._torch_stream():
+                for idx, env in self._parts:
+                    lo, hi = int(idx[0]), int(idx[-1]) + 1
+                    a = None if actions is None else actions[:, lo:hi].contiguous()
+                    parts.append(env.rollout(n_steps, actions=a, auto_reset=auto_reset))
+                return {k: t.cat([p[k] for p in parts]) for k in ('returns', 'episodes', 'collisions')}
         res = {'returns': np.empty(E, np.float64), 'episodes': np.empty(E, np.uint32), 'collisions': np.empty(E, np.uint32)}
         for idx, env in self._parts:
             a = None if actions is None else np.ascontiguousarray(np.asarray(actions, np.uint8)[:, idx])
@@ -83,13 +199,23 @@ class MultiMapVecEnv:
         return res
 
     def get_state(self):
+        """(cells [E, A] of each env's own map, step index).  Device mode: a CUDA tensor gathered from the runs' state views
+        on ``self.stream`` (the runs' buffers are separate allocations: this is a copy)."""
+        if self.device_arrays:
+            with self._torch_stream():
+                local = self._torch.cat([env.state_view() for _, env in self._parts])
+            return local, self._parts[-1][1].t
         local = np.empty((self.n_envs, self.n_agents), np.uint16)
         t = 0
         for idx, env in self._parts:
             local[idx], t = env.get_state()
         return local, t
 
-    def close(self):
+    def sync(self):
         for _, env in self._parts:
+            env.sync()
+
+    def close(self):
+        for _, env in reversed(self._parts):            # (the first handle owns the shared stream: it goes last)
             env.close()
         self._parts = []

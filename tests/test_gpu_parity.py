@@ -952,3 +952,64 @@ def test_rollout_with_large_lds_move_table():
         assert np.array_equal(_bits(res['returns']), _bits(ref['returns'])) and np.array_equal(res['episodes'], ref['episodes'])
         assert np.array_equal(env.get_state()[0], co.state)
         env.close()
+
+
+def test_mixed_map_batch_in_device_mode_on_one_stream():
+    """MultiMapVecEnv with device_arrays=True (mapf_env.py:127: every env owns its grid): torch tensors in and out, every
+    run's launch on ONE stream, nothing waits.  48 envs on three maps in runs of 16 / 16 / 5 / 11: the runs that start at a
+    multiple of 16 envs work on the caller's tensors in place, the last one (env 37) through staging copies -- each env
+    against its own pure-Python oracle, prepared step replayed 30 times, then a fused rollout, then the gathered state."""
+    import torch
+    from gym_mapf_amd.envs.multi_map import MultiMapVecEnv
+    rs = np.random.RandomState(23)
+    maps = [['....', '.@..', '....'], ['.....', '..@..', '.....', '.....'], ['...', '...', '...']]
+    A, E, off = 4, 48, 5000
+    pick = [0] * 16 + [1] * 16 + [2] * 5 + [0] * 11
+    grids = [MapfGrid(m) for m in maps]
+    starts, goals, oracles = [], [], []
+    for e in range(E):
+        valid = grids[pick[e]].tables()[0]
+        s = [valid[i] for i in rs.choice(len(valid), A, replace=False)]
+        g = [valid[i] for i in rs.choice(len(valid), A, replace=False)]
+        starts.append(s), goals.append(g)
+        oracles.append(mo.OracleEnv(maps[pick[e]], A, s, g, 0.3, -10.0, 5.0, -1.0, mo.MAKESPAN))
+    env = MultiMapVecEnv([grids[k] for k in pick], A, starts, goals, 0.3, -10.0, 5.0, -1.0, OptimizationCriteria.Makespan,
+                         seed=9, env_id_offset=off, device_arrays=True)
+    assert env.n_handles == 4 and env.stream
+    ids = off + np.arange(E)
+    actions = torch.zeros((E, A), dtype=torch.uint8, device='cuda')
+    call, out = env.prepare_step(actions, auto_reset=True)
+    assert call.in_place_runs == 3                                   # runs at envs 0, 16, 32; the run at env 37 is staged
+    stream = torch.cuda.ExternalStream(env.stream)
+    for t in range(30):
+        acts = philox.random_actions_np(9, ids, t, A)
+        with torch.cuda.stream(stream):
+            actions.copy_(torch.as_tensor(acts, device='cuda'))       # the caller refills its tensor in place, on that stream
+        call()
+        env.sync()
+        u = philox.slip_uniforms_np(9, ids, t, A)
+        local, reward, done = out['local'].cpu().numpy(), out['reward'].cpu().numpy(), out['done'].cpu().numpy()
+        prob, coll, wt_ = out['prob'].cpu().numpy(), out['collision'].cpu().numpy(), out['was_terminal'].cpu().numpy()
+        for e, o in enumerate(oracles):
+            nxt, r, d, c, p, wt = o.step(acts[e].tolist(), u[e].tolist())
+            assert list(nxt) == local[e].tolist() and _bits(r) == _bits(reward[e]) and _bits(p) == _bits(prob[e]), (t, e)
+            assert (d, c, wt) == (bool(done[e]), bool(coll[e]), bool(wt_[e])), (t, e)
+            if d:
+                o.reset()
+    acts_ro = np.stack([philox.random_actions_np(10, ids, 30 + k, A) for k in range(12)])
+    res = env.rollout(12, actions=torch.as_tensor(acts_ro, device='cuda'), auto_reset=True)
+    env.sync()
+    returns, episodes = res['returns'].cpu().numpy(), res['episodes'].cpu().numpy()
+    for e, o in enumerate(oracles):
+        ret, epi = 0.0, 0
+        for k in range(12):
+            nxt, r, d, c, p, wt = o.step(acts_ro[k, e].tolist(), philox.slip_uniforms_np(9, [off + e], 30 + k, A)[0].tolist())
+            ret, epi = ret + r, epi + int(d)
+            if d:
+                o.reset()
+        assert _bits(ret) == _bits(returns[e]) and epi == episodes[e], e
+    state, t_now = env.get_state()
+    env.sync()
+    state = state.cpu().numpy()
+    assert t_now == 42 and all(state[e].tolist() == list(o.local) for e, o in enumerate(oracles))
+    env.close()

@@ -16,6 +16,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def per_kernel(path, counter):
@@ -44,6 +45,8 @@ def hbm_bytes(fetch, write, key):
 
 
 def main():
+    import bench
+    csrc = bench.csrc_hash()          # the kernel sources these passes ran (bench.py uses an entry only for the same sources)
     args = sys.argv[1:]
     merge = bool(args) and args[0] == "--merge"   # keep what profiles/traffic.json holds for batches not named in this call
     if merge:
@@ -66,7 +69,7 @@ def main():
         per_step = (b1 - b2) / (T1 - T2)
         alg = E * A * (5.0 + 18.0 / A)
         out["kernels"].append({
-            "kernel": label, "instance": F1["rollout_kernel"][2].split("(mapf::")[0].replace("void ", "").strip(),
+            "kernel": label, "csrc_hash": csrc, "instance": F1["rollout_kernel"][2].split("(mapf::")[0].replace("void ", "").strip(),
             "n_envs": E, "n_agents": A, "bytes_per_env_step_launch": round(per_step, 1), "fixed_bytes": round(b1 - per_step * T1, 1),
             "algorithmic_bytes_per_env_step_launch": alg,
             "measured": {str(T1): {"FETCH_SIZE_KB": round(F1["rollout_kernel"][0], 2), "WRITE_SIZE_KB": round(W1["rollout_kernel"][0], 2),
@@ -76,7 +79,7 @@ def main():
         if "step_kernel" in F1 and "step_kernel" in W1:
             name = F1["step_kernel"][2]
             out["kernels"].append({
-                "kernel": step_label or None, "instance": name.split("(mapf::")[0].replace("void ", "").strip(), "single_step_of": label,
+                "kernel": step_label or None, "csrc_hash": csrc, "instance": name.split("(mapf::")[0].replace("void ", "").strip(), "single_step_of": label,
                 "n_envs": E, "n_agents": A, "bytes_per_env_step_launch": round(hbm_bytes(F1, W1, "step_kernel"), 1), "fixed_bytes": 0.0,
                 "algorithmic_bytes_per_env_step_launch": alg,
                 "measured": {"1": {"FETCH_SIZE_KB": round(F1["step_kernel"][0], 2), "WRITE_SIZE_KB": round(W1["step_kernel"][0], 2),

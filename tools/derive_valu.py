@@ -1,24 +1,43 @@
 #!/usr/bin/env python3
-"""profiles/valu.json from one rocprofv3 SQ counter pass of the bench command (tools/refresh_profiles.sh, pass sq1:
-SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU ... with --kernel-trace): what bench.py's `roofline.valu_frac`
-is computed from.
+"""profiles/valu.json from the rocprofv3 SQ counter passes of the bench command (tools/refresh_profiles.sh: pass sq1 --
+SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU ... -- and pass sq3 -- SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_MUL_F64
+SQ_INSTS_VALU_ADD_F64 ... -- both with --kernel-trace): what bench.py's `roofline.valu_frac` is computed from.
 
-usage: python tools/derive_valu.py <label> <E> <A> <T> <counter_collection.csv> <kernel_trace.csv> [...]   (groups of six)
-       label = the rollout kernel as the library reports it for that batch (bench line `roofline.kernel`)
+usage: python tools/derive_valu.py <label> <E> <A> <T> <sq1 counter_collection.csv> <sq1 kernel_trace.csv> <sq3 counter_collection.csv> [...]
+       (groups of seven; label = the rollout kernel as the library reports it for that batch: bench line `roofline.kernel`)
 
-Per kernel instance and batch: VALU wave-instructions per launch (SQ_INSTS_VALU), the share of a SIMD's cycles during
-which its resident waves had a vector instruction in flight -- SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES (both quad-cycles
-summed over waves) x waves resident per SIMD (SQ_WAVES / 1024 SIMDs, at most 8) -- and the mean duration of the launches
-that pass measured.  The same instructions in a shorter live launch fill proportionally more of the issue slots, so
-bench.py reports valu_frac = busy_share x pass duration / live duration."""
+Per kernel instance and batch: the launch's vector wave-instructions by kind (64-bit integer, float64 multiply, float64
+add, everything else), and `valu_ms_per_simd` = the time ONE SIMD's vector ALU needs for its 1/1024 share of them when each
+kind issues at its measured peak rate (profiles/r04_valu_issue_cost.txt, tools/microbench/valu_issue_cost64.hip: ns per
+wave-instruction per SIMD at eight waves per SIMD; packed 16-bit / dot / SDWA instructions are not counted apart by the
+hardware and go in at the plain 32-bit rate, so the figure is a LOWER bound).  bench.py divides it by the live launch time.
+Also kept, from the counters alone: the launch's length in shader cycles (SQ_BUSY_CYCLES is summed over the 32 shader
+engines), the waves resident per SIMD on average (wave cycles / that length -- NOT waves launched / 1024: a 131072-env launch
+of a kernel that fits two waves per SIMD keeps two resident, not eight) and the share of its own cycles a wave spends with a
+vector instruction in flight.  A share above 1 is a broken derivation and is refused."""
 import collections
 import csv
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SIMDS = 256 * 4
+sys.path.insert(0, ROOT)
+SIMDS, SHADER_ENGINES = 256 * 4, 32
+
+
+def issue_costs_ns():
+    """{kind: ns per wave-instruction per SIMD} from the committed microbenchmark output"""
+    want = {'v_xor_b32': 'plain', 'v_mad_u64_u32': 'int64', 'v_mul_f64': 'mul_f64', 'v_add_f64': 'add_f64'}
+    out = {}
+    with open(os.path.join(ROOT, 'profiles', 'r04_valu_issue_cost.txt')) as f:
+        for line in f:
+            m = re.match(r'(\S+)(?: clamp)?\s+[0-9.]+ ms\s+([0-9.]+) ns/wave-instr/SIMD', line)
+            if m and m.group(1) in want:
+                out[want[m.group(1)]] = float(m.group(2))       # (the last v_xor_b32 line wins: the warmed one)
+    assert set(out) == set(want.values()), out
+    return out
 
 
 def rollout_means(path):
@@ -29,7 +48,7 @@ def rollout_means(path):
                 vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {}
     for c, v in vals.items():
-        full = [x for x in v if x >= 0.5 * max(v)]          # (the bench also launches one short rollout: the parity leg)
+        full = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v   # (the bench also launches one short rollout: the parity leg)
         out[c] = sum(full) / len(full)
     return out
 
@@ -45,6 +64,7 @@ def rollout_duration_ms(path):
 
 
 def main():
+    import bench
     args = sys.argv[1:]
     dst = os.path.join(ROOT, "profiles", "valu.json")
     try:
@@ -52,19 +72,35 @@ def main():
             doc = json.load(f)
     except (OSError, ValueError):
         doc = {"kernels": []}
-    doc["_how"] = " ".join(__doc__.strip().split("\n\n")[2].split())
-    while len(args) >= 6:
-        label, E, A, T, counters, trace = args[:6]
-        args = args[6:]
+    doc["_how"] = " ".join(" ".join(__doc__.strip().split("\n\n")[2:]).split())
+    cost = issue_costs_ns()
+    doc["issue_cost_ns_per_wave_instruction_per_simd"] = cost
+    while len(args) >= 7:
+        label, E, A, T, counters, trace, counters3 = args[:7]
+        args = args[7:]
         E, A, T = int(E), int(A), int(T)
         m = rollout_means(counters)
+        m3 = rollout_means(counters3)
         ms, n = rollout_duration_ms(trace)
-        per_simd = min(8.0, m["SQ_WAVES"] / SIMDS)
-        entry = {"kernel": label, "n_envs": E, "n_agents": A, "env_steps_per_launch": T,
-                 "valu_insts_per_launch": m["SQ_INSTS_VALU"], "valu_insts_per_wave_step": m["SQ_INSTS_VALU"] / m["SQ_WAVES"] / T,
-                 "waves": m["SQ_WAVES"], "waves_per_simd": per_simd,
+        n_valu = m["SQ_INSTS_VALU"]
+        n_int64, n_mul, n_add = m3["SQ_INSTS_VALU_INT64"], m3["SQ_INSTS_VALU_MUL_F64"], m3["SQ_INSTS_VALU_ADD_F64"]
+        n_plain = n_valu - n_int64 - n_mul - n_add
+        assert n_plain > 0, (n_valu, n_int64, n_mul, n_add)
+        valu_ns = n_plain * cost['plain'] + n_int64 * cost['int64'] + n_mul * cost['mul_f64'] + n_add * cost['add_f64']
+        valu_ms_per_simd = valu_ns / SIMDS / 1e6
+        launch_cycles = m["SQ_BUSY_CYCLES"] / SHADER_ENGINES
+        share = valu_ms_per_simd / ms
+        if not 0.0 < share <= 1.0:
+            raise SystemExit('derive_valu: %s at %d envs: vector-ALU time %.4f ms per SIMD against a launch of %.4f ms -- a share of %.3f cannot be' %
+                             (label, E, valu_ms_per_simd, ms, share))
+        entry = {"kernel": label, "n_envs": E, "n_agents": A, "env_steps_per_launch": T, "csrc_hash": bench.csrc_hash(),
+                 "valu_insts_per_launch": n_valu, "valu_insts_per_wave_step": n_valu / m["SQ_WAVES"] / T,
+                 "valu_insts_by_kind": {"int64": n_int64, "mul_f64": n_mul, "add_f64": n_add, "other": n_plain},
+                 "valu_ms_per_simd": valu_ms_per_simd, "valu_share_of_launch_in_pass": share,
+                 "waves": m["SQ_WAVES"], "launch_shader_cycles": launch_cycles,
+                 "shader_clock_ghz_in_pass": launch_cycles / (ms * 1e6),
+                 "waves_resident_per_simd": m["SQ_WAVE_CYCLES"] * 4.0 / (SIMDS * launch_cycles),
                  "valu_active_share_of_wave_cycles": m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"],
-                 "valu_busy_share_of_simd_cycles": m["SQ_ACTIVE_INST_VALU"] / m["SQ_WAVE_CYCLES"] * per_simd,
                  "launch_ms_in_pass": ms, "launches_in_pass": n}
         doc["kernels"] = [k for k in doc["kernels"] if not (k["kernel"] == label and k["n_envs"] == E and k["n_agents"] == A)] + [entry]
         print(json.dumps(entry, indent=1))

@@ -1,14 +1,14 @@
 #!/bin/bash
 # Regenerates the measurement artefacts kept under profiles/ on a GPU box:
-#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r03 c3 c4s'
-#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r03 c5s c5'
+#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r04 c3 c4s'
+#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r04 c5s c5'
 # writes gpurun_out/prof_<tag>/<tag>_<config>_*; copy them into profiles/ afterwards (gpurun_out/ is scratch) and
 # run tools/derive_traffic.py / tools/derive_valu.py there is no need: the script does it and copies the two JSON files
 # next to its other outputs.  Every rocprofv3 call has the program itself right after `--`; PMC passes use
 # --kernel-trace only.  Configurations: c3 = the bench default (configs[2]); c4s = configs[3]'s share of one GPU
 # (32768 envs); c5s = configs[4]'s share (16384 envs x 32 agents); c5 = configs[4] whole on one GPU.
 set -eo pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 shift || true
 configs=${*:-c3}
 out=$PWD/gpurun_out/prof_$tag
@@ -54,7 +54,7 @@ for cfg in $configs; do
             --output-format csv -d $P/$cfg/sq3 -- $BENCH > /dev/null
   for k in 1 2 3; do python3 tools/pmc_compact.py $P/$cfg/sq$k/*/*counter_collection.csv > "${pre}_pmc_sq_pass$k.csv"; done
   python3 tools/sq_summary.py $P/$cfg/sq1/*/*counter_collection.csv $P/$cfg/sq2/*/*counter_collection.csv $P/$cfg/sq3/*/*counter_collection.csv > "${pre}_sq_counters_summary.txt"
-  python3 tools/derive_valu.py "${label%%||*}" $E $A 256 $P/$cfg/sq1/*/*counter_collection.csv $P/$cfg/sq1/*/*kernel_trace.csv > /dev/null
+  python3 tools/derive_valu.py "${label%%||*}" $E $A 256 $P/$cfg/sq1/*/*counter_collection.csv $P/$cfg/sq1/*/*kernel_trace.csv $P/$cfg/sq3/*/*counter_collection.csv > /dev/null
   echo "$cfg: sq done"
 done
 
@@ -71,8 +71,17 @@ cp profiles/traffic.json "$out/traffic.json"
 cp profiles/valu.json "$out/valu.json"
 echo "traffic + valu done"
 
-# 4. the un-profiled lines: the driver's command and the default (c3 only)
+# 4. the un-profiled lines, AFTER traffic.json / valu.json exist (so that `roofline.traffic` / `valu_frac` are live in them --
+# the line under rocprofv3 above was printed before the counters of these sources had been derived): every configuration's
+# bench line; for c3 also the driver's exact command and the default
 for cfg in $configs; do
+  case $cfg in
+    c3)  flags="" ;;
+    c4s) flags="--config c4 --envs 32768" ;;
+    c5s) flags="--config c5 --envs 16384" ;;
+    c5)  flags="--config c5" ;;
+  esac
+  python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-scalar-env $flags > "$out/${tag}_${cfg}_bench.json"
   if [ "$cfg" = c3 ]; then
     python3 tools/exp/launch_series.py 300 > "$out/${tag}_launch_series.txt" 2>&1
     python3 bench.py --steps 20 --warmup 5 > "$out/${tag}_bench_steps20_warmup5.json"
