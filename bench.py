@@ -30,10 +30,11 @@ time of that region.  Rank 0 prints ONE JSON line.  Keys beyond the contract:
                 bytes / HIP-event time per launch; `traffic` = HBM bytes per launch from the committed PMC passes
                 (profiles/traffic.json: per-step + fixed part), `traffic_frac` = that / the same time / peak;
                 `valu_frac` = the time a SIMD's vector ALU needs for its share of the launch's vector instructions -- the
-                committed SQ counter passes' instruction counts by kind (profiles/valu.json: plain 32-bit, 64-bit integer,
-                float64 multiply / add) x the measured peak issue time of each kind (profiles/r04_valu_issue_cost.txt) --
-                divided by the live launch time; traffic / valu entries made from other kernel sources than this tree's
-                (csrc_hash) are not used: the keys then print null
+                committed SQ counter passes' instruction counts by kind (profiles/valu.json: 64-bit integer, float64
+                multiply / add as counted, the 32-bit rest split by the kernel's static mix into fast and ordinary
+                encodings) x the measured issue time of each kind (profiles/r04_valu_issue_cost*.txt) -- divided by the
+                live launch time; traffic / valu entries made from other kernel sources than this tree's (csrc_hash) are
+                not used: the keys then print null
   single_step_launches   the same env-steps as one mapf_step launch each, recorded ONCE into a hipGraph (256 nodes; the
                 step index lives in device memory, so every replay draws fresh numbers) and replayed; the next
                 observation is read from the handle's state view (cells written once); `plain_launches` = the same
@@ -265,8 +266,8 @@ def scalar_env_rate(budget_s=2.0):
 
 def measured_valu(kernel, n_envs, n_agents, steps_per_launch):
     """The committed SQ counter passes of `kernel` at this batch (profiles/valu.json, tools/derive_valu.py): (VALU
-    wave-instructions per launch, the time in ms a SIMD's vector ALU needs for its share of them at the measured peak issue
-    rates of their kinds -- profiles/r04_valu_issue_cost.txt), or None when no such pass of THESE kernel sources is committed."""
+    wave-instructions per launch, the time in ms a SIMD's vector ALU needs for its share of them at the measured issue
+    rates of their kinds -- profiles/r04_valu_issue_cost*.txt), or None when no such pass of THESE kernel sources is committed."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'valu.json')) as f:
             entries = json.load(f)['kernels']

@@ -14,11 +14,21 @@ using gu16 = __attribute__((address_space(1))) uint16_t *;
 using gu8 = __attribute__((address_space(1))) uint8_t *;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+// A pointer the kernel KNOWS to name device memory, typed so: pointers that reach a kernel through a re-read argument block
+// (lq_step_kernel<BIG>) are generic to the compiler, which then emits FLAT loads / stores -- and with a flat operation
+// pending every wait becomes s_waitcnt vmcnt(0), because flat operations may complete out of order.
+#define MAPF_GLOBAL __attribute__((address_space(1)))
+template <typename T> __device__ __forceinline__ MAPF_GLOBAL T *as_global(T *p) { return (MAPF_GLOBAL T *)p; }
+template <typename T> __device__ __forceinline__ MAPF_GLOBAL T *gat(T *base, uint32_t index) {   // at() of a pointer that is global
+    return (MAPF_GLOBAL T *)((MAPF_GLOBAL char *)as_global(base) + index * uint32_t(sizeof(T)));
+}
+
 // P packed dwords (2P cells) of a lane, moved as one global access
 template <int P> struct Packed;
 template <> struct Packed<1> {
     uint32_t v[1];
     static __device__ __forceinline__ Packed load(const void *p) { return Packed{{*reinterpret_cast<const uint32_t *>(p)}}; }
+    static __device__ __forceinline__ Packed load(const MAPF_GLOBAL uint16_t *p) { return Packed{{*(const MAPF_GLOBAL uint32_t *)p}}; }
     __device__ __forceinline__ void store(void *p) const { *reinterpret_cast<uint32_t *>(p) = v[0]; }
     __device__ __forceinline__ void store_global(gu16 p) const { *(gu32)p = v[0]; }
 };
@@ -26,6 +36,11 @@ template <> struct Packed<4> {
     uint32_t v[4];
     static __device__ __forceinline__ Packed load(const void *p) {
         const uint4 w = *reinterpret_cast<const uint4 *>(p);
+        return Packed{{w.x, w.y, w.z, w.w}};
+    }
+    static __device__ __forceinline__ Packed load(const MAPF_GLOBAL uint16_t *p) {
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        const u32x4_ w = *(const MAPF_GLOBAL u32x4_ *)p;
         return Packed{{w.x, w.y, w.z, w.w}};
     }
     __device__ __forceinline__ void store(void *p) const { *reinterpret_cast<uint4 *>(p) = make_uint4(v[0], v[1], v[2], v[3]); }
@@ -38,6 +53,10 @@ template <> struct Packed<2> {
     uint32_t v[2];
     static __device__ __forceinline__ Packed load(const void *p) {
         const u32x2 w = *reinterpret_cast<const u32x2 *>(p);
+        return Packed{{w.x, w.y}};
+    }
+    static __device__ __forceinline__ Packed load(const MAPF_GLOBAL uint16_t *p) {
+        const u32x2 w = *(const MAPF_GLOBAL u32x2 *)p;
         return Packed{{w.x, w.y}};
     }
     __device__ __forceinline__ void store(void *p) const { *reinterpret_cast<u32x2 *>(p) = u32x2{v[0], v[1]}; }

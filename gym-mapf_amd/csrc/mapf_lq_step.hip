@@ -138,8 +138,24 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
         stage_outcome_table(p_block.c, lds_generic<OutcomeRow>(lds, kStepOutcomeAt));
         stage_slip_table(slip_rows, lds_generic<SlipRow>(lds, kStepSlipAt));   // ends with __syncthreads()
     }
+    // ---- first trip of a chunk: state, actions, scenario byte -- issued by themselves, so that the BIG form can request the
+    // NEXT chunk's before it computes the current one (a third of a wave's cycles there went to waiting for this trip)
+    struct FirstTrip { Packed<K / 2> cells; uint64_t raw; uint32_t scen_id; };
+    auto first_trip = [&](const uint32_t chunk) __attribute__((always_inline)) {
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t e = ((chunk * block_threads + threadIdx.x) >> 6) * uint32_t(64 / Q) + lane / uint32_t(Q);
+        const uint32_t lane_cell = e * n_agents + uint32_t(K) * (lane & uint32_t(Q - 1));
+        FirstTrip f;
+        f.cells = Packed<K / 2>::load(at(state, lane_cell));
+        if constexpr (K == 8) f.raw = *reinterpret_cast<const uint64_t *>(at(actions, lane_cell));   // one action byte per agent of the lane
+        else f.raw = K == 4 ? uint64_t(*reinterpret_cast<const uint32_t *>(at(actions, lane_cell)))
+                            : uint64_t(*reinterpret_cast<const uint16_t *>(at(actions, lane_cell)));
+        f.scen_id = 0u;
+        if (SCEN) f.scen_id = *at(scen, e);
+        return f;
+    };
     // (!BIG: one block per 256 lanes, one pass.  A resident grid WITHOUT the LDS table was measured 6-8 % slower than that.)
-    auto one_chunk = [&](const uint32_t chunk, auto first_tag) __attribute__((always_inline)) {
+    auto one_chunk = [&](const uint32_t chunk, const FirstTrip &in, auto first_tag) __attribute__((always_inline)) {
     // BIG: the loop would keep every field of the argument block live in SGPRs across iterations (106 of them, one block per
     // CU); the fields are re-read from the kernarg segment through a pointer the optimiser cannot see through, so that they
     // are fetched where an iteration uses them, as in the straight-line form (scalar cache hits).
@@ -163,17 +179,12 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
     const uint32_t lane_cell = e * n_agents + uint32_t(K) * x.g;    // my first agent's element index
     const uint32_t fixed_cell = uint32_t(K) * x.g;                  // ... in a broadcast row
 
-    // ---- first trip: state, actions, scenario byte (or my cells of the goal row); the block's first 64 lanes also fetch
-    // the slip rows (96 eight-byte words) for the LDS copy
+    // ---- first trip (requested by first_trip()): state, actions, scenario byte; with it the table image / my cells of the goal row
     uint32_t c[P], g[P], sc[P];
-    const Packed<P> cells = Packed<P>::load(at(state, lane_cell));
-    uint64_t raw;                                                   // one action byte per agent of the lane
-    if constexpr (K == 8) raw = *reinterpret_cast<const uint64_t *>(at(actions, lane_cell));
-    else raw = K == 4 ? uint64_t(*reinterpret_cast<const uint32_t *>(at(actions, lane_cell)))
-                      : uint64_t(*reinterpret_cast<const uint16_t *>(at(actions, lane_cell)));
-    uint32_t scen_id = 0u;
+    const Packed<P> cells = in.cells;
+    const uint64_t raw = in.raw;
+    const uint32_t scen_id = in.scen_id;
     Packed<P> gl{}, sl{};
-    if (SCEN) scen_id = *at(scen, e);
     // (!BIG) EVERY wave fetches the 1 KB table image (slip rows + outcome rows, built on the host: TableImage) with one
     // 16-byte load per lane and writes it to LDS itself: the waves of a block write identical bytes to identical addresses
     // and a wave's LDS operations execute in order, so each wave may read the image right after its own write -- no barrier
@@ -185,7 +196,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
     // As a vector load + readfirstlane it put an s_waitcnt vmcnt(0) -- i.e. the whole first trip -- in front of the Philox rounds
     const uint64_t t_base = t_dev ? *(const __attribute__((address_space(4))) uint64_t *)(uintptr_t)t_dev : 0ull;
     __builtin_amdgcn_sched_barrier(0);
-    if (!SCEN) gl = Packed<P>::load(at(p.goal, p.goal_broadcast ? fixed_cell : lane_cell));
+    if (!SCEN) gl = Packed<P>::load(gat(p.goal, p.goal_broadcast ? fixed_cell : lane_cell));
 
     // ---- the slip call of my quad(s) for steps 2h, 2h+1 (ONE call per four agents: the stream's call unit is what a lane
     // of this kernel owns, so a single step pays one call per lane and uses half of its words; with two agents per lane the
@@ -217,8 +228,8 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
     // ---- second trip: the scenario's rows, then the move-table rows of my agents
     if (SCEN) {
         const uint32_t scen_row = scen_id * 2u * n_agents + fixed_cell;   // my cells of the env's start row; goal row: + A
-        gl = Packed<P>::load(at(p.scen_rows, scen_row + n_agents));
-        sl = Packed<P>::load(at(p.scen_rows, scen_row));
+        gl = Packed<P>::load(gat(p.scen_rows, scen_row + n_agents));   // (as_global: see mapf_lq.hpp -- the BIG form's
+        sl = Packed<P>::load(gat(p.scen_rows, scen_row));              //  argument block is re-read, its pointers generic)
     }
 #pragma unroll
     for (int i = 0; i < P; ++i) c[i] = cells.v[i];
@@ -252,6 +263,13 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
 #endif
 #pragma unroll
     for (int i = 0; i < P; ++i) { g[i] = gl.v[i]; sc[i] = sl.v[i]; }
+    // (the start cells are consumed HERE, with the goal cells: left pending until the state store at the end, their wait would
+    // sit behind the output stores -- whose number the compiler cannot count across the null-pointer branches -- as a full
+    // s_waitcnt vmcnt(0), i.e. a wait for the stores' acknowledgements and for the next chunk's prefetch)
+    if (SCEN) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) asm volatile("" : "+v"(sc[i]));
+    }
     if constexpr (!BIG) {   // complete the rows: thresholds (bias-shifted, as the packed sampling compares them) by the code's row offset
         uint32_t th[K];
 #pragma unroll
@@ -354,13 +372,13 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
     asm volatile("" :: "v"(reward), "v"(prob), "v"(out.v[0]));
     STEP_STAMP(5);   // everything computed
 #endif
-    if (p.out_local) out.store(at(p.out_local, lane_cell));
-    if (x.g == uint32_t(Q - 1) && p.out_prob) *at(p.out_prob, e) = prob;
+    if (p.out_local) out.store_global(gat(p.out_local, lane_cell));
+    if (x.g == uint32_t(Q - 1) && p.out_prob) *gat(p.out_prob, e) = prob;
     if (x.g == 0u) {
-        if (p.out_reward) *at(p.out_reward, e) = reward;
-        if (p.out_done) *at(p.out_done, e) = uint8_t(done_coll);
-        if (p.out_collision) *at(p.out_collision, e) = uint8_t(done_coll >> 16);
-        if (p.out_was_terminal) *at(p.out_was_terminal, e) = was_terminal ? 1 : 0;
+        if (p.out_reward) *gat(p.out_reward, e) = reward;
+        if (p.out_done) *gat(p.out_done, e) = uint8_t(done_coll);
+        if (p.out_collision) *gat(p.out_collision, e) = uint8_t(done_coll >> 16);
+        if (p.out_was_terminal) *gat(p.out_was_terminal, e) = was_terminal ? 1 : 0;
     }
     if (SCEN) {                                                    // MapfEnv.reset(): start cells, no reseed
         const bool back = p.auto_reset && done;                    // (a terminal state that stays is rewritten as it is)
@@ -369,7 +387,7 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
         for (int i = 0; i < P; ++i) keep.v[i] = back ? sc[i] : n[i];
         keep.store(at(state, lane_cell));
     } else if (p.auto_reset && done) {
-        Packed<P>::load(at(p.start, p.start_broadcast ? fixed_cell : lane_cell)).store(at(state, lane_cell));
+        Packed<P>::load(gat(p.start, p.start_broadcast ? fixed_cell : lane_cell)).store(at(state, lane_cell));
     } else if (!was_terminal) {
         out.store(at(state, lane_cell));
     }
@@ -394,10 +412,24 @@ __global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *con
 #endif
     };   // one_chunk
     if constexpr (BIG) {
+        // Two chunks per iteration, their first trips in two sets of registers that take turns: "cur = next" would be a
+        // register move of values still in flight, i.e. a wait for the very loads the prefetch is there to hide.
+        const uint32_t stride = gridDim.x;
+        FirstTrip a = first_trip(blockIdx.x);
 #pragma nounroll
-        for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) one_chunk(chunk, std::false_type{});
+        for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += 2u * stride) {
+            const uint32_t second = chunk + stride, third = second + stride;
+            const FirstTrip b = first_trip(second < n_chunks ? second : chunk);   // (clamped: past the end it re-reads its own)
+            __builtin_amdgcn_sched_barrier(0);                       // the requests go out HERE, ahead of this chunk's work
+            one_chunk(chunk, a, std::false_type{});
+            if (second >= n_chunks) break;
+            a = first_trip(third < n_chunks ? third : second);
+            __builtin_amdgcn_sched_barrier(0);
+            one_chunk(second, b, std::false_type{});
+        }
     } else {
-        one_chunk(blockIdx.x, std::true_type{});
+        const FirstTrip in = first_trip(blockIdx.x);
+        one_chunk(blockIdx.x, in, std::true_type{});
     }
     signal_step_done(p_block.done_flag, p_block.done_seq);
 }

@@ -6,15 +6,17 @@ SQ_INSTS_VALU_ADD_F64 ... -- both with --kernel-trace): what bench.py's `rooflin
 usage: python tools/derive_valu.py <label> <E> <A> <T> <sq1 counter_collection.csv> <sq1 kernel_trace.csv> <sq3 counter_collection.csv> [...]
        (groups of seven; label = the rollout kernel as the library reports it for that batch: bench line `roofline.kernel`)
 
-Per kernel instance and batch: the launch's vector wave-instructions by kind (64-bit integer, float64 multiply, float64
-add, everything else), and `valu_ms_per_simd` = the time ONE SIMD's vector ALU needs for its 1/1024 share of them when each
-kind issues at its measured peak rate (profiles/r04_valu_issue_cost.txt, tools/microbench/valu_issue_cost64.hip: ns per
-wave-instruction per SIMD at eight waves per SIMD; packed 16-bit / dot / SDWA instructions are not counted apart by the
-hardware and go in at the plain 32-bit rate, so the figure is a LOWER bound).  bench.py divides it by the live launch time.
-Also kept, from the counters alone: the launch's length in shader cycles (SQ_BUSY_CYCLES is summed over the 32 shader
-engines), the waves resident per SIMD on average (wave cycles / that length -- NOT waves launched / 1024: a 131072-env launch
-of a kernel that fits two waves per SIMD keeps two resident, not eight) and the share of its own cycles a wave spends with a
-vector instruction in flight.  A share above 1 is a broken derivation and is refused."""
+Per kernel instance and batch: the launch's vector wave-instructions by kind -- 64-bit integer, float64 multiply, float64
+add as the hardware counts them, and the 32-bit rest split by the kernel's STATIC mix (profiles/valu_mix.json,
+tools/valu_mix.py) into the fast kind (32-bit-encoded VOP1 / VOP2 on vector registers only, v_bitop3: ~1.2 ns per
+wave-instruction per SIMD) and the ordinary kind (VOP3, SDWA, DPP, packed, dot, perm, multiplies, compares / selects, any
+scalar or literal operand: ~1.9 ns) -- and `valu_ms_per_simd` = the time ONE SIMD's vector ALU needs for its 1/1024 share
+of them at the measured issue rates (profiles/r04_valu_issue_cost.txt and r04_valu_issue_cost32.txt,
+tools/microbench/valu_issue_cost64.hip and valu_issue_cost.hip: eight waves per SIMD, independent registers).  bench.py
+divides it by the live launch time.  Also kept, from the counters alone: the launch's length in shader cycles
+(SQ_BUSY_CYCLES is summed over the 32 shader engines), the waves resident per SIMD on average (wave cycles / that length --
+NOT waves launched / 1024: a 131072-env launch of a kernel that fits two waves per SIMD keeps two resident, not eight) and
+the share of its own cycles a wave spends with a vector instruction in flight.  A share above 1 is a broken derivation and is refused."""
 import collections
 import csv
 import json
@@ -28,16 +30,38 @@ SIMDS, SHADER_ENGINES = 256 * 4, 32
 
 
 def issue_costs_ns():
-    """{kind: ns per wave-instruction per SIMD} from the committed microbenchmark output"""
-    want = {'v_xor_b32': 'plain', 'v_mad_u64_u32': 'int64', 'v_mul_f64': 'mul_f64', 'v_add_f64': 'add_f64'}
-    out = {}
-    with open(os.path.join(ROOT, 'profiles', 'r04_valu_issue_cost.txt')) as f:
-        for line in f:
-            m = re.match(r'(\S+)(?: clamp)?\s+[0-9.]+ ms\s+([0-9.]+) ns/wave-instr/SIMD', line)
-            if m and m.group(1) in want:
-                out[want[m.group(1)]] = float(m.group(2))       # (the last v_xor_b32 line wins: the warmed one)
-    assert set(out) == set(want.values()), out
-    return out
+    """{kind: ns per wave-instruction per SIMD} from the two committed microbenchmark outputs: every kind as its ratio to
+    v_xor_b32 IN THE SAME RUN (the boxes' clocks differ by a few percent) times the mean v_xor_b32 time of the two runs;
+    'ordinary' = the median ratio of the VOP3 / SDWA / DPP / multiply / select / scalar-operand forms measured."""
+    def parse(name):
+        out = {}
+        with open(os.path.join(ROOT, 'profiles', name)) as f:
+            for line in f:
+                m = re.match(r'(.+?)\s+[0-9.]+ ms\s+([0-9.]+) ns/wave-instr/SIMD', line)
+                if m:
+                    out[m.group(1).strip()] = float(m.group(2))          # (a repeated name: the last, warmed line wins)
+        return out
+    wide, narrow = parse('r04_valu_issue_cost.txt'), parse('r04_valu_issue_cost32.txt')
+    base = 0.5 * (wide['v_xor_b32'] + narrow['v_xor_b32'])
+    ordinary = sorted(narrow[k] / narrow['v_xor_b32'] for k in (
+        'v_min3_u32', 'v_perm_b32', 'v_bfe_u32', 'v_and_or_b32', 'v_lshl_or_b32', 'v_cmp+v_cndmask', 'v_mov_b32_dpp', 'v_xor_b32_dpp',
+        'v_xor_b32_sdwa', 'v_mul_lo_u32', 'v_mul_u32_u24', 'v_mad_u32_u24', 'v_add3_u32', 'v_xor_b32 (sgpr)'))
+    return {'fast': base, 'ordinary': base * ordinary[len(ordinary) // 2],
+            'int64': base * wide['v_mad_u64_u32'] / wide['v_xor_b32'], 'mul_f64': base * wide['v_mul_f64'] / wide['v_xor_b32'],
+            'add_f64': base * wide['v_add_f64'] / wide['v_xor_b32']}
+
+
+def fast_share(instance):
+    """share of the fast kind among `instance`'s 32-bit vector instructions (static mix of THESE kernel sources)"""
+    import bench
+    with open(os.path.join(ROOT, 'profiles', 'valu_mix.json')) as f:
+        doc = json.load(f)
+    if doc.get('csrc_hash') != bench.csrc_hash():
+        raise SystemExit('derive_valu: profiles/valu_mix.json was made from other kernel sources -- run tools/valu_mix.py first')
+    for name, mix in doc['instances'].items():
+        if name in instance:
+            return mix['fast_share_of_32bit']
+    raise SystemExit('derive_valu: no static mix for %r in profiles/valu_mix.json (add the instance to tools/valu_mix.py)' % instance)
 
 
 def rollout_means(path):
@@ -51,6 +75,16 @@ def rollout_means(path):
         full = [x for x in v if x >= 0.5 * max(v)] if max(v) > 0 else v   # (the bench also launches one short rollout: the parity leg)
         out[c] = sum(full) / len(full)
     return out
+
+
+def rollout_instance(path):
+    """the rollout kernel's name as rocprofv3 prints it (of the full-length dispatches: the most frequent one)"""
+    names = collections.Counter()
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if "rollout_kernel" in r["Kernel_Name"]:
+                names[r["Kernel_Name"]] += 1
+    return names.most_common(1)[0][0]
 
 
 def rollout_duration_ms(path):
@@ -86,7 +120,10 @@ def main():
         n_int64, n_mul, n_add = m3["SQ_INSTS_VALU_INT64"], m3["SQ_INSTS_VALU_MUL_F64"], m3["SQ_INSTS_VALU_ADD_F64"]
         n_plain = n_valu - n_int64 - n_mul - n_add
         assert n_plain > 0, (n_valu, n_int64, n_mul, n_add)
-        valu_ns = n_plain * cost['plain'] + n_int64 * cost['int64'] + n_mul * cost['mul_f64'] + n_add * cost['add_f64']
+        instance = rollout_instance(counters)
+        share_fast = fast_share(instance)
+        valu_ns = n_plain * (share_fast * cost['fast'] + (1.0 - share_fast) * cost['ordinary']) + \
+            n_int64 * cost['int64'] + n_mul * cost['mul_f64'] + n_add * cost['add_f64']
         valu_ms_per_simd = valu_ns / SIMDS / 1e6
         launch_cycles = m["SQ_BUSY_CYCLES"] / SHADER_ENGINES
         share = valu_ms_per_simd / ms
@@ -95,7 +132,9 @@ def main():
                              (label, E, valu_ms_per_simd, ms, share))
         entry = {"kernel": label, "n_envs": E, "n_agents": A, "env_steps_per_launch": T, "csrc_hash": bench.csrc_hash(),
                  "valu_insts_per_launch": n_valu, "valu_insts_per_wave_step": n_valu / m["SQ_WAVES"] / T,
-                 "valu_insts_by_kind": {"int64": n_int64, "mul_f64": n_mul, "add_f64": n_add, "other": n_plain},
+                 "valu_insts_by_kind": {"int64": n_int64, "mul_f64": n_mul, "add_f64": n_add, "other_32bit": n_plain,
+                                        "fast_share_of_other_32bit": share_fast},
+                 "instance": instance.split("(mapf::")[0].replace("void ", "").strip(),
                  "valu_ms_per_simd": valu_ms_per_simd, "valu_share_of_launch_in_pass": share,
                  "waves": m["SQ_WAVES"], "launch_shader_cycles": launch_cycles,
                  "shader_clock_ghz_in_pass": launch_cycles / (ms * 1e6),

@@ -13,6 +13,8 @@ shift || true
 configs=${*:-c3}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p "$out"
+# the static instruction mix (tools/valu_mix.py, made in the build container) must belong to THESE kernel sources
+python3 -c "import json, bench; assert json.load(open('profiles/valu_mix.json'))['csrc_hash'] == bench.csrc_hash(), 'run tools/valu_mix.py first'"
 export TMPDIR=/tmp
 P=/tmp/prof
 rm -rf $P && mkdir -p $P
