@@ -97,6 +97,13 @@ def rollout_duration_ms(path):
     return sum(full) / len(full), len(full)
 
 
+def price(counts, share_fast, cost):
+    """vector-ALU time in ns of a launch: counts = (32-bit rest, 64-bit integer, float64 multiply, float64 add)"""
+    n_plain, n_int64, n_mul, n_add = counts
+    return n_plain * (share_fast * cost['fast'] + (1.0 - share_fast) * cost['ordinary']) + \
+        n_int64 * cost['int64'] + n_mul * cost['mul_f64'] + n_add * cost['add_f64']
+
+
 def main():
     import bench
     args = sys.argv[1:]
@@ -122,8 +129,7 @@ def main():
         assert n_plain > 0, (n_valu, n_int64, n_mul, n_add)
         instance = rollout_instance(counters)
         share_fast = fast_share(instance)
-        valu_ns = n_plain * (share_fast * cost['fast'] + (1.0 - share_fast) * cost['ordinary']) + \
-            n_int64 * cost['int64'] + n_mul * cost['mul_f64'] + n_add * cost['add_f64']
+        valu_ns = price((n_plain, n_int64, n_mul, n_add), share_fast, cost)
         valu_ms_per_simd = valu_ns / SIMDS / 1e6
         launch_cycles = m["SQ_BUSY_CYCLES"] / SHADER_ENGINES
         share = valu_ms_per_simd / ms

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Static instruction mix of the bench's rollout kernel instances (no GPU needed: hipcc -S): which share of a kernel's
-32-bit vector instructions is of the FAST kind -- VOP1 / VOP2 in the 32-bit encoding with vector-register operands only
-(v_xor, v_and, v_or, v_add, shifts, v_mov) and v_bitop3, which issue every ~1.2 ns per SIMD -- and which is of the ordinary
-kind (VOP3 encodings, SDWA, DPP, packed, dot, perm, multiplies, compares / selects, anything with a scalar or literal
-operand: ~1.9 ns; profiles/r04_valu_issue_cost32.txt).  64-bit integer and float64 instructions are counted by the
+32-bit vector instructions is of the FAST kind -- bitwise logic, add / sub, right shifts, moves and v_bitop3 on vector
+registers (inline constants and literals allowed), which issue every ~1.2 ns per SIMD -- and which is of the ordinary kind
+(left shifts, min / max, compares / selects, multiplies, perm, alignbit, the fused shift-add / or3 / add3 forms, packed,
+dot, SDWA, DPP, anything with a scalar-register operand: ~1.9 ns; profiles/r04_valu_issue_cost32.txt and
+r04_valu_issue_cost_forms.txt).  64-bit integer and float64 instructions are counted by the
 hardware (SQ_INSTS_VALU_INT64 / _MUL_F64 / _ADD_F64) and are left out here.  Writes profiles/valu_mix.json, keyed by the
 instance's template arguments as rocprofv3 prints them, with the hash of the kernel sources; tools/derive_valu.py prices a
 launch's counted vector instructions with it.
@@ -20,7 +21,11 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 CSRC = os.path.join(ROOT, 'gym-mapf_amd', 'csrc')
-FAST = re.compile(r'^v_(xor|and|or|add|sub|subrev|lshlrev|lshrrev|ashrrev|mov|not|min|max)_[a-z0-9]+_e32$|^v_mov_b64_e32$|^v_bitop3_b32$')
+# measured fast (profiles/r04_valu_issue_cost_forms.txt): bitwise logic, add / sub, right shifts and moves -- in the 32-bit or
+# the VOP3 encoding, with vector registers, inline constants or a literal -- and v_bitop3 on vector registers.  Measured
+# ordinary (1.5-1.65 x): LEFT shifts, v_min / v_max, compares, selects, multiplies, v_perm, v_alignbit, v_lshl_add / _or,
+# v_or3, v_add3, packed 16-bit, dot, SDWA, DPP, and ANY instruction with a scalar-register operand (v_bitop3 included).
+FAST = re.compile(r'^v_(xor|and|or|add|sub|subrev|lshrrev|mov|not)_[a-z0-9]+(_e32|_e64)?$|^v_mov_b64_e32$|^v_bitop3_b32$')
 WIDE = re.compile(r'^v_(mad_u64_u32|mad_i64_i32|lshl_add_u64|lshlrev_b64|lshrrev_b64|add_f64|mul_f64|fma_f64|cvt_f64|cmp_\w+_f64|cmp_\w+_u64)')
 
 
@@ -33,11 +38,7 @@ def classify(line):
     if WIDE.match(op):
         return 'wide'
     operands = text[len(op):]
-    if FAST.match(op):
-        # a scalar register, a literal or an inline constant other than a small integer keeps the 32-bit encoding but
-        # measured like the ordinary kind (v_xor_b32 with an SGPR: 1.57 x)
-        if re.search(r'\bs\d+\b|\bs\[|\bvcc\b|\bexec\b|0x[0-9a-f]+', operands):
-            return 'ordinary'
+    if FAST.match(op) and not re.search(r'\bs\d+\b|\bs\[|\bvcc\b|\bexec\b|\bsdwa\b|dst_sel|quad_perm|row_', operands):
         return 'fast'
     return 'ordinary'
 
