@@ -196,6 +196,7 @@ struct RolloutTuning {
     bool bitmap_pairs = true;        // MAPF_BITMAP_PAIRS=0: the 32-agent rollout keeps the all-pairs collision tests (tests compare both)
     int step_big = 1;                // MAPF_STEP_BIG: the packed single step's resident-grid / LDS-table form -- 0 never, 1 for batches
                                      //   of at least four times what the device holds at once (default), 2 whenever it fits (tests)
+    unsigned step_block = 0;         // MAPF_STEP_BLOCK=64|128|256|512: block size of the plain packed single step (experiments; 0 = by batch)
     bool scen_table = true;          // MAPF_SCEN_TABLE=0: never build the scenario table (StepArgs::scen) -- tests compare both forms
 };
 RolloutTuning default_rollout_tuning(int device);

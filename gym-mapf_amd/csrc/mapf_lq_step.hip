@@ -97,7 +97,7 @@ static_assert(kStepArgsOffset % alignof(StepArgs) == 0, "the block follows the l
 static_assert(kStepLds <= kStepMoveAt, "LDS image of the BIG form: slip rows, outcome rows, then the move table");
 
 template <int Q, int K, bool SCEN, bool TERM, bool BIG = false>
-__global__ void __launch_bounds__(BIG ? 1024 : 256) lq_step_kernel(uint16_t *const state, const uint8_t *const actions, const uint8_t *const scen,
+__global__ void __launch_bounds__(BIG ? 1024 : 512) lq_step_kernel(uint16_t *const state, const uint8_t *const actions, const uint8_t *const scen,
                                                       const SlipRow *const slip_rows, const uint64_t *const t_dev,
                                                       const uint32_t agents_block, const uint32_t t_lo, const uint32_t seed_lo,
                                                       const uint32_t seed_hi, const StepArgs p_block, const uint32_t n_chunks) {
@@ -521,6 +521,7 @@ bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning 
     }
     unsigned block = 256u;
     while (block > 64u && lanes < 256u * uint64_t(block)) block /= 2u;   // small batches: spread over the CUs
+    if (tune.step_block == 64u || tune.step_block == 128u || tune.step_block == 256u || tune.step_block == 512u) block = tune.step_block;
     const uint64_t per_block = block / unsigned(Q);
     if (args.n_envs == 0 || args.n_envs % per_block != 0) return false;
     const unsigned grid = unsigned(args.n_envs / per_block);
