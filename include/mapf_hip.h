@@ -108,7 +108,10 @@ int mapf_reset(mapf_handle_t h, const uint8_t *mask);
  *   actions   u8 [E*A]   per-agent actions (the decoded joint action, :242-243)
  *   uniforms  f64[E*A]   the rand() values the reference would draw in agent order
  *                        (:255), or NULL: drawn on device from Philox4x32-10 keyed by
- *                        (seed; global env id, step index t, agent)
+ *                        (seed; global env id, step index t, agent) -- the exact counter layout is
+ *                        oracle/philox.py's (ABI 4: one call per agent QUAD per two steps; ABI 3
+ *                        used one per agent pair per four steps, so the same seed draws other
+ *                        numbers than it did there)
  *   out_local u16[E*A]   the state step() returns, as per-agent cells
  *   out_reward f64[E], out_done u8[E], out_collision u8[E], out_prob f64[E]
  *   out_was_terminal u8[E]: 1 where the env was already terminal, i.e. the reference
