@@ -4,10 +4,11 @@
 // counts, ragged batches) stays with lg_step_kernel (mapf_lg_kernels.hip), whose semantics this kernel reproduces
 // line by line.
 //
-// A single step is launch- and latency-bound (argument block -> state / actions -> table rows -> stores, with ~290 vector
+// A single step is launch- and latency-bound (argument block -> state / actions -> table rows -> stores, with ~225 vector
 // instructions in between and ~1 us of dispatch overhead around it): what the kernel is built around is described at its
-// template below; the measurements behind every choice are profiles/r03_step_stamps_*.txt, r03_single_step_scaling.txt,
-// r03_step_index_costs.txt and r03_kernel_end_costs.txt.
+// template below; the measurements behind every choice are profiles/r03_step_stamps_*.txt, r03_step_index_costs.txt,
+// r03_kernel_end_costs.txt (round 3) and r04_step_stamps_65536.txt, r04_step_table_forms.txt, r04_single_step_scaling.txt
+// (round 4: one Philox call per lane, scalar t_dev load, no block barrier, 8-byte table rows) -- DESIGN.md 4.2.
 #include "mapf_lq.hpp"
 
 #include <type_traits>
@@ -80,7 +81,7 @@ constexpr uint32_t kStepSlipAt = offsetof(TableImage, slip), kStepOutcomeAt = of
 //     the previous call auto-reset every finished episode and no START state is itself terminal) -- the usual training
 //     loop -- and the !TERM instance drops is_terminal(prev): the duplicate-cell half of the pair tests, the on-goal test
 //     of the current cells and every was-terminal select.
-//   * BIG = the form for batches several times larger than the device holds at once (profiles/r03_single_step_scaling.txt):
+//   * BIG = the form for batches several times larger than the device holds at once (profiles/r04_single_step_scaling.txt):
 //     there the step is bound by the texture path's rate for DIVERGENT gathers -- four 16-byte table rows per lane, 64
 //     different cache lines per wave-instruction, ~1 line per cycle -- not by arithmetic or HBM.  A resident grid of
 //     1024-thread blocks (two per CU) stages the whole move table into LDS once and walks the batch in chunks of 1024
@@ -455,7 +456,7 @@ bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning 
     const bool scen = args.scen != nullptr, term = !args.state_not_terminal;
     const uint8_t *const no_scen = nullptr;
     // The BIG form (resident grid, move table in LDS): batches several times what the device holds at once
-    // (profiles/r03_single_step_scaling.txt), a table that leaves room for two 1024-thread blocks per CU.
+    // (profiles/r04_single_step_scaling.txt), a table that leaves room for two 1024-thread blocks per CU.
     // MAPF_STEP_BIG=0 never, =2 whenever it fits.
     const size_t big_lds = kStepMoveAt + size_t(args.c.n_cells) * kBigCols * sizeof(MoveEntry);
     int n_cu = 256, dev = 0;
