@@ -215,15 +215,16 @@ __device__ __forceinline__ PairAcc<true> packed_pair_tests(const LaneCtx<Q> &x, 
 }
 
 // ---- vertex / swap facts of an env through a per-env LDS occupancy bitmap instead of all agent pairs (32 agents: 496
-// pairs are ~3/4 of a step's vector instructions; this is O(A)).  TWO bits per cell -- "an agent stood here when the step
-// began" and "an agent ends here" -- so one returning atomic per agent answers both questions.  The env's lanes sit in
-// ONE wave and a wave's LDS operations execute in program order, so no barrier is needed between the phases:
-//   1. every agent sets the START bit of its current cell;
-//   2. every agent sets the END bit of its next cell with a returning atomic OR and looks at the old word:
-//      END bit already set  <=>  two agents end in one cell: the vertex collision (mapf_env.py:386-387);
-//      START bit set and next != current  <=>  it moves onto a cell another agent held when the step began -- the only
-//      agents that can be half of a swap (:382-384): "candidates";
-//   3. the touched words are cleared;
+// pairs are ~3/4 of a step's vector instructions; this is O(A)).  ONE bit per cell -- "an agent ends here" -- and three
+// LDS operations per agent (rounds 3-4 kept a second bit, "an agent stood here when the step began": four operations and a
+// bitmap twice the size).  The env's lanes sit in ONE wave and a wave's LDS operations execute in program order, so no
+// barrier is needed between the phases:
+//   1. every agent sets the bit of its NEXT cell with a returning atomic OR and looks at the old word:
+//      bit already set  <=>  two agents end in one cell: the vertex collision (mapf_env.py:386-387);
+//   2. every agent READS the word of its CURRENT cell: bit set and next != current  <=>  another agent ends on the cell it
+//      leaves (current cells of a non-terminal state are distinct) -- both halves of a swap (:382-384) see that, so they
+//      are the "candidates";
+//   3. the touched words (next cells) are cleared;
 //   4. a swap needs TWO candidates in one env (each partner moves onto the other's cell), which is rare (an agent in a
 //      hundred is a candidate on the 32-agent maps): only while some env of the wave has two does each group elect its
 //      lowest candidate, broadcast its (current, next) pair, and every lane compare its own agents' (next, current)
@@ -242,32 +243,48 @@ template <int Q, int K, typename Image>
 __device__ __forceinline__ PairAcc<true> bitmap_pair_tests(const LaneCtx<Q> &x, Image image, uint32_t bitmap_at, const uint32_t (&c)[K / 2],
                                                            const uint32_t (&n)[K / 2]) {
     static_assert(Q <= 16 && K <= 8, "a group is at most one 16-lane row");
-    uint32_t cur[K], nxt[K], wc[K], wn[K], sn[K];
+    // cell -> word (cell >> 5) * 4 bytes, bit cell & 31: shifts and bit-field extracts take the low five bits of their
+    // count register by themselves, so an even agent's count is its packed register as it is
+    uint32_t cnt_c[K], cnt_n[K], wc[K], wn[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        cur[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu;
-        nxt[k] = (k & 1) ? n[k / 2] >> 16 : n[k / 2] & 0xFFFFu;
-        wc[k] = bitmap_at + ((cur[k] >> 4) << 2);
-        wn[k] = bitmap_at + ((nxt[k] >> 4) << 2);
-        sn[k] = (nxt[k] & 15u) << 1;
+        cnt_c[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2];             // (even agents: the odd agent's cell rides in the high half)
+        cnt_n[k] = (k & 1) ? n[k / 2] >> 16 : n[k / 2];
+        wc[k] = bitmap_at + ((c[k / 2] >> ((k & 1) ? 19 : 3)) & 0x1FFCu);
+        wn[k] = bitmap_at + ((n[k / 2] >> ((k & 1) ? 19 : 3)) & 0x1FFCu);
     }
+    uint32_t old[K], seen[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) __hip_atomic_fetch_or((lds_u32)lds_addr(image, wc[k]), 1u << ((cur[k] & 15u) << 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    uint32_t old[K];
+    for (int k = 0; k < K; ++k) old[k] = __hip_atomic_fetch_or((lds_u32)lds_addr(image, wn[k]), 1u << (cnt_n[k] & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-    for (int k = 0; k < K; ++k) old[k] = __hip_atomic_fetch_or((lds_u32)lds_addr(image, wn[k]), 2u << sn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int k = 0; k < K; ++k) seen[k] = __hip_atomic_load((lds_u32)lds_addr(image, wc[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
-    for (int k = 0; k < K; ++k) { *(lds_u32)lds_addr(image, wc[k]) = 0u; *(lds_u32)lds_addr(image, wn[k]) = 0u; }
-    uint32_t cand = 0u, vertex_hit = 0u;
+    for (int k = 0; k < K; ++k) __hip_atomic_store((lds_u32)lds_addr(image, wn[k]), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // (v_bfe_u32 reads bits 4:0 of its offset operand, so the count registers go in unmasked)
+    // candidate k: the bit of my current cell is set and I moved (half-word k of c ^ n is not zero: a v_min with a word
+    // select, written out -- the optimiser turns min(x, 1) into compare + select through a scalar mask)
+    uint32_t is_cand[K], n_mine = 0u, vertex_hit = 0u, one = 1u;
+    asm volatile("" : "+v"(one));
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        const uint32_t bits = old[k] >> sn[k];                      // bit 0: START of my next cell, bit 1: END of it
-        vertex_hit |= bits & 2u;
-        cand |= ((bits & 1u) != 0u && nxt[k] != cur[k]) ? 1u << k : 0u;
+        const uint32_t diff = c[k / 2] ^ n[k / 2];
+        uint32_t moved;
+        if (k & 1) asm("v_min_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(moved) : "v"(diff), "v"(one));
+        else asm("v_min_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(moved) : "v"(diff), "v"(one));
+        is_cand[k] = __builtin_amdgcn_ubfe(seen[k], cnt_c[k], 1u) & moved;
+        n_mine += is_cand[k];
+        vertex_hit |= __builtin_amdgcn_ubfe(old[k], cnt_n[k], 1u);
     }
     uint32_t swap_hit = 0u;
-    const uint32_t n_cand = group_reduce<Q, true>(uint32_t(__builtin_popcount(cand)), x);
+    const uint32_t n_cand = group_reduce<Q, true>(n_mine, x);
     if (__builtin_expect(__any(n_cand >= 2u), 0)) {
+        uint32_t cand = 0u, cur[K], nxt[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            cand |= is_cand[k] << k;
+            cur[k] = cnt_c[k] & 0xFFFFu;
+            nxt[k] = cnt_n[k] & 0xFFFFu;
+        }
         while (__any(cand != 0u)) {
             const uint32_t k_low = uint32_t(__builtin_ctz(cand | 0x100u));              // my lowest candidate slot (8 = none)
             const uint32_t key = cand ? (x.g << 3) | k_low : 0xFFFFu;
@@ -287,7 +304,7 @@ __device__ __forceinline__ PairAcc<true> bitmap_pair_tests(const LaneCtx<Q> &x, 
     }
     PairAcc<true> acc;
     acc.dup = 0xFFFFFFFFu;
-    acc.vertex = min(vertex_hit, 1u) - 1u;   // 0 <=> hit (both half-words zero), else all ones
+    acc.vertex = vertex_hit - 1u;            // 0 <=> hit (both half-words zero), else all ones
     acc.swap = swap_hit - 1u;
     return acc;
 }

@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     }
     uint32_t bitmap_at = 0u;
     if (BITMAP) {
-        const uint32_t stride = (((p.c.n_cells + 15u) >> 4) * 4u + 15u) & ~15u;    // bytes per env: two bits per cell
+        const uint32_t stride = (((p.c.n_cells + 31u) >> 5) * 4u + 15u) & ~15u;    // bytes per env: one bit per cell
         bitmap_at = bitmap_base + (threadIdx.x / uint32_t(Q)) * stride;
         const uint32_t n_words = (blockDim.x / uint32_t(Q)) * (stride >> 2);
         for (uint32_t w = threadIdx.x; w < n_words; w += blockDim.x) *(lds_u32)lds_addr(lds, bitmap_base + 4u * w) = 0u;
@@ -545,7 +545,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
 }
 
 // bytes of one env's occupancy bitmap (BITMAP instances)
-static size_t bitmap_stride(uint32_t n_cells) { return (size_t((n_cells + 15u) / 16u) * 4u + 15u) & ~size_t(15); }   // two bits per cell
+static size_t bitmap_stride(uint32_t n_cells) { return (size_t((n_cells + 31u) / 32u) * 4u + 15u) & ~size_t(15); }   // one bit per cell
 
 template <int Q, int K, bool RECORD, bool STREAM, bool COMPACT = false, bool BITMAP = false>
 hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream) {
