@@ -689,22 +689,25 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
         int n_cu = 256, dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
         const size_t bitmap_lds = kMoveAt + size_t(args.c.n_cells) * kBitmapCols * kCompactEntry;   // (no STAY column in that form)
-        // 32 agents: eight per lane (Q = 4, one 512-thread block per CU) once the batch gives every CU two such blocks' worth
-        // (C5 whole on one GPU: 484 G agent-steps/s against 444 G for the bitmap form below, profiles/r03_configs.txt)
-        if ((tune.force_k == 0 || tune.force_k == 8) && n_agents == 32 && layout_fits(n_agents, 8, args, lds_bytes, &block, &Q) &&
-            args.n_envs % (512u / 4u) == 0 && (tune.force_k == 8 || args.n_envs * 4u >= tune.oct_min_lanes)) {
-            block = 512u;
-            K = 8;
-        } else
-        // 32 agents below that: four per lane, collisions through per-env occupancy bitmaps (64 envs per 512-thread block)
-        // when the bitmaps fit behind the table -- O(A) instead of 496 pair tests per env (C5's share of one GPU: 419 G
-        // against 377 G)
+        // 32 agents: four per lane, collisions through per-env occupancy bitmaps behind the table (one bit per cell) -- O(A)
+        // instead of 496 pair tests per env.  64 envs per 512-thread block; 128 per 1024-thread block (four waves per SIMD)
+        // once the batch gives every CU a block of that size and 128 bitmaps fit (C5's share of one GPU: 481 G against 377 G
+        // for the all-pairs form; C5 whole: profiles/r04_c5_one_bit_bitmap_ab.txt).  MAPF_LQ_K=8 / MAPF_BITMAP_PAIRS=0 keep the
+        // all-pairs forms reachable (eight agents per lane, Q = 4, one 512-thread block per CU; four per lane below).
+        const size_t per_env = bitmap_stride(args.c.n_cells);
+        unsigned bitmap_block = 512u;
+        if (tune.bitmap_block == 1024u || (tune.bitmap_block == 0u && args.n_envs * 8u >= uint64_t(n_cu) * 1024u)) bitmap_block = 1024u;
+        if (bitmap_block == 1024u && (args.n_envs % (1024u / 8u) != 0 || bitmap_lds + (1024u / 8u) * per_env > kLdsBytes)) bitmap_block = 512u;
         if (tune.bitmap_pairs && n_agents == 32 && tune.force_k != 8 && tune.force_k != 2 && layout_fits(n_agents, 4, args, bitmap_lds, &block, &Q) &&
-            args.n_envs % (512u / 8u) == 0 && bitmap_lds + (512u / 8u) * bitmap_stride(args.c.n_cells) <= kLdsBytes) {
-            block = 512u;
+            args.n_envs % (bitmap_block / 8u) == 0 && bitmap_lds + (bitmap_block / 8u) * per_env <= kLdsBytes) {
+            block = bitmap_block;
             K = 4;
             bitmap = true;
             lds_bytes = bitmap_lds;
+        } else if ((tune.force_k == 0 || tune.force_k == 8) && n_agents == 32 && layout_fits(n_agents, 8, args, lds_bytes, &block, &Q) &&
+                   args.n_envs % (512u / 4u) == 0 && (tune.force_k == 8 || args.n_envs * 4u >= tune.oct_min_lanes)) {
+            block = 512u;
+            K = 8;
         } else {
             if (tune.force_k == 8 || !layout_fits(n_agents, 4, args, lds_bytes, &block, &Q) || Q < 4) return false;
             block = 512u;

@@ -421,6 +421,8 @@ def _goal_scenario_tables(n_agents, n_envs, seed):
     (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_PAIRS': '0'}),
     # (32 agents, 8-byte rows: collisions through per-env LDS occupancy bitmaps instead of the 496 agent pairs -- the default)
     (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
+    # (... in 1024-thread blocks, 128 bitmaps behind the table: what a batch that fills every CU with such a block gets)
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024'}),
     (64, 16384, 'lq_rollout_kernel<Q=16,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
     (8, 300, 'lg_rollout_kernel<L=4,FULL,MV_GLOBAL', {}), (5, 600, 'lg_rollout_kernel<L=4,RAGGED', {}),
     (8, 16417, 'lg_rollout_kernel<L=4,FULL,MV_LDS', {}), (6, 512, 'rollout_kernel<A=6>', {})])
@@ -649,6 +651,19 @@ def test_config5_bench_tables_16384_envs_under_default_dispatch(monkeypatch):
     assert all(len(set(r.tolist())) == cfg['agents'] for r in start[:512])
     assert _full_size_check(grid, nbr, cfg['agents'], start, goal, cfg['fail_prob'], OptimizationCriteria.Makespan,
                             mo.MAKESPAN, 4, 16, env_id_offset=offset) > 500
+
+
+def test_config5_whole_131072_envs_under_default_dispatch(monkeypatch):
+    """BASELINE configs[4] whole on ONE GPU (131072 envs x 32 agents, as `bench.py --config c5` builds it): every CU gets a
+    1024-thread block, so the default dispatch is the occupancy-bitmap form with 128 bitmaps behind the table -- every env of
+    every step against the C oracle (single steps, a streamed recorded rollout, a policy-stream rollout)."""
+    import bench
+    monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    cfg = bench.CONFIGS['c5']
+    grid, _, nbr, start, goal = bench.workload_tables(cfg, cfg['envs'], 0)
+    assert _full_size_check(grid, nbr, cfg['agents'], start, goal, cfg['fail_prob'], OptimizationCriteria.Makespan, mo.MAKESPAN, 2, 8,
+                            want_rollout='lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=1024',
+                            n_streamed=8) > 4000
 
 
 def test_config5_random64_32agents_16384_envs():
