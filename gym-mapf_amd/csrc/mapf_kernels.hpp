@@ -194,6 +194,7 @@ struct RolloutTuning {
     int force_k = 0;                 // MAPF_LQ_K=2|4|8 pins the agents per lane of the packed layout (tests)
     size_t mv_lds_max_bytes = 0;     // largest move table staged into LDS (MAPF_MV_LDS_MAX_BYTES; default: two blocks per CU)
     bool bitmap_pairs = true;        // MAPF_BITMAP_PAIRS=0: the 32-agent rollout keeps the all-pairs collision tests (tests compare both)
+    bool bitmap_stay_column = true;  // MAPF_BITMAP_STAYCOL=0: the bitmap form always stages the four-column table (tests)
     unsigned bitmap_block = 0;       // MAPF_BITMAP_BLOCK=512|1024: block size of the bitmap form (experiments / tests; 0 = by batch)
     int step_big = 1;                // MAPF_STEP_BIG: the packed single step's resident-grid / LDS-table form -- 0 never, 1 for batches
                                      //   of at least four times what the device holds at once (default), 2 whenever it fits (tests)

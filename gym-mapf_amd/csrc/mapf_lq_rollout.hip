@@ -51,7 +51,7 @@ static_assert(sizeof(SlipRow) * 8 + sizeof(OutcomeRow) * 16 <= kLdsReserve, "sta
 // in-kernel policy.  Memory pipeline and store scheme as lg_rollout_kernel<DENSE>.
 constexpr uint32_t kSlipAt = 0, kOutcomeAt = sizeof(SlipRow) * 8, kMoveAt = kLdsReserve, kMoveCols = 6;
 constexpr uint32_t kCompactCols = 5, kCompactEntry = 8;   // COMPACT: cells + code only, no sixth column
-constexpr uint32_t kBitmapCols = 4;                       // COMPACT + BITMAP: no STAY column either
+constexpr uint32_t kBitmapCols = 4;                       // COMPACT + BITMAP == 1: no STAY column either
 static_assert(kOutcomeAt + sizeof(OutcomeRow) * 16 <= kMoveAt, "LDS image: slip rows, outcome rows, then the move table");
 
 // TERM = an env may be terminal when a step begins.  With auto-reset on and no env whose START state is itself
@@ -60,7 +60,9 @@ static_assert(kOutcomeAt + sizeof(OutcomeRow) * 16 <= kMoveAt, "LDS image: slip 
 // BITMAP = the vertex / swap facts come from a per-env LDS occupancy bitmap (bitmap_pair_tests in mapf_lq.hpp) instead of
 // all agent pairs: O(A) instead of O(A^2) -- the 32-agent configurations, where 496 pairs were three quarters of a step.
 // The bitmaps (one per env of the block, ceil(V / 32) words each) follow the move table in the LDS image at `bitmap_base`.
-template <int Q, int K, bool RECORD, bool STREAM, bool SOC, bool COMPACT, bool TERM, bool BITMAP = false>
+// BITMAP == 1: the table has FOUR columns (the moves; a STAY row is made up in registers) -- the form that leaves room for 128
+// bitmaps, i.e. 1024-thread blocks; BITMAP == 2: five columns (STAY included: no selects per agent), 64 bitmaps, 512 threads.
+template <int Q, int K, bool RECORD, bool STREAM, bool SOC, bool COMPACT, bool TERM, int BITMAP = 0>
 __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents, const uint32_t bitmap_base) {
     constexpr int P = K / 2;   // packed dwords per lane
     static_assert(K == 2 || K == 4 || K == 8, "two, four or eight agents per lane");
@@ -92,9 +94,9 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     {   // move table -> LDS with six columns per cell (0..4 = the actions, 5 = STAY again: where out-of-range action
         // bytes are clamped to), batches of four independent loads per thread
         // (COMPACT: five columns, the first 8 bytes of every row)
-        // (COMPACT + BITMAP: FOUR columns -- the moves; a STAY row is (cell, cell, cell) with the all-equal code and is made
+        // (COMPACT + BITMAP == 1: FOUR columns -- the moves; a STAY row is (cell, cell, cell) with the all-equal code and is made
         // up in registers -- which leaves room for the occupancy bitmaps behind the table)
-        constexpr uint32_t kCols = !COMPACT ? kMoveCols : (BITMAP ? kBitmapCols : kCompactCols);
+        constexpr uint32_t kCols = !COMPACT ? kMoveCols : (BITMAP == 1 ? kBitmapCols : kCompactCols);
         const uint32_t n_words = p.c.n_cells * kCols;
         for (uint32_t w0 = threadIdx.x; w0 < n_words; w0 += 4u * blockDim.x) {
             MoveEntry part[4];
@@ -102,7 +104,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
             for (uint32_t k = 0; k < 4u; ++k) {
                 const uint32_t w = min(w0 + k * blockDim.x, n_words - 1u);
                 const uint32_t cell = w / kCols, col = w - cell * kCols;
-                part[k] = p.mv[!COMPACT ? cell * kMvCols + (col < kMvCols ? col : 0u) : cell * kMvCols + col + (BITMAP ? 1u : 0u)];
+                part[k] = p.mv[!COMPACT ? cell * kMvCols + (col < kMvCols ? col : 0u) : cell * kMvCols + col + (BITMAP == 1 ? 1u : 0u)];
             }
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) {
@@ -249,7 +251,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     // steps, so the prefetch address is clamped.  `raw` is the register that holds this step's action word.
     uint32_t pk_eights = 0x00080008u, pk_steps = 0x02020202u, sel_base = 0x0C0C0504u;   // sample_slot_packed's constants,
     asm volatile("" : "+v"(pk_eights), "+v"(pk_steps), "+v"(sel_base));                   // one vector register each
-    uint32_t row_bytes = COMPACT ? (BITMAP ? kBitmapCols : kCompactCols) * kCompactEntry : kMoveCols * uint32_t(sizeof(MoveEntry));
+    uint32_t row_bytes = COMPACT ? (BITMAP == 1 ? kBitmapCols : kCompactCols) * kCompactEntry : kMoveCols * uint32_t(sizeof(MoveEntry));
     asm volatile("" : "+v"(row_bytes));   // (one register for the whole loop; as an SGPR operand the assembler rejects the SDWA form)
     auto one_step = [&](const uint32_t s, RawWord &raw, auto w_tag, auto first_tag, auto tail_tag) __attribute__((always_inline)) {
         constexpr int W = decltype(w_tag)::value;
@@ -310,7 +312,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         for (int k = 0; k < K; ++k) asm volatile("" : "+v"(cell_at[k]));
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (COMPACT && BITMAP) cells_code[k] = lds_at<u32x2>(lds, kMoveAt - kCompactEntry + (act[k] << 3) + cell_at[k]);   // column act - 1 (STAY: see below)
+            if (COMPACT && BITMAP == 1) cells_code[k] = lds_at<u32x2>(lds, kMoveAt - kCompactEntry + (act[k] << 3) + cell_at[k]);   // column act - 1 (STAY: see below)
             else if (COMPACT) cells_code[k] = lds_at<u32x2>(lds, kMoveAt + (act[k] << 3) + cell_at[k]);
             else entry[k] = lds_entry_at(lds, kMoveAt + (act[k] << 4) + cell_at[k]);
         }
@@ -332,7 +334,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         STAMP(1);   // previous step: probability chain, totals, trajectory stores
         if (COMPACT) {   // the code's thresholds: a second LDS read that depends on the first; the row completes to a MoveEntry
             uint32_t row_off[K], th[K];
-            if (BITMAP) {   // a STAY row: the cell itself, the all-equal code (one entry: candidates m = r = l)
+            if (BITMAP == 1) {   // a STAY row: the cell itself, the all-equal code (one entry: candidates m = r = l)
 #pragma unroll
                 for (int k = 0; k < K; ++k) {
                     const bool stay = act[k] == 0u;
@@ -405,7 +407,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
 
         // --- pair tests, then the per-env facts as ONE integer: f = vertex | swap << 1 | off_goal << 2
         PairAcc<true> acc;
-        if constexpr (BITMAP) acc = bitmap_pair_tests<Q, K>(x, lds, bitmap_at, c, n);
+        if constexpr (BITMAP != 0) acc = bitmap_pair_tests<Q, K>(x, lds, bitmap_at, c, n);
         else acc = packed_pair_tests<Q, P, false, true>(x, c, n);
         STAMP(4);   // pair tests
         uint32_t away = n[0] ^ g[0];
@@ -547,7 +549,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
 // bytes of one env's occupancy bitmap (BITMAP instances)
 static size_t bitmap_stride(uint32_t n_cells) { return (size_t((n_cells + 31u) / 32u) * 4u + 15u) & ~size_t(15); }   // one bit per cell
 
-template <int Q, int K, bool RECORD, bool STREAM, bool COMPACT = false, bool BITMAP = false>
+template <int Q, int K, bool RECORD, bool STREAM, bool COMPACT = false, int BITMAP = 0>
 hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size_t lds_bytes, hipStream_t stream) {
     // (criteria, may-be-terminal): the instance without terminal handling exists for Makespan only
     const bool term = !(args.auto_reset && !args.start_terminal_any);
@@ -562,7 +564,8 @@ hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size
     const unsigned grid = unsigned(args.n_envs / (block / unsigned(Q)));
     note_kernel("lq_rollout_kernel<Q=%d,K=%d,%s,%s,%s%s%s%s> block=%u (packed layout: %d agents per lane%s%s)", Q, K, RECORD ? "RECORD" : "TOTALS",
                 STREAM ? "STREAM" : "POLICY", args.c.criteria != 0u ? "SOC" : "MAKESPAN", COMPACT ? ",COMPACT" : "",
-                (args.c.criteria == 0u && !term) ? ",NO_TERMINAL" : "", BITMAP ? ",BITMAP" : "", block, K, COMPACT ? ", 8-byte table rows" : "",
+                (args.c.criteria == 0u && !term) ? ",NO_TERMINAL" : "", BITMAP == 2 ? ",BITMAP5" : (BITMAP ? ",BITMAP" : ""), block, K,
+                COMPACT ? (BITMAP == 1 ? ", 8-byte table rows without the STAY column" : ", 8-byte table rows") : "",
                 BITMAP ? ", collisions through per-env occupancy bitmaps" : "");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds_bytes, stream, args, A, bitmap_base);
     return hipGetLastError();
@@ -582,7 +585,7 @@ hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, int form, const Rollou
     constexpr int K = MAPF_LQ_K;
     constexpr bool R = MAPF_LQ_RECORD != 0;
     const bool stream_actions = args.actions != nullptr;
-    const bool compact = form != 0, bitmap = form == 2;   // form: 0 full table rows, 1 8-byte rows, 2 8-byte rows + occupancy bitmaps
+    const bool compact = form != 0, bitmap = form >= 2;   // form: 0 full table rows, 1 8-byte rows, 2 / 3 8-byte rows + occupancy bitmaps (four / five columns)
     (void)bitmap;
 #if MAPF_LQ_K == 8
     // eight agents per lane: 8, 16 and 32 agents (Q = 1, 2, 4); 8-byte table rows for the 32-agent maps only
@@ -604,8 +607,10 @@ hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, int form, const Rollou
 #if MAPF_LQ_K == 4
     if (bitmap) {    // 32 agents only (that is where the 496 pairs dominate)
         if (Q != 8) return hipErrorInvalidValue;
-        return stream_actions ? launch_impl<8, K, R, true, true, true>(args, A, block, lds_bytes, stream)
-                              : launch_impl<8, K, R, false, true, true>(args, A, block, lds_bytes, stream);
+        if (form == 3) return stream_actions ? launch_impl<8, K, R, true, true, 2>(args, A, block, lds_bytes, stream)
+                                             : launch_impl<8, K, R, false, true, 2>(args, A, block, lds_bytes, stream);
+        return stream_actions ? launch_impl<8, K, R, true, true, 1>(args, A, block, lds_bytes, stream)
+                              : launch_impl<8, K, R, false, true, 1>(args, A, block, lds_bytes, stream);
     }
     if (compact) {   // instantiated for the group sizes whose maps need it: 16, 32 and 64 agents
         switch (Q) {
@@ -668,7 +673,7 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
     const uint32_t A = uint32_t(n_agents);
     unsigned block = 0;
     int Q = 0, K = 0;
-    bool compact = false, bitmap = false;
+    bool compact = false, bitmap = false, stay_column = false;
     size_t lds_bytes = kMoveAt + size_t(args.c.n_cells) * kMoveCols * sizeof(MoveEntry);   // the kernel's whole LDS image
     if (lds_bytes <= tune.mv_lds_max_bytes && lds_bytes <= kLdsBytes - kLdsReserve) {
         // Four agents per lane halve the waves: that form needs tune.quad_min_lanes lanes (default: enough to put one
@@ -703,7 +708,10 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
             block = bitmap_block;
             K = 4;
             bitmap = true;
-            lds_bytes = bitmap_lds;
+            // where the five-column table (STAY included: four selects per agent-step less) still leaves room for the block's
+            // bitmaps -- 64 of them on the 64x64 maps, not 128 -- it is the one staged (C5's share: profiles/r04_c5_forms_ab.txt)
+            stay_column = tune.bitmap_stay_column && lds_bytes + (bitmap_block / 8u) * per_env <= kLdsBytes;
+            if (!stay_column) lds_bytes = bitmap_lds;
         } else if ((tune.force_k == 0 || tune.force_k == 8) && n_agents == 32 && layout_fits(n_agents, 8, args, lds_bytes, &block, &Q) &&
                    args.n_envs % (512u / 4u) == 0 && (tune.force_k == 8 || args.n_envs * 4u >= tune.oct_min_lanes)) {
             block = 512u;
@@ -721,7 +729,7 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
         *err = hipErrorInvalidValue;
         return true;
     }
-    const int form = bitmap ? 2 : (compact ? 1 : 0);
+    const int form = bitmap ? (stay_column ? 3 : 2) : (compact ? 1 : 0);
     if (K == 8) *err = record ? launch_rollout_lq_k8_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k8_r0(Q, form, args, A, block, lds_bytes, stream);
     else if (K == 4) *err = record ? launch_rollout_lq_k4_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k4_r0(Q, form, args, A, block, lds_bytes, stream);
     else *err = record ? launch_rollout_lq_k2_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k2_r0(Q, form, args, A, block, lds_bytes, stream);

@@ -420,9 +420,12 @@ def _goal_scenario_tables(n_agents, n_envs, seed):
     (16, 4096, 'lq_rollout_kernel<Q=4,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
     (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_PAIRS': '0'}),
     # (32 agents, 8-byte rows: collisions through per-env LDS occupancy bitmaps instead of the 496 agent pairs -- the default)
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
+    # (five-column table where it leaves room for the bitmaps -- here it does -- else four columns and a made-up STAY row)
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP5> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_STAYCOL': '0'}),
     # (... in 1024-thread blocks, 128 bitmaps behind the table: what a batch that fills every CU with such a block gets)
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024', 'MAPF_BITMAP_STAYCOL': '0'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP5> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024'}),
     (64, 16384, 'lq_rollout_kernel<Q=16,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
     (8, 300, 'lg_rollout_kernel<L=4,FULL,MV_GLOBAL', {}), (5, 600, 'lg_rollout_kernel<L=4,RAGGED', {}),
     (8, 16417, 'lg_rollout_kernel<L=4,FULL,MV_LDS', {}), (6, 512, 'rollout_kernel<A=6>', {})])
