@@ -145,6 +145,13 @@ __device__ __forceinline__ void slip_move(const SlipRow *lds_slip, const MoveEnt
     q = row.q[idx];
 }
 
+// The list slot alone (exact, 53-bit mantissa), for callers that fetch the slot's cell and probability themselves
+__device__ __forceinline__ uint32_t slip_slot_exact(const SlipRow *lds_slip, const MoveEntry &entry, uint64_t mant) {
+    const SlipRow &row = lds_slip[entry_code(entry)];
+    const bool b0 = mant < row.thr[0], b1 = mant < row.thr[1], b2 = mant < row.thr[2];
+    return b0 ? 0u : (b1 ? 1u : (b2 ? 2u : 0u));
+}
+
 // Fast path of the same sampling with only the top 16 bits of the uniform (hi = mant >> 37): hi < th[k] decides
 // mant < thr[k] unless hi == th[k]; `tie_dist` is 0 in that (rare) case and the caller repeats the move
 // with the full 53-bit mantissa.

@@ -53,6 +53,13 @@ constexpr uint32_t kSlipAt = 0, kOutcomeAt = sizeof(SlipRow) * 8, kMoveAt = kLds
 constexpr uint32_t kCompactCols = 5, kCompactEntry = 8;   // COMPACT: cells + code only, no sixth column
 constexpr uint32_t kBitmapCols = 4;                       // COMPACT + BITMAP == 1: no STAY column either
 static_assert(kOutcomeAt + sizeof(OutcomeRow) * 16 <= kMoveAt, "LDS image: slip rows, outcome rows, then the move table");
+// The LDS copy of a table row carries its slip row's byte offset PLUS kRowBias, so that sample_slot_packed's probability
+// address -- that operand minus 8 per threshold not passed -- is never negative and packs into an unsigned field (the
+// systolic probability chain below files four of them per word); the immediates of the LDS reads absorb the bias.
+constexpr uint32_t kRowBias = 16;
+// index (in doubles from kSlipAt) of a +0.0: the all-equal code's list has ONE entry, so thr[1] of its row is the integer 0
+constexpr uint32_t kZeroFactor = (7u * uint32_t(sizeof(SlipRow)) + uint32_t(offsetof(SlipRow, thr)) + 8u) / 8u;
+static_assert(offsetof(SlipRow, thr) % 8 == 0 && kZeroFactor < 128u, "a zero factor the packed probability indices can name");
 
 // TERM = an env may be terminal when a step begins.  With auto-reset on and no env whose START state is itself
 // terminal (the handle knows: mapf_create looks) that cannot happen after the launch's first step -- a done env is back
@@ -111,8 +118,8 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
                 const uint32_t w = w0 + k * blockDim.x;
                 if (w < n_words) {
                     // COMPACT rows: {c0 | c1 << 16, c2 | byte offset of the code's slip row << 16}
-                    if (COMPACT) reinterpret_cast<u32x2 *>(lds_mv)[w] = u32x2{part[k].x, (part[k].y & 0xFFFFu) | (part[k].w << 16)};
-                    else lds_mv[w] = make_uint4(part[k].x, part[k].y, part[k].z ^ kHalfBias, part[k].w);   // thresholds: see sample_slot_packed
+                    if (COMPACT) reinterpret_cast<u32x2 *>(lds_mv)[w] = u32x2{part[k].x, (part[k].y & 0xFFFFu) | ((part[k].w + kRowBias) << 16)};
+                    else lds_mv[w] = make_uint4(part[k].x, part[k].y, part[k].z ^ kHalfBias, part[k].w + kRowBias);   // thresholds: see sample_slot_packed
                 }
             }
         }
@@ -135,14 +142,26 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     const uint32_t reset_above = p.auto_reset ? 0u : 0xFFFFFFFFu;
 
     const bool leader = x.g == 0u, tail = x.g == uint32_t(Q - 1);
-    gf64 ret_p = (gf64)(p.out_returns ? at(p.out_returns, e) : nullptr);
-    gu32 epi_p = (gu32)(p.out_episodes ? at(p.out_episodes, e) : nullptr);
-    gu32 col_p = (gu32)(p.out_collisions ? at(p.out_collisions, e) : nullptr);
-    asm volatile("" : "+v"(ret_p), "+v"(epi_p), "+v"(col_p));
-    double ret = (p.accumulate && ret_p && leader) ? *ret_p : 0.0;
-    uint32_t episodes = (p.accumulate && epi_p && leader) ? *epi_p : 0u;
-    uint32_t collisions = (p.accumulate && col_p && leader) ? *col_p : 0u;
-    const uint64_t env_id = p.env_id_offset + e;
+    // the totals' addresses: held in vector registers across the step loop (formed again at the end they keep their argument
+    // fields alive in scalar registers, which the eight-agents-per-lane instances do not have), except with four agents per
+    // lane, whose 1024-thread forms have 128 vector registers per lane and none to spare: those form them again where they
+    // store.  The running counts are added to what the arrays hold at the end.
+    constexpr bool HOLD_TOTALS = K != 4;
+    auto totals_at = [&](gf64 &ret_p, gu32 &epi_p, gu32 &col_p) __attribute__((always_inline)) {
+        ret_p = (gf64)(p.out_returns ? at(p.out_returns, e) : nullptr);
+        epi_p = (gu32)(p.out_episodes ? at(p.out_episodes, e) : nullptr);
+        col_p = (gu32)(p.out_collisions ? at(p.out_collisions, e) : nullptr);
+    };
+    gf64 ret_p = nullptr;
+    gu32 epi_p = nullptr, col_p = nullptr;
+    if (HOLD_TOTALS) {
+        totals_at(ret_p, epi_p, col_p);
+        asm volatile("" : "+v"(ret_p), "+v"(epi_p), "+v"(col_p));
+    }
+    double ret = 0.0;
+    if (p.accumulate && p.out_returns && leader) ret = *(gf64)at(p.out_returns, e);
+    // (formed where it is used -- the slip refresh, one step in four, and the tie path: not held across the loop)
+#define env_id (p.env_id_offset + x.e)
     const uint64_t t_first = first_step_index(p);
     const uint32_t n_envs = uint32_t(p.n_envs);
 
@@ -203,6 +222,23 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     double pq[K], p_reward = -0.0;
 #pragma unroll
     for (int i = 0; i < K; ++i) pq[i] = 0.0;
+    // SYS: the ordered probability product as a systolic chain.  With Q lanes per env the product of a step is Q - 1
+    // hand-overs of K multiplies each, and the lock-step form (packed_prob_product) has EVERY lane execute all of them --
+    // 45 of the ~200 vector instructions of a 32-agent lane-step.  Here every lane does ONE round per step: lane g continues,
+    // with its factors of step u - g, the product lane g - 1 handed over a step ago; the last lane completes step u - (Q-1)
+    // and stores it Q - 1 rows behind the other trajectory arrays (a launch ends with Q - 1 draining rounds).  A lane keeps
+    // its factors of the last Q steps as packed LDS indices (four 7-bit fields per word: the probabilities live in the slip
+    // rows) and reads the delayed ones when their turn comes.  Same multiplications in the same order: bit-identical.
+    // (Q = 16: a ring of 16 words does not fit the 128 registers of a 1024-thread block; nor do 8 beside the greedy policy's goal
+    // coordinates and the SoC bookkeeping -- tests/test_cabi_and_host.py keeps every instance free of spills)
+    constexpr bool SYS = RECORD && K == 4 && Q == 8 && !(SOC && !STREAM);
+    constexpr int kRing = SYS ? Q : 1;
+    uint32_t qring[kRing], p_qword = 0u;   // qring[j]: my factors' indices of the step j before the pending one
+#pragma unroll
+    for (int j = 0; j < kRing; ++j) qring[j] = 0u;
+    double chain_run = 1.0;                // what I handed on in the last round
+    uint32_t eight = 8u;
+    asm volatile("" : "+v"(eight));
     uint32_t p_cells[P], p_status = 0u, counts = 0u;   // p_status: done | collision << 16 of the pending step; counts: their sums
 #pragma unroll
     for (int i = 0; i < P; ++i) p_cells[i] = 0u;
@@ -212,18 +248,57 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     StampCtx &st = st_;
     { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); st.last = _t; }
 #endif
-    auto finish_pending = [&]() __attribute__((always_inline)) {
+    // SYS, at the top of a step: file the pending step's indices, pick the word whose turn it is in this lane (the one
+    // filed g steps ago: a select tree over the bits of g, masks hoisted) and request its four probabilities
+    auto chain_fetch = [&](double (&qv)[K]) __attribute__((always_inline)) {
+        if constexpr (SYS) {
+            asm volatile("" : "+v"(p_qword));
+#pragma unroll
+            for (int j = kRing - 1; j > 0; --j) qring[j] = qring[j - 1];
+            qring[0] = p_qword;
+            uint32_t level[kRing];
+#pragma unroll
+            for (int j = 0; j < kRing; ++j) level[j] = qring[j];
+#pragma unroll
+            for (int width = kRing, bit = 1; width > 1; width /= 2, bit *= 2) {
+                const bool upper = (x.g & uint32_t(bit)) != 0u;
+#pragma unroll
+                for (int j = 0; j < width / 2; ++j) level[j] = upper ? level[2 * j + 1] : level[2 * j];
+            }
+            const uint32_t mine = level[0];
+            uint32_t at[K];
+            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(at[0]) : "v"(mine), "v"(eight));
+            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(at[1]) : "v"(mine), "v"(eight));
+            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(at[2]) : "v"(mine), "v"(eight));
+            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(at[3]) : "v"(mine), "v"(eight));
+#pragma unroll
+            for (int k = 0; k < K; ++k) qv[k] = lds_at<double>(lds, kSlipAt + at[k]);
+        }
+    };
+    // SYS: one round -- continue what the lane before me handed over (the group's first lane starts a product: 1.0 * q is q)
+    auto chain_round = [&](const double (&qv)[K]) __attribute__((always_inline)) {
+        const uint32_t lo = from_prev_lane<Q>(uint32_t(__double2loint(chain_run)));
+        const uint32_t hi = from_prev_lane<Q>(uint32_t(__double2hiint(chain_run)));
+        double run = __hiloint2double(int(x.g == 0u ? 0x3FF00000u : hi), int(x.g == 0u ? 0u : lo));
+#pragma unroll
+        for (int k = 0; k < K; ++k) run = __dmul_rn(run, qv[k]);
+        chain_run = run;
+        return run;                                            // in the last lane: the product of the step Q - 1 before the pending one
+    };
+    auto finish_pending = [&](const double (&qv)[K]) __attribute__((always_inline)) {
         // opaque from here on: otherwise the optimiser moves these consumers back to where the values are produced
         // (the end of the previous step), which is exactly the stall this pipeline removes
         asm volatile("" : "+v"(p_reward), "+v"(p_status));
-        if (RECORD) {
+        if (RECORD && !SYS) {
 #pragma unroll
             for (int i = 0; i < K; ++i) asm volatile("" : "+v"(pq[i]));
         }
         ret = __dadd_rn(ret, p_reward);
         counts += p_status;                                    // two 16-bit counts (a launch has at most 65535 steps)
         if (RECORD) {
-            const double prob = packed_prob_product<Q, K>(pq);   // total in the last lane
+            double prob;
+            if constexpr (SYS) prob = chain_round(qv);
+            else prob = packed_prob_product<Q, K>(pq);           // total in the last lane
             Packed<P> out;
 #pragma unroll
             for (int i = 0; i < P; ++i) out.v[i] = p_cells[i];
@@ -258,6 +333,10 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         constexpr bool FIRST = decltype(first_tag)::value, TAIL = decltype(tail_tag)::value;
         constexpr bool MAYBE_TERMINAL = TERM || FIRST;   // (the launch's first step finds whatever state the last launch left)
         const uint64_t t = t_first + s;
+        double qv[K];                                              // SYS: the factors of this step's chain round
+#ifdef MAPF_EXP_EARLY_FETCH   // (experiment builds only: measured equal -- 531-537 G against 531-532 G on C5's share -- and 8 registers dearer)
+        if (SYS && !FIRST) chain_fetch(qv);
+#endif
         uint32_t cur[K], act[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) cur[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu;
@@ -319,14 +398,20 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         STAMP(0);   // loop top: action fetch / policy, table read issue
         // --- ... then the previous step is finished while they are in flight
         if (!FIRST) {
-            finish_pending();
+#ifndef MAPF_EXP_EARLY_FETCH
+            if (SYS) chain_fetch(qv);                              // behind the table reads: its factors arrive with the rows
+#endif
+            finish_pending(qv);
 #ifdef MAPF_EXP_NO_ADVANCE   // (experiment builds only: every step overwrites row 0, i.e. no HBM write stream)
             if (false) {
 #else
             if (RECORD) {
 #endif
                 rec_lane += step_cells;
-                wide_lane += step_rows;
+                // SYS: the last lane's probability rows trail by Q - 1 steps -- its pointer rests on row 0 (which the early,
+                // incomplete products overwrite until the right one arrives) while s < Q; the unrolled loop only runs beyond that
+                if (SYS && TAIL) wide_lane += (tail && s < uint32_t(Q)) ? 0u : step_rows;
+                else wide_lane += step_rows;
                 narrow_lane += step_rows;
                 if (Q == 1) { prob_lane += step_rows; coll_lane += step_rows; }
             }
@@ -339,13 +424,13 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
                 for (int k = 0; k < K; ++k) {
                     const bool stay = act[k] == 0u;
                     cells_code[k].x = stay ? cur[k] : cells_code[k].x;
-                    cells_code[k].y = stay ? (7u * uint32_t(sizeof(SlipRow))) << 16 : cells_code[k].y;
+                    cells_code[k].y = stay ? (7u * uint32_t(sizeof(SlipRow)) + kRowBias) << 16 : cells_code[k].y;
                 }
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 row_off[k] = cells_code[k].y >> 16;
-                th[k] = lds_at<uint32_t>(lds, kSlipAt + uint32_t(offsetof(SlipRow, th_biased)) + row_off[k]);   // (th[0] | th[1] << 16) ^ bias
+                th[k] = lds_at<uint32_t>(lds, kSlipAt + uint32_t(offsetof(SlipRow, th_biased)) - kRowBias + row_off[k]);   // (th[0] | th[1] << 16) ^ bias
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) entry[k] = make_uint4(cells_code[k].x, cells_code[k].y, th[k], row_off[k]);
@@ -372,18 +457,20 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         }
         STAMP(2);   // slip Philox (1 step in 4)
         double q[K];
-        uint32_t n[P], word[P], d[K], tie_all = 0u;
+        uint32_t n[P], word[P], d[K], q_at[K], tie_all = 0u;   // q_at: byte offset of the sampled slot's probability from kSlipAt
 #pragma unroll
         for (int i = 0; i < P; ++i) {
             word[i] = W == 0 ? rng[i].w0 : W == 1 ? rng[i].w1 : W == 2 ? rng[i].w2 : W == 3 ? rng[i].w3 : step_word(rng[i], t);
             const uint32_t biased = word[i] ^ kHalfBias;             // low half: agent 2i's uniform, high half: agent 2i+1's
-            uint32_t q_at[2], cell[2];
+            uint32_t cell[2];
             d[2 * i] = sample_slot_packed(entry[2 * i], __builtin_amdgcn_perm(biased, biased, 0x01000100u), pk_eights, pk_steps,
-                                          sel_base, q_at[0], cell[0]);
+                                          sel_base, q_at[2 * i], cell[0]);
             d[2 * i + 1] = sample_slot_packed(entry[2 * i + 1], __builtin_amdgcn_perm(biased, biased, 0x03020302u), pk_eights, pk_steps,
-                                              sel_base, q_at[1], cell[1]);
-            q[2 * i] = lds_at<double>(lds, kSlipAt + 16u + q_at[0]);
-            q[2 * i + 1] = lds_at<double>(lds, kSlipAt + 16u + q_at[1]);
+                                              sel_base, q_at[2 * i + 1], cell[1]);
+            if (!SYS) {   // (SYS reads the probabilities when their chain round comes)
+                q[2 * i] = lds_at<double>(lds, kSlipAt + 16u - kRowBias + q_at[2 * i]);
+                q[2 * i + 1] = lds_at<double>(lds, kSlipAt + 16u - kRowBias + q_at[2 * i + 1]);
+            }
             n[i] = cell[0] | (cell[1] << 16);
             tie_all = i == 0 ? pk_min_u16(d[0], d[1]) : pk_min_u16(tie_all, pk_min_u16(d[2 * i], d[2 * i + 1]));
         }
@@ -395,10 +482,17 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
             for (int k = 0; k < K; ++k) {
                 if (__any(zero_half(d[k]) != 0u)) {
                     MoveEntry full = entry[k];
-                    if (COMPACT) full.y = (full.y & 0xFFFFu) | ((full.w / uint32_t(sizeof(SlipRow))) << 16);   // the code, where entry_code() looks
+                    if (COMPACT) full.y = (full.y & 0xFFFFu) | (((full.w - kRowBias) / uint32_t(sizeof(SlipRow))) << 16);   // the code, where entry_code() looks
                     const uint32_t hi = (k & 1) ? word[k / 2] >> 16 : word[k / 2] & 0xFFFFu;
                     uint32_t nx;
-                    slip_move<false>(slip, full, refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi), 0.0, nx, q[k]);
+                    const uint64_t mant = refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi);
+                    if (SYS) {
+                        const uint32_t slot = slip_slot_exact(slip, full, mant);
+                        nx = entry_cell(full, slot);
+                        q_at[k] = entry_row_offset(entry[k]) - 16u + 8u * slot;   // what sample_slot_packed makes of that slot
+                    } else {
+                        slip_move<false>(slip, full, mant, 0.0, nx, q[k]);
+                    }
                     n[k / 2] = (k & 1) ? (n[k / 2] & 0xFFFFu) | (nx << 16) : (n[k / 2] & 0xFFFF0000u) | nx;
                 }
             }
@@ -463,7 +557,12 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         p_status = row_status;
 #pragma unroll
         for (int i = 0; i < P; ++i) p_cells[i] = n[i];
-        if (RECORD) {                                          // a zero factor makes the whole product +0.0
+        if (RECORD && SYS) {                                   // the factors' indices: (offset from kSlipAt) / 8, seven bits each
+            static_assert(!SYS || K == 4, "four fields per word");
+            uint32_t w = (q_at[0] >> 3) | (q_at[1] << 5) | (q_at[2 % K] << 13) | (q_at[3 % K] << 21);
+            if (MAYBE_TERMINAL) w = was_terminal ? (w & ~0x7Fu) | kZeroFactor : w;
+            p_qword = w;
+        } else if (RECORD) {                                   // a zero factor makes the whole product +0.0
             pq[0] = was_terminal ? 0.0 : q[0];
 #pragma unroll
             for (int k = 1; k < K; ++k) pq[k] = q[k];
@@ -512,7 +611,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         shift_raw();
         s = 1;
     }
-    for (; s < p.n_steps && ((t_first + s) & 3u) != 0u; ++s) single_step(s);
+    for (; s < p.n_steps && (((t_first + s) & 3u) != 0u || (SYS && s < uint32_t(Q))); ++s) single_step(s);
     for (; s + 2u * kAhead <= p.n_steps; s += kAhead) {        // the group's last step prefetches row s + 2 kAhead - 1
         one_step(s, raw[0], W0{}, No{}, No{});
         one_step(s + 1u, raw[1], W1{}, No{}, No{});
@@ -526,10 +625,25 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         }
     }
     for (; s < p.n_steps; ++s) single_step(s);
-    if (p.n_steps > 0) finish_pending();                       // the last step's chain, totals and stores
+    if (p.n_steps > 0) {                                       // the last step's chain, totals and stores
+        double qv[K];
+        if (SYS) chain_fetch(qv);
+        finish_pending(qv);
+        if constexpr (SYS) {
+            // ... and the Q - 1 rounds that complete the products still on their way through the group (the other lanes
+            // re-store the last reward in place)
+            for (uint32_t u = p.n_steps; u < p.n_steps + uint32_t(Q - 1); ++u) {
+                wide_lane += (tail && u >= uint32_t(Q)) ? step_rows : 0u;
+                p_qword = 0u;
+                chain_fetch(qv);
+                const double prob = chain_round(qv);
+                *wide_lane = tail ? prob : p_reward;
+            }
+        }
+    }
 #ifdef MAPF_STAMPS
-    if (x.lane == 0u && epi_p) {   // diagnostic build: segment sums replace the episode counts
-        for (int k = 0; k < 8; ++k) epi_p[k] = uint32_t(st.seg[k]);
+    if (x.lane == 0u && p.out_episodes) {   // diagnostic build: segment sums replace the episode counts
+        for (int k = 0; k < 8; ++k) at(p.out_episodes, e)[k] = uint32_t(st.seg[k]);
         return;
     }
 #endif
@@ -540,11 +654,14 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         fin.store(at(p.state, lane_cell));
     }
     if (leader) {
+        if (!HOLD_TOTALS) totals_at(ret_p, epi_p, col_p);
         if (ret_p) *ret_p = ret;
-        if (epi_p) *epi_p = episodes + (counts & 0xFFFFu);
-        if (col_p) *col_p = collisions + (counts >> 16);
+        if (epi_p) *epi_p = (p.accumulate ? *epi_p : 0u) + (counts & 0xFFFFu);
+        if (col_p) *col_p = (p.accumulate ? *col_p : 0u) + (counts >> 16);
     }
 }
+
+#undef env_id
 
 // bytes of one env's occupancy bitmap (BITMAP instances)
 static size_t bitmap_stride(uint32_t n_cells) { return (size_t((n_cells + 31u) / 32u) * 4u + 15u) & ~size_t(15); }   // one bit per cell

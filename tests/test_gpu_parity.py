@@ -486,6 +486,37 @@ def test_goal_reaching_episodes_against_c_oracle(n_agents, n_envs, layout, env_v
         env.close()
 
 
+@pytest.mark.parametrize('env_vars,want', [
+    ({'MAPF_MV_LDS_MAX_BYTES': '2048'}, 'COMPACT,NO_TERMINAL,BITMAP5> block=512'),
+    ({'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024', 'MAPF_BITMAP_STAYCOL': '0'}, 'COMPACT,NO_TERMINAL,BITMAP> block=1024'),
+    ({'MAPF_LQ_K': '4'}, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL> block=')])
+def test_systolic_probability_chain_over_short_and_split_launches(env_vars, want, monkeypatch):
+    """32 agents in eight lanes: the ordered probability product is a systolic chain -- one hand-over per step, the last lane
+    completing a step's product seven steps later and every launch ending with seven draining rounds.  Launches SHORTER than
+    the chain (1, 2, 7 steps), of its length, and longer ones, issued back to back: every recorded probability (and
+    everything else) against the C oracle, slip 0.2 and 0 (all factors 1.0), episodes ending and restarting in between."""
+    for k, v in env_vars.items():
+        monkeypatch.setenv(k, v)
+    A, E = 32, 2048
+    grid, nbr, rc, start, goal = _goal_scenario_tables(A, E, 8100 + A)
+    for fail_prob in (0.2, 0.0):
+        env = VecMapfEnv(grid, A, None, None, fail_prob, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=77, env_id_offset=9,
+                         start_local=start, goal_local=goal)
+        co = c_oracle.COracle(nbr, A, start, goal, fail_prob, -1000.0, 100.0, -1.0, mo.MAKESPAN, seed=77, env_id_offset=9)
+        rs = np.random.RandomState(5)
+        for T in (1, 2, 7, 8, 9, 1, 13, 3, 16):
+            acts = rs.randint(0, 5, size=(T, E, A)).astype(np.uint8)
+            res = env.rollout(T, actions=acts, auto_reset=True, record=True)
+            assert want in env.last_kernel('rollout'), env.last_kernel('rollout')
+            for t in range(T):
+                ref = co.step(acts[t], auto_reset=True)
+                assert np.array_equal(_bits(res['prob'][t]), _bits(ref['prob'])), (fail_prob, T, t)
+                assert np.array_equal(res['local'][t], ref['local']) and np.array_equal(_bits(res['reward'][t]), _bits(ref['reward']))
+                assert np.array_equal(res['done'][t], ref['done']) and np.array_equal(res['collision'][t], ref['collision'])
+        assert np.array_equal(env.get_state()[0], co.state)
+        env.close()
+
+
 # ----------------------------------------------------------------------- BASELINE.json full sizes
 def _full_size_check(grid, nbr, A, start, goal, fail_prob, crit, ocrit, n_step, n_roll, kernel='auto', env_id_offset=0,
                      want_step=None, want_rollout=None, n_streamed=0):

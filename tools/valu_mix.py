@@ -64,10 +64,11 @@ def main():
     import bench
     # (rocprofv3's spelling of the instance, -D flags of its translation unit, mangled template arguments)
     instances = [
-        ('lq_rollout_kernel<2, 4, true, true, false, false, false, false>', ['-DMAPF_LQ_K=4', '-DMAPF_LQ_RECORD=1'], 'ILi2ELi4ELb1ELb1ELb0ELb0ELb0ELb0E'),
-        ('lq_rollout_kernel<8, 4, true, true, false, true, false, true>', ['-DMAPF_LQ_K=4', '-DMAPF_LQ_RECORD=1'], 'ILi8ELi4ELb1ELb1ELb0ELb1ELb0ELb1E'),
-        ('lq_rollout_kernel<4, 8, true, true, false, true, false, false>', ['-DMAPF_LQ_K=8', '-DMAPF_LQ_RECORD=1'], 'ILi4ELi8ELb1ELb1ELb0ELb1ELb0ELb0E'),
-        ('lq_rollout_kernel<1, 8, true, true, false, false, false, false>', ['-DMAPF_LQ_K=8', '-DMAPF_LQ_RECORD=1'], 'ILi1ELi8ELb1ELb1ELb0ELb0ELb0ELb0E'),
+        ('lq_rollout_kernel<2, 4, true, true, false, false, false, 0>', ['-DMAPF_LQ_K=4', '-DMAPF_LQ_RECORD=1'], 'ILi2ELi4ELb1ELb1ELb0ELb0ELb0ELi0E'),
+        ('lq_rollout_kernel<8, 4, true, true, false, true, false, 2>', ['-DMAPF_LQ_K=4', '-DMAPF_LQ_RECORD=1'], 'ILi8ELi4ELb1ELb1ELb0ELb1ELb0ELi2E'),
+        ('lq_rollout_kernel<8, 4, true, true, false, true, false, 1>', ['-DMAPF_LQ_K=4', '-DMAPF_LQ_RECORD=1'], 'ILi8ELi4ELb1ELb1ELb0ELb1ELb0ELi1E'),
+        ('lq_rollout_kernel<4, 8, true, true, false, true, false, 0>', ['-DMAPF_LQ_K=8', '-DMAPF_LQ_RECORD=1'], 'ILi4ELi8ELb1ELb1ELb0ELb1ELb0ELi0E'),
+        ('lq_rollout_kernel<1, 8, true, true, false, false, false, 0>', ['-DMAPF_LQ_K=8', '-DMAPF_LQ_RECORD=1'], 'ILi1ELi8ELb1ELb1ELb0ELb0ELb0ELi0E'),
     ]
     doc = {'_how': ' '.join(__doc__.split('\n\n')[0].split()), 'csrc_hash': bench.csrc_hash(), 'instances': {}}
     for name, flags, mangled in instances:
