@@ -31,6 +31,13 @@
 // 8 bytes of each 16-byte row (the three cells and the equality code; five columns), one block per CU owns up to 158 KB
 // of it, and the code's thresholds come from a second, dependent LDS read of the code's slip row.
 //
+// 32 agents on such maps (BASELINE configs[4]): four agents per lane, eight lanes per env, and two things that are O(A)
+// instead of what the other instances do -- the vertex / swap facts through a per-env ONE-BIT occupancy bitmap in LDS behind
+// the table (BITMAP, bitmap_pair_tests in mapf_lq.hpp: three LDS operations per agent instead of 496 agent pairs per env;
+// 128 bitmaps behind a four-column table in 1024-thread blocks, 64 behind the five-column one in 512-thread blocks), and the
+// ordered probability product as a systolic chain over the steps (SYS below: one hand-over per step and lane instead of
+// seven).  DESIGN.md section 4.1 has the measurements of each step.
+//
 // Scope: the fused rollout of FULL groups only (A = K * Q, Q a power of two <= 16), every block full, move table in
 // LDS -- the bench configurations and their neighbours.  Everything else (odd agent counts, ragged batches, tables
 // beyond the LDS budget, single steps) stays with mapf_lg_rollout.hip; launch_rollout_lg() picks.  Same stream,
