@@ -50,7 +50,7 @@ def test_valu_share_is_priced_by_kind_and_never_exceeds_one(tmp_path, monkeypatc
     assert dv.price((1000, 0, 0, 0), 0.0, cost) / dv.price((1000, 0, 0, 0), 1.0, cost) == pytest.approx(cost['ordinary'] / cost['fast'])
     assert dv.price((0, 10, 10, 10), 0.5, cost) == pytest.approx(10 * (cost['int64'] + cost['mul_f64'] + cost['add_f64']))
     # a synthetic pass whose counters cannot fit its launch time is refused (round 3's file held a "share" of 4.5)
-    kernel = 'void mapf::(anonymous namespace)::lq_rollout_kernel<2, 4, true, true, false, false, false, false>(mapf::RolloutArgs, unsigned int, unsigned int)'
+    kernel = 'void mapf::(anonymous namespace)::lq_rollout_kernel<2, 4, true, true, false, false, false, 0>(mapf::RolloutArgs, unsigned int, unsigned int)'
 
     def write(path, counters, fields=('Kernel_Name', 'Counter_Name', 'Counter_Value')):
         with open(path, 'w', newline='') as f:
