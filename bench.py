@@ -39,6 +39,8 @@ time of that region.  Rank 0 prints ONE JSON line.  Keys beyond the contract:
                 step index lives in device memory, so every replay draws fresh numbers) and replayed; the next
                 observation is read from the handle's state view (cells written once); `plain_launches` = the same
                 calls issued one by one from the host (host-enqueue bound)
+  per_gpu_shapes   the one-GPU shares of configs[3] (32768 envs x 8 agents) and configs[4] (16384 envs x 32 agents): the same
+                fused launch, HIP-event time of 3 x 10 launches each (default configuration only)
   scalar_env    the reference's own regime (configs[0]: empty-8-8, 2 agents, slip 0, ONE env): MapfEnv.step()
                 calls per second through the drop-in class, beside the reference's build-container figure
   cpu_baseline  the pure-Python restatement of the reference (oracle/, kind "port") timed on this box's host
@@ -320,6 +322,63 @@ def spawn_ranks(n, deadline_s, command=None):
             raise SystemExit(124)
         time.sleep(0.05)
     raise SystemExit(rc)
+
+
+def per_gpu_shape_rate(name, n_envs, T=256, n_launch=10, blocks=3, preroll_ms=60.0):
+    """The fused rollout on what ONE GPU runs of a BASELINE configuration that is sharded over eight (configs[3]: 32768 envs
+    of 8 agents, configs[4]: 16384 envs of 32 agents) -- the same launch as the headline leg (T env-steps per launch, every
+    env-step's outputs recorded to HBM, actions streamed from a two-slot ring), HIP events around `n_launch` launches on the
+    handle's stream, median of `blocks` blocks.  A side leg of the default run (world size 1): the per-GPU rates of those
+    configurations next to the headline in ONE driver-run line; their parity is the GPU test suite's
+    (test_config4_share_* / test_config5_*)."""
+    import ctypes
+    import torch
+    from gym_mapf_amd import _native as nat
+    from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv
+    cfg = CONFIGS[name]
+    A, E = cfg['agents'], n_envs
+    grid, _, nbr, start, goal = workload_tables(cfg, E, 0)
+    env = VecMapfEnv(grid, A, None, None, cfg['fail_prob'], R_CLASH, R_GOAL, R_LIVING, OptimizationCriteria.Makespan, seed=SEED,
+                     device=torch.cuda.current_device(), device_arrays=True, start_local=start, goal_local=goal)
+    actions = env.fill_random_actions(0, 2 * T)
+    rec = {'local': env._empty((T, E, A), np.uint16), 'reward': env._empty((T, E), np.float64), 'prob': env._empty((T, E), np.float64),
+           'done': env._empty((T, E), np.uint8), 'collision': env._empty((T, E), np.uint8)}
+    acc = {'returns': torch.zeros(E, dtype=torch.float64, device='cuda'),
+           'episodes': torch.zeros(E, dtype=torch.int32, device='cuda').view(torch.uint32),
+           'collisions': torch.zeros(E, dtype=torch.int32, device='cuda').view(torch.uint32)}
+    ios = [nat.MapfRolloutIO(struct_size=ctypes.sizeof(nat.MapfRolloutIO), n_steps=T, step_flags=nat.MAPF_STEP_AUTO_RESET, accumulate=1,
+                             actions=actions[slot * T].data_ptr(), out_returns=acc['returns'].data_ptr(),
+                             out_episodes=acc['episodes'].data_ptr(), out_collisions=acc['collisions'].data_ptr(),
+                             rec_local=rec['local'].data_ptr(), rec_reward=rec['reward'].data_ptr(), rec_done=rec['done'].data_ptr(),
+                             rec_collision=rec['collision'].data_ptr(), rec_prob=rec['prob'].data_ptr()) for slot in range(2)]
+    env.reset()
+    k = 0
+    t_end = time.perf_counter() + preroll_ms * 1e-3
+    while time.perf_counter() < t_end:
+        for _ in range(4):
+            nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(ios[k % 2])))
+            k += 1
+        env.sync()
+    ms = []
+    for _ in range(blocks):
+        env.sync()
+        env.timer_begin()
+        for _ in range(n_launch):
+            nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(ios[k % 2])))
+            k += 1
+        ms.append(env.timer_end() / n_launch)
+        env.sync()
+    launch_ms = sorted(ms)[(len(ms) - 1) // 2]
+    kernel = env.last_kernel('rollout')
+    env.close()
+    launch_bytes = float(T) * E * A * bytes_per_agent_step(A)
+    traffic = measured_traffic(kernel, E, A, T)
+    return {"workload": "%s's share of one GPU: %s map, %d agents, slip=%g, %d envs" % (cfg['baseline'], cfg['map'], A, cfg['fail_prob'], E),
+            "value": float(T) * E * A / (launch_ms * 1e-3), "unit": "agent-steps/s", "ms_per_launch_hip_events": launch_ms,
+            "launches": n_launch, "blocks": blocks, "kernel": kernel,
+            "roofline": {"bound": "hbm", "achieved": launch_bytes / (launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": launch_bytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_launch": launch_bytes}}
 
 
 def main():
@@ -634,6 +693,10 @@ def main():
             line["single_step_launches"] = single
         if world == 1 and not args.no_side_legs and not args.no_scalar_env:
             line["scalar_env"] = scalar_env_rate()
+        if world == 1 and not args.no_side_legs and args.config == 'c3' and args.envs is None:
+            # what each GPU runs of the two BASELINE configurations that are sharded over eight
+            line["per_gpu_shapes"] = {"c4_share": per_gpu_shape_rate('c4', CONFIGS['c4']['envs'] // 8),
+                                      "c5_share": per_gpu_shape_rate('c5', CONFIGS['c5']['envs'] // 8)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         sys.stdout.flush()
