@@ -255,8 +255,8 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     StampCtx &st = st_;
     { unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); st.last = _t; }
 #endif
-    // SYS, at the top of a step: file the pending step's indices, pick the word whose turn it is in this lane (the one
-    // filed g steps ago: a select tree over the bits of g, masks hoisted) and request its four probabilities
+    // SYS, once per step (behind the step's table reads): file the pending step's indices, pick the word whose turn it is in
+    // this lane (the one filed g steps ago: a select tree over the bits of g, masks hoisted) and request its four probabilities
     auto chain_fetch = [&](double (&qv)[K]) __attribute__((always_inline)) {
         if constexpr (SYS) {
             asm volatile("" : "+v"(p_qword));
@@ -833,7 +833,7 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
             K = 4;
             bitmap = true;
             // where the five-column table (STAY included: four selects per agent-step less) still leaves room for the block's
-            // bitmaps -- 64 of them on the 64x64 maps, not 128 -- it is the one staged (C5's share: profiles/r04_c5_forms_ab.txt)
+            // bitmaps -- 64 of them on the 64x64 maps, not 128 -- it is the one staged (C5's share: profiles/r04_c5_stay_column_ab.txt)
             stay_column = tune.bitmap_stay_column && lds_bytes + (bitmap_block / 8u) * per_env <= kLdsBytes;
             if (!stay_column) lds_bytes = bitmap_lds;
         } else if ((tune.force_k == 0 || tune.force_k == 8) && n_agents == 32 && layout_fits(n_agents, 8, args, lds_bytes, &block, &Q) &&
