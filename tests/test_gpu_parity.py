@@ -595,6 +595,36 @@ def test_large_map_maze128_32agents_16384_envs(monkeypatch, criteria):
 
 
 @pytest.mark.parametrize('criteria', ['Makespan', 'SoC'])
+def test_reference_room64_maps_32agents_under_default_dispatch(monkeypatch, criteria):
+    """32 agents on the reference's own 64x64 room maps (room-64-64-16: 3646 free cells, room-64-64-8: 3232; scenarios that
+    construct with 32 agents), 8192 envs over several scenarios each: the occupancy-bitmap / systolic-chain form of the packed
+    rollout under default dispatch -- the four-column table where five columns would not leave room for the bitmaps, the
+    five-column one where they do -- and the packed single step, every env of every step against the C oracle."""
+    monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    crit, ocrit = (OptimizationCriteria.SoC, mo.SOC) if criteria == 'SoC' else (OptimizationCriteria.Makespan, mo.MAKESPAN)
+    for map_name, want in (('room-64-64-16', ',BITMAP> block=512'), ('room-64-64-8', ',BITMAP5> block=512')):
+        scen_ids = []
+        for sid in range(1, 26):                                   # (a scenario whose first 32 agents do not construct is skipped)
+            try:
+                _scen_tables(map_name, [sid], 32, 1)
+                scen_ids.append(sid)
+            except Exception:
+                pass
+            if len(scen_ids) == 4:
+                break
+        assert len(scen_ids) >= 2, (map_name, scen_ids)
+        grid, nbr, start, goal = _scen_tables(map_name, scen_ids, 32, 8192)
+        n = _full_size_check(grid, nbr, 32, start, goal, 0.2, crit, ocrit, 3, 16, want_step='lq_step_kernel<Q=8,K=4',
+                             want_rollout='lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,%s,COMPACT' % ('SOC' if criteria == 'SoC' else 'MAKESPAN'),
+                             n_streamed=16)
+        assert n > 50, (map_name, n)
+        env = VecMapfEnv(grid, 32, None, None, 0.2, -1000.0, 100.0, -1.0, crit, seed=42, start_local=start, goal_local=goal)
+        env.rollout(4, auto_reset=True, record=True)
+        assert want in env.last_kernel('rollout'), (map_name, env.last_kernel('rollout'))
+        env.close()
+
+
+@pytest.mark.parametrize('criteria', ['Makespan', 'SoC'])
 def test_large_map_berlin256_4agents_65536_envs(monkeypatch, criteria):
     """Berlin_1_256 (47540 free cells, a 3.8 MB move table; the map mapf_grid_tests.py:22-32 opens), scen 11, 4 agents,
     65536 envs: packed single step <Q=1,K=4,SCEN> at V = 47540 and the lane-group rollout <L=2,FULL,MV_GLOBAL,...,DENSE>."""
