@@ -394,6 +394,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-side-legs', action='store_true', help='skip single_step_launches and scalar_env (profiling runs)')
     ap.add_argument('--no-scalar-env', action='store_true', help='skip the scalar_env leg (its ~100k one-env launches swamp a profile)')
+    ap.add_argument('--no-per-gpu-shapes', action='store_true',
+                    help='skip the per_gpu_shapes leg (profiling runs: it launches the headline kernel at another batch size)')
     ap.add_argument('--kernel', default='auto', choices=['auto', 'thread_per_env', 'lane_group'])
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' + --share-device rehearses the N > 1 path on a one-GPU box")
@@ -693,7 +695,7 @@ def main():
             line["single_step_launches"] = single
         if world == 1 and not args.no_side_legs and not args.no_scalar_env:
             line["scalar_env"] = scalar_env_rate()
-        if world == 1 and not args.no_side_legs and args.config == 'c3' and args.envs is None:
+        if world == 1 and not args.no_side_legs and not args.no_per_gpu_shapes and args.config == 'c3' and args.envs is None:
             # what each GPU runs of the two BASELINE configurations that are sharded over eight
             line["per_gpu_shapes"] = {"c4_share": per_gpu_shape_rate('c4', CONFIGS['c4']['envs'] // 8),
                                       "c5_share": per_gpu_shape_rate('c5', CONFIGS['c5']['envs'] // 8)}

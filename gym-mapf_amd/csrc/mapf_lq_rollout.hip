@@ -688,7 +688,7 @@ hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size
     const unsigned grid = unsigned(args.n_envs / (block / unsigned(Q)));
     note_kernel("lq_rollout_kernel<Q=%d,K=%d,%s,%s,%s%s%s%s> block=%u (packed layout: %d agents per lane%s%s)", Q, K, RECORD ? "RECORD" : "TOTALS",
                 STREAM ? "STREAM" : "POLICY", args.c.criteria != 0u ? "SOC" : "MAKESPAN", COMPACT ? ",COMPACT" : "",
-                (args.c.criteria == 0u && !term) ? ",NO_TERMINAL" : "", BITMAP == 2 ? ",BITMAP5" : (BITMAP ? ",BITMAP" : ""), block, K,
+                (args.c.criteria == 0u && !term) ? ",NO_TERMINAL" : "", (BITMAP == 2 && COMPACT) ? ",BITMAP5" : (BITMAP ? ",BITMAP" : ""), block, K,
                 COMPACT ? (BITMAP == 1 ? ", 8-byte table rows without the STAY column" : ", 8-byte table rows") : "",
                 BITMAP ? ", collisions through per-env occupancy bitmaps" : "");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds_bytes, stream, args, A, bitmap_base);
@@ -709,7 +709,8 @@ hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, int form, const Rollou
     constexpr int K = MAPF_LQ_K;
     constexpr bool R = MAPF_LQ_RECORD != 0;
     const bool stream_actions = args.actions != nullptr;
-    const bool compact = form != 0, bitmap = form >= 2;   // form: 0 full table rows, 1 8-byte rows, 2 / 3 8-byte rows + occupancy bitmaps (four / five columns)
+    // form: 0 full table rows, 1 8-byte rows, 2 / 3 8-byte rows + occupancy bitmaps (four / five columns), 4 full rows + bitmaps
+    const bool compact = form >= 1 && form <= 3, bitmap = form >= 2;
     (void)bitmap;
 #if MAPF_LQ_K == 8
     // eight agents per lane: 8, 16 and 32 agents (Q = 1, 2, 4); 8-byte table rows for the 32-agent maps only
@@ -731,6 +732,8 @@ hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, int form, const Rollou
 #if MAPF_LQ_K == 4
     if (bitmap) {    // 32 agents only (that is where the 496 pairs dominate)
         if (Q != 8) return hipErrorInvalidValue;
+        if (form == 4) return stream_actions ? launch_impl<8, K, R, true, false, 2>(args, A, block, lds_bytes, stream)
+                                             : launch_impl<8, K, R, false, false, 2>(args, A, block, lds_bytes, stream);
         if (form == 3) return stream_actions ? launch_impl<8, K, R, true, true, 2>(args, A, block, lds_bytes, stream)
                                              : launch_impl<8, K, R, false, true, 2>(args, A, block, lds_bytes, stream);
         return stream_actions ? launch_impl<8, K, R, true, true, 1>(args, A, block, lds_bytes, stream)
@@ -797,13 +800,22 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
     const uint32_t A = uint32_t(n_agents);
     unsigned block = 0;
     int Q = 0, K = 0;
-    bool compact = false, bitmap = false, stay_column = false;
+    bool compact = false, bitmap = false, stay_column = false, full_rows_bitmap = false;
     size_t lds_bytes = kMoveAt + size_t(args.c.n_cells) * kMoveCols * sizeof(MoveEntry);   // the kernel's whole LDS image
     if (lds_bytes <= tune.mv_lds_max_bytes && lds_bytes <= kLdsBytes - kLdsReserve) {
         // Four agents per lane halve the waves: that form needs tune.quad_min_lanes lanes (default: enough to put one
         // wave on every SIMD); below that the two-agents-per-lane form of the same kernel runs.
         // Eight agents per lane halve them again (at 8 agents nothing crosses lanes any more): worth it from two waves
         // per SIMD of THAT form on, i.e. 131072 envs at 8 agents.
+        // 32 agents: four per lane with the occupancy bitmaps behind the full table (O(A) collision tests, see below) wherever that
+        // form applies -- 496 agent pairs per env are most of either all-pairs form's step
+        if (tune.bitmap_pairs && n_agents == 32 && (tune.force_k == 0 || tune.force_k == 4) && layout_fits(n_agents, 4, args, lds_bytes, &block, &Q) &&
+            lds_bytes + (block / 8u) * bitmap_stride(args.c.n_cells) <= kLdsBytes &&
+            (tune.force_k == 4 || args.n_envs * uint64_t(Q) >= tune.quad_min_lanes)) {
+            K = 4;
+            bitmap = true;
+            full_rows_bitmap = true;
+        } else
         if ((tune.force_k == 0 || tune.force_k == 8) && layout_fits(n_agents, 8, args, lds_bytes, &block, &Q) &&
             (tune.force_k == 8 || args.n_envs * uint64_t(Q) >= tune.oct_min_lanes) && block <= 512u) K = 8;
         else if (tune.force_k != 2 && tune.force_k != 8 && layout_fits(n_agents, 4, args, lds_bytes, &block, &Q) &&
@@ -853,7 +865,7 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
         *err = hipErrorInvalidValue;
         return true;
     }
-    const int form = bitmap ? (stay_column ? 3 : 2) : (compact ? 1 : 0);
+    const int form = full_rows_bitmap ? 4 : (bitmap ? (stay_column ? 3 : 2) : (compact ? 1 : 0));
     if (K == 8) *err = record ? launch_rollout_lq_k8_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k8_r0(Q, form, args, A, block, lds_bytes, stream);
     else if (K == 4) *err = record ? launch_rollout_lq_k4_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k4_r0(Q, form, args, A, block, lds_bytes, stream);
     else *err = record ? launch_rollout_lq_k2_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k2_r0(Q, form, args, A, block, lds_bytes, stream);

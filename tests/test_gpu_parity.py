@@ -410,7 +410,10 @@ def _goal_scenario_tables(n_agents, n_envs, seed):
     (8, 8192, 'lq_rollout_kernel<Q=2,K=4', {'MAPF_LQ_K': '4'}), (8, 16448, 'lq_rollout_kernel<Q=4,K=2', {'MAPF_LQ_K': '2'}),
     (8, 16448, 'lg_rollout_kernel<L=4,FULL,MV_LDS', {'MAPF_QUAD_LANES': '0'}),
     (16, 4096, 'lq_rollout_kernel<Q=4,K=4', {'MAPF_LQ_K': '4'}), (16, 4128, 'lq_rollout_kernel<Q=8,K=2', {'MAPF_LQ_K': '2'}),
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4', {'MAPF_LQ_K': '4'}), (32, 1024, 'lq_rollout_kernel<Q=16,K=2', {'MAPF_LQ_K': '2'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL> block=', {'MAPF_LQ_K': '4', 'MAPF_BITMAP_PAIRS': '0'}),
+    # (32 agents, full table rows in LDS: occupancy bitmaps behind them -- what MAPF_LQ_K=4 or a batch of one wave per SIMD gets)
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL,BITMAP> block=', {'MAPF_LQ_K': '4'}),
+    (32, 1024, 'lq_rollout_kernel<Q=16,K=2', {'MAPF_LQ_K': '2'}),
     (32, 1024, 'lg_rollout_kernel<L=16,FULL,MV_GLOBAL', {'MAPF_MV_LDS_MAX_BYTES': '0'}),
     # eight agents per lane (the default only for batches of two waves per SIMD and more)
     (8, 8192, 'lq_rollout_kernel<Q=1,K=8', {'MAPF_LQ_K': '8'}), (16, 4096, 'lq_rollout_kernel<Q=2,K=8', {'MAPF_LQ_K': '8'}),
@@ -489,7 +492,8 @@ def test_goal_reaching_episodes_against_c_oracle(n_agents, n_envs, layout, env_v
 @pytest.mark.parametrize('env_vars,want', [
     ({'MAPF_MV_LDS_MAX_BYTES': '2048'}, 'COMPACT,NO_TERMINAL,BITMAP5> block=512'),
     ({'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024', 'MAPF_BITMAP_STAYCOL': '0'}, 'COMPACT,NO_TERMINAL,BITMAP> block=1024'),
-    ({'MAPF_LQ_K': '4'}, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL> block=')])
+    ({'MAPF_LQ_K': '4'}, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL,BITMAP> block='),
+    ({'MAPF_LQ_K': '4', 'MAPF_BITMAP_PAIRS': '0'}, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL> block=')])
 def test_systolic_probability_chain_over_short_and_split_launches(env_vars, want, monkeypatch):
     """32 agents in eight lanes: the ordered probability product is a systolic chain -- one hand-over per step, the last lane
     completing a step's product seven steps later and every launch ending with seven draining rounds.  Launches SHORTER than
