@@ -92,6 +92,7 @@ struct mapf_handle_s {
     // plus A-wide unrolling); only spill-free kernels are dispatched, so those sizes use the lane-group rollout.
     bool lane_group_rollout = false;
     bool start_terminal_any = true;   // is_terminal(start) for some env (looked up once at create)
+    bool mv_delta8 = false;           // every neighbour id lies within +-127 of its cell's id (the 4-byte delta rows of the bitmap rollout)
     // Can some env be terminal right now?  Not after a call that auto-reset every finished episode (unless a START state
     // is itself terminal) or after a full reset; yes after steps without auto-reset and after set_state.  The packed
     // single step runs its instance without is_terminal(prev) when the answer is no.  While recording a graph the
@@ -376,6 +377,12 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
     else h->lane_group = A > 2;
     h->lane_group_rollout = h->lane_group || A > uint32_t(mapf::kTpeRolloutMaxAgents);
     h->tune = mapf::default_rollout_tuning(d->device);
+    h->mv_delta8 = true;
+    for (uint32_t v = 0; v < V && h->mv_delta8; ++v)
+        for (uint32_t a = 0; a < 5; ++a) {
+            const int64_t delta = int64_t(d->nbr[uint64_t(v) * 5 + a]) - int64_t(v);
+            if (delta < -127 || delta > 127) h->mv_delta8 = false;
+        }
 
     mapf::SlipRow slip_host[8];
     h->c.need_rng = build_slip_table(d->fail_prob, slip_host, h->c.p_cand) ? 1u : 0u;
@@ -706,6 +713,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     a.auto_reset = io->step_flags & MAPF_STEP_AUTO_RESET;
     a.accumulate = io->accumulate != 0;
     a.start_terminal_any = h->start_terminal_any;
+    a.mv_delta8 = h->mv_delta8;
     if (h->device_ptrs) {
         for (const void *p : {(const void *)io->actions, (const void *)io->out_returns, (const void *)io->out_episodes,
                               (const void *)io->out_collisions, (const void *)io->rec_local, (const void *)io->rec_reward,

@@ -132,6 +132,7 @@ struct RolloutArgs {
     uint32_t n_steps;
     bool start_broadcast, goal_broadcast, auto_reset, accumulate;
     bool start_terminal_any;       // some env's START state is terminal (two starts coincide / every start is its goal)
+    bool mv_delta8;                // every candidate cell of the move table lies within +-127 ids of its own cell (mapf_create looks)
 };
 
 // Every launcher names the kernel instance (and block size) that took the launch; the C ABI keeps the name of a
@@ -194,6 +195,7 @@ struct RolloutTuning {
     int force_k = 0;                 // MAPF_LQ_K=2|4|8 pins the agents per lane of the packed layout (tests)
     size_t mv_lds_max_bytes = 0;     // largest move table staged into LDS (MAPF_MV_LDS_MAX_BYTES; default: two blocks per CU)
     bool bitmap_pairs = true;        // MAPF_BITMAP_PAIRS=0: the 32-agent rollout keeps the all-pairs collision tests (tests compare both)
+    bool bitmap_delta_rows = true;   // MAPF_BITMAP_DELTA=0: the bitmap form never uses the 4-byte delta rows (tests compare the tables)
     bool bitmap_stay_column = true;  // MAPF_BITMAP_STAYCOL=0: the bitmap form always stages the four-column table (tests)
     unsigned bitmap_block = 0;       // MAPF_BITMAP_BLOCK=512|1024: block size of the bitmap form (experiments / tests; 0 = by batch)
     int step_big = 1;                // MAPF_STEP_BIG: the packed single step's resident-grid / LDS-table form -- 0 never, 1 for batches

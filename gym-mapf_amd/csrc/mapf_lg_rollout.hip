@@ -261,6 +261,7 @@ RolloutTuning default_rollout_tuning(int device) {
     if (const char *e = getenv("MAPF_BITMAP_PAIRS")) t.bitmap_pairs = atoi(e) != 0;
     if (const char *e = getenv("MAPF_BITMAP_BLOCK")) t.bitmap_block = unsigned(atoi(e));
     if (const char *e = getenv("MAPF_BITMAP_STAYCOL")) t.bitmap_stay_column = atoi(e) != 0;
+    if (const char *e = getenv("MAPF_BITMAP_DELTA")) t.bitmap_delta_rows = atoi(e) != 0;
     if (const char *e = getenv("MAPF_STEP_BIG")) t.step_big = atoi(e);
     if (const char *e = getenv("MAPF_STEP_BLOCK")) t.step_block = unsigned(atoi(e));
     return t;

@@ -135,6 +135,21 @@ __device__ __forceinline__ uint32_t sample_slot_packed(const MoveEntry &entry, u
     return d;
 }
 
+// The same for a 4-byte DELTA row (bytes 0..2: the three candidates' cell ids minus the row's own cell, signed; byte 3: the slip
+// row's biased offset / 16): the slot selects a BYTE, and the sampled cell is my current cell -- half-word H of `packed_cells` --
+// plus the sign-extended delta (one add with a word select on one operand and a sign-extending byte select on the other).
+template <int H>
+__device__ __forceinline__ uint32_t sample_slot_delta(uint32_t row, uint32_t th, uint32_t row_off, uint32_t h, uint32_t eights, uint32_t ones,
+                                                      uint32_t byte_base, uint32_t packed_cells, uint32_t &q_at, uint32_t &cell) {
+    const uint32_t d = pk_sub_sat_i16(h, th);
+    const uint32_t sign = pk_sign_i16(d);
+    q_at = dot2_i16(sign, eights, row_off);
+    const uint32_t delta = __builtin_amdgcn_perm(row, row, dot2_i16(sign, ones, byte_base));   // {byte `slot` of the row, 0, 0, 0}
+    if (H == 0) asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_0" : "=v"(cell) : "v"(packed_cells), "v"(delta));
+    else asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:BYTE_0" : "=v"(cell) : "v"(packed_cells), "v"(delta));
+    return d;
+}
+
 // "same half-word" tests only: my pair against a pair that arrives straight or half-swapped (half rotation)
 template <bool DUP, bool MOVES>
 __device__ __forceinline__ void pair_apply_same(uint32_t pk_prev, uint32_t pk_next, uint32_t o_prev, uint32_t o_next,

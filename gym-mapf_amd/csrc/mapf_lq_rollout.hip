@@ -59,6 +59,7 @@ static_assert(sizeof(SlipRow) * 8 + sizeof(OutcomeRow) * 16 <= kLdsReserve, "sta
 constexpr uint32_t kSlipAt = 0, kOutcomeAt = sizeof(SlipRow) * 8, kMoveAt = kLdsReserve, kMoveCols = 6;
 constexpr uint32_t kCompactCols = 5, kCompactEntry = 8;   // COMPACT: cells + code only, no sixth column
 constexpr uint32_t kBitmapCols = 4;                       // COMPACT + BITMAP == 1: no STAY column either
+constexpr uint32_t kDeltaCols = 6, kDeltaEntry = 4;       // COMPACT + BITMAP == 3: 4-byte delta rows, STAY twice (as the full table)
 static_assert(kOutcomeAt + sizeof(OutcomeRow) * 16 <= kMoveAt, "LDS image: slip rows, outcome rows, then the move table");
 // The LDS copy of a table row carries its slip row's byte offset PLUS kRowBias, so that sample_slot_packed's probability
 // address -- that operand minus 8 per threshold not passed -- is never negative and packs into an unsigned field (the
@@ -76,6 +77,10 @@ static_assert(offsetof(SlipRow, thr) % 8 == 0 && kZeroFactor < 128u, "a zero fac
 // The bitmaps (one per env of the block, ceil(V / 32) words each) follow the move table in the LDS image at `bitmap_base`.
 // BITMAP == 1: the table has FOUR columns (the moves; a STAY row is made up in registers) -- the form that leaves room for 128
 // bitmaps, i.e. 1024-thread blocks; BITMAP == 2: five columns (STAY included: no selects per agent), 64 bitmaps, 512 threads.
+// BITMAP == 3: 4-BYTE rows -- the three candidates as signed byte DELTAS against the row's own cell (a neighbour's id differs
+// from a cell's by less than a column's height, which mapf_create checks: RolloutArgs::mv_delta8) plus the slip row's offset
+// in the fourth byte -- so that SIX columns (STAY twice: an action byte is extracted and clamped by one v_min_u32, and no STAY
+// row is made up) take half the room of the five 8-byte ones: 128 bitmaps fit behind them on the 64x64 maps.
 template <int Q, int K, bool RECORD, bool STREAM, bool SOC, bool COMPACT, bool TERM, int BITMAP = 0>
 __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents, const uint32_t bitmap_base) {
     constexpr int P = K / 2;   // packed dwords per lane
@@ -110,7 +115,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         // (COMPACT: five columns, the first 8 bytes of every row)
         // (COMPACT + BITMAP == 1: FOUR columns -- the moves; a STAY row is (cell, cell, cell) with the all-equal code and is made
         // up in registers -- which leaves room for the occupancy bitmaps behind the table)
-        constexpr uint32_t kCols = !COMPACT ? kMoveCols : (BITMAP == 1 ? kBitmapCols : kCompactCols);
+        constexpr uint32_t kCols = !COMPACT ? kMoveCols : (BITMAP == 1 ? kBitmapCols : (BITMAP == 3 ? kDeltaCols : kCompactCols));
         const uint32_t n_words = p.c.n_cells * kCols;
         for (uint32_t w0 = threadIdx.x; w0 < n_words; w0 += 4u * blockDim.x) {
             MoveEntry part[4];
@@ -118,14 +123,19 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
             for (uint32_t k = 0; k < 4u; ++k) {
                 const uint32_t w = min(w0 + k * blockDim.x, n_words - 1u);
                 const uint32_t cell = w / kCols, col = w - cell * kCols;
-                part[k] = p.mv[!COMPACT ? cell * kMvCols + (col < kMvCols ? col : 0u) : cell * kMvCols + col + (BITMAP == 1 ? 1u : 0u)];
+                part[k] = p.mv[(!COMPACT || BITMAP == 3) ? cell * kMvCols + (col < kMvCols ? col : 0u) : cell * kMvCols + col + (BITMAP == 1 ? 1u : 0u)];
             }
 #pragma unroll
             for (uint32_t k = 0; k < 4u; ++k) {
                 const uint32_t w = w0 + k * blockDim.x;
                 if (w < n_words) {
                     // COMPACT rows: {c0 | c1 << 16, c2 | byte offset of the code's slip row << 16}
-                    if (COMPACT) reinterpret_cast<u32x2 *>(lds_mv)[w] = u32x2{part[k].x, (part[k].y & 0xFFFFu) | ((part[k].w + kRowBias) << 16)};
+                    if (COMPACT && BITMAP == 3) {
+                        // {c0 - cell, c1 - cell, c2 - cell (low bytes: a slot past the list's end is never sampled), (row offset + bias) / 8}
+                        const uint32_t cell = w / kCols;
+                        reinterpret_cast<uint32_t *>(lds_mv)[w] = ((part[k].x - cell) & 0xFFu) | ((((part[k].x >> 16) - cell) & 0xFFu) << 8) |
+                                                                  (((part[k].y - cell) & 0xFFu) << 16) | (((part[k].w + kRowBias) >> 3) << 24);
+                    } else if (COMPACT) reinterpret_cast<u32x2 *>(lds_mv)[w] = u32x2{part[k].x, (part[k].y & 0xFFFFu) | ((part[k].w + kRowBias) << 16)};
                     else lds_mv[w] = make_uint4(part[k].x, part[k].y, part[k].z ^ kHalfBias, part[k].w + kRowBias);   // thresholds: see sample_slot_packed
                 }
             }
@@ -331,9 +341,10 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     // (word picked at run time, call refreshed when t is a multiple of four).  FIRST = the launch's first step: nothing
     // is pending yet and the slip call is refreshed whatever t is.  TAIL = the action rows may run out within kAhead
     // steps, so the prefetch address is clamped.  `raw` is the register that holds this step's action word.
-    uint32_t pk_eights = 0x00080008u, pk_steps = 0x02020202u, sel_base = 0x0C0C0504u;   // sample_slot_packed's constants,
+    // (delta rows: the slot selects a byte -- steps of one, the row's byte 2 down to 0, zeros above it)
+    uint32_t pk_eights = 0x00080008u, pk_steps = BITMAP == 3 ? 0x00010001u : 0x02020202u, sel_base = BITMAP == 3 ? 0x0C0C0C02u : 0x0C0C0504u;   // sample_slot_packed's constants,
     asm volatile("" : "+v"(pk_eights), "+v"(pk_steps), "+v"(sel_base));                   // one vector register each
-    uint32_t row_bytes = COMPACT ? (BITMAP == 1 ? kBitmapCols : kCompactCols) * kCompactEntry : kMoveCols * uint32_t(sizeof(MoveEntry));
+    uint32_t row_bytes = COMPACT ? (BITMAP == 3 ? kDeltaCols * kDeltaEntry : (BITMAP == 1 ? kBitmapCols : kCompactCols) * kCompactEntry) : kMoveCols * uint32_t(sizeof(MoveEntry));
     asm volatile("" : "+v"(row_bytes));   // (one register for the whole loop; as an SGPR operand the assembler rejects the SDWA form)
     auto one_step = [&](const uint32_t s, RawWord &raw, auto w_tag, auto first_tag, auto tail_tag) __attribute__((always_inline)) {
         constexpr int W = decltype(w_tag)::value;
@@ -351,7 +362,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const uint32_t byte = uint32_t(raw >> (8 * k)) & 0xFFu;
-                act[k] = COMPACT ? (byte > 4u ? 0u : byte) : min(byte, 5u);   // six columns: extract + clamp is one v_min_u32 (byte select)
+                act[k] = (COMPACT && BITMAP != 3) ? (byte > 4u ? 0u : byte) : min(byte, 5u);   // six columns: extract + clamp is one v_min_u32 (byte select)
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) asm volatile("" : "+v"(act[k]));   // the wait for `raw` sits here
@@ -391,6 +402,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         // --- my agents' table rows (cell * 96 + action * 16, the table's LDS offset is an immediate): requested first ...
         MoveEntry entry[K];
         u32x2 cells_code[K];
+        uint32_t delta_row[K];
         uint32_t cell_at[K];   // (all the word-select multiplies first: back to back with their users each one costs an s_nop)
 #pragma unroll
         for (int k = 0; k < K; ++k) cell_at[k] = (k & 1) ? half_times<1>(c[k / 2], row_bytes) : half_times<0>(c[k / 2], row_bytes);
@@ -398,7 +410,8 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         for (int k = 0; k < K; ++k) asm volatile("" : "+v"(cell_at[k]));
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (COMPACT && BITMAP == 1) cells_code[k] = lds_at<u32x2>(lds, kMoveAt - kCompactEntry + (act[k] << 3) + cell_at[k]);   // column act - 1 (STAY: see below)
+            if (COMPACT && BITMAP == 3) delta_row[k] = lds_at<uint32_t>(lds, kMoveAt + (act[k] << 2) + cell_at[k]);
+            else if (COMPACT && BITMAP == 1) cells_code[k] = lds_at<u32x2>(lds, kMoveAt - kCompactEntry + (act[k] << 3) + cell_at[k]);   // column act - 1 (STAY: see below)
             else if (COMPACT) cells_code[k] = lds_at<u32x2>(lds, kMoveAt + (act[k] << 3) + cell_at[k]);
             else entry[k] = lds_entry_at(lds, kMoveAt + (act[k] << 4) + cell_at[k]);
         }
@@ -436,11 +449,12 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) {
-                row_off[k] = cells_code[k].y >> 16;
+                if (BITMAP == 3) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(row_off[k]) : "v"(delta_row[k]), "v"(eight));
+                else row_off[k] = cells_code[k].y >> 16;
                 th[k] = lds_at<uint32_t>(lds, kSlipAt + uint32_t(offsetof(SlipRow, th_biased)) - kRowBias + row_off[k]);   // (th[0] | th[1] << 16) ^ bias
             }
 #pragma unroll
-            for (int k = 0; k < K; ++k) entry[k] = make_uint4(cells_code[k].x, cells_code[k].y, th[k], row_off[k]);
+            for (int k = 0; k < K; ++k) entry[k] = BITMAP == 3 ? make_uint4(delta_row[k], 0u, th[k], row_off[k]) : make_uint4(cells_code[k].x, cells_code[k].y, th[k], row_off[k]);
         }
         // A slip-stream call serves an agent quad for two steps: every four steps a lane refreshes the two calls of the
         // block (h0, h0 + 1) for each of its quads, in lockstep, and files their words per pair in step order (rng[i] =
@@ -470,10 +484,18 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
             word[i] = W == 0 ? rng[i].w0 : W == 1 ? rng[i].w1 : W == 2 ? rng[i].w2 : W == 3 ? rng[i].w3 : step_word(rng[i], t);
             const uint32_t biased = word[i] ^ kHalfBias;             // low half: agent 2i's uniform, high half: agent 2i+1's
             uint32_t cell[2];
-            d[2 * i] = sample_slot_packed(entry[2 * i], __builtin_amdgcn_perm(biased, biased, 0x01000100u), pk_eights, pk_steps,
-                                          sel_base, q_at[2 * i], cell[0]);
-            d[2 * i + 1] = sample_slot_packed(entry[2 * i + 1], __builtin_amdgcn_perm(biased, biased, 0x03020302u), pk_eights, pk_steps,
-                                              sel_base, q_at[2 * i + 1], cell[1]);
+            if constexpr (BITMAP == 3) {
+                d[2 * i] = sample_slot_delta<0>(entry[2 * i].x, entry[2 * i].z, entry[2 * i].w, __builtin_amdgcn_perm(biased, biased, 0x01000100u),
+                                                pk_eights, pk_steps, sel_base, c[i], q_at[2 * i], cell[0]);
+                d[2 * i + 1] = sample_slot_delta<1>(entry[2 * i + 1].x, entry[2 * i + 1].z, entry[2 * i + 1].w,
+                                                    __builtin_amdgcn_perm(biased, biased, 0x03020302u), pk_eights, pk_steps, sel_base, c[i],
+                                                    q_at[2 * i + 1], cell[1]);
+            } else {
+                d[2 * i] = sample_slot_packed(entry[2 * i], __builtin_amdgcn_perm(biased, biased, 0x01000100u), pk_eights, pk_steps,
+                                              sel_base, q_at[2 * i], cell[0]);
+                d[2 * i + 1] = sample_slot_packed(entry[2 * i + 1], __builtin_amdgcn_perm(biased, biased, 0x03020302u), pk_eights, pk_steps,
+                                                  sel_base, q_at[2 * i + 1], cell[1]);
+            }
             if (!SYS) {   // (SYS reads the probabilities when their chain round comes)
                 q[2 * i] = lds_at<double>(lds, kSlipAt + 16u - kRowBias + q_at[2 * i]);
                 q[2 * i + 1] = lds_at<double>(lds, kSlipAt + 16u - kRowBias + q_at[2 * i + 1]);
@@ -489,6 +511,13 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
             for (int k = 0; k < K; ++k) {
                 if (__any(zero_half(d[k]) != 0u)) {
                     MoveEntry full = entry[k];
+                    if (COMPACT && BITMAP == 3) {   // the candidates' cells back from their deltas
+                        const uint32_t mine = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu, row = full.x;
+                        const uint32_t c0 = (mine + uint32_t(int32_t(int8_t(row)))) & 0xFFFFu, c1 = (mine + uint32_t(int32_t(int8_t(row >> 8)))) & 0xFFFFu,
+                                       c2 = (mine + uint32_t(int32_t(int8_t(row >> 16)))) & 0xFFFFu;
+                        full.x = c0 | (c1 << 16);
+                        full.y = c2;
+                    }
                     if (COMPACT) full.y = (full.y & 0xFFFFu) | (((full.w - kRowBias) / uint32_t(sizeof(SlipRow))) << 16);   // the code, where entry_code() looks
                     const uint32_t hi = (k & 1) ? word[k / 2] >> 16 : word[k / 2] & 0xFFFFu;
                     uint32_t nx;
@@ -548,7 +577,7 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 const uint32_t goal_k = (k & 1) ? g[k / 2] >> 16 : g[k / 2] & 0xFFFFu;
-                mine += (cur[k] == goal_k && (act[k] == 0u || (!COMPACT && act[k] == 5u))) ? 1u : 0u;
+                mine += (cur[k] == goal_k && (act[k] == 0u || ((!COMPACT || BITMAP == 3) && act[k] == 5u))) ? 1u : 0u;
             }
             const int stayed = int(group_reduce<Q, true>(mine, x));
             const double living = __dmul_rn(double(int(n_agents) - stayed), p.c.r_living);
@@ -688,8 +717,8 @@ hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size
     const unsigned grid = unsigned(args.n_envs / (block / unsigned(Q)));
     note_kernel("lq_rollout_kernel<Q=%d,K=%d,%s,%s,%s%s%s%s> block=%u (packed layout: %d agents per lane%s%s)", Q, K, RECORD ? "RECORD" : "TOTALS",
                 STREAM ? "STREAM" : "POLICY", args.c.criteria != 0u ? "SOC" : "MAKESPAN", COMPACT ? ",COMPACT" : "",
-                (args.c.criteria == 0u && !term) ? ",NO_TERMINAL" : "", (BITMAP == 2 && COMPACT) ? ",BITMAP5" : (BITMAP ? ",BITMAP" : ""), block, K,
-                COMPACT ? (BITMAP == 1 ? ", 8-byte table rows without the STAY column" : ", 8-byte table rows") : "",
+                (args.c.criteria == 0u && !term) ? ",NO_TERMINAL" : "", (BITMAP == 2 && COMPACT) ? ",BITMAP5" : (BITMAP == 3 ? ",BITMAPD" : (BITMAP ? ",BITMAP" : "")), block, K,
+                COMPACT ? (BITMAP == 3 ? ", 4-byte delta rows" : (BITMAP == 1 ? ", 8-byte table rows without the STAY column" : ", 8-byte table rows")) : "",
                 BITMAP ? ", collisions through per-env occupancy bitmaps" : "");
     hipLaunchKernelGGL(kern, dim3(grid), dim3(block), lds_bytes, stream, args, A, bitmap_base);
     return hipGetLastError();
@@ -709,8 +738,9 @@ hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, int form, const Rollou
     constexpr int K = MAPF_LQ_K;
     constexpr bool R = MAPF_LQ_RECORD != 0;
     const bool stream_actions = args.actions != nullptr;
-    // form: 0 full table rows, 1 8-byte rows, 2 / 3 8-byte rows + occupancy bitmaps (four / five columns), 4 full rows + bitmaps
-    const bool compact = form >= 1 && form <= 3, bitmap = form >= 2;
+    // form: 0 full table rows, 1 8-byte rows, 2 / 3 8-byte rows + occupancy bitmaps (four / five columns), 4 full rows + bitmaps,
+    // 5 4-byte delta rows + bitmaps
+    const bool compact = (form >= 1 && form <= 3) || form == 5, bitmap = form >= 2;
     (void)bitmap;
 #if MAPF_LQ_K == 8
     // eight agents per lane: 8, 16 and 32 agents (Q = 1, 2, 4); 8-byte table rows for the 32-agent maps only
@@ -732,6 +762,8 @@ hipError_t MAPF_LQ_NAME(MAPF_LQ_K, MAPF_LQ_RECORD)(int Q, int form, const Rollou
 #if MAPF_LQ_K == 4
     if (bitmap) {    // 32 agents only (that is where the 496 pairs dominate)
         if (Q != 8) return hipErrorInvalidValue;
+        if (form == 5) return stream_actions ? launch_impl<8, K, R, true, true, 3>(args, A, block, lds_bytes, stream)
+                                             : launch_impl<8, K, R, false, true, 3>(args, A, block, lds_bytes, stream);
         if (form == 4) return stream_actions ? launch_impl<8, K, R, true, false, 2>(args, A, block, lds_bytes, stream)
                                              : launch_impl<8, K, R, false, false, 2>(args, A, block, lds_bytes, stream);
         if (form == 3) return stream_actions ? launch_impl<8, K, R, true, true, 2>(args, A, block, lds_bytes, stream)
@@ -800,7 +832,7 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
     const uint32_t A = uint32_t(n_agents);
     unsigned block = 0;
     int Q = 0, K = 0;
-    bool compact = false, bitmap = false, stay_column = false, full_rows_bitmap = false;
+    bool compact = false, bitmap = false, stay_column = false, full_rows_bitmap = false, delta_rows = false;
     size_t lds_bytes = kMoveAt + size_t(args.c.n_cells) * kMoveCols * sizeof(MoveEntry);   // the kernel's whole LDS image
     if (lds_bytes <= tune.mv_lds_max_bytes && lds_bytes <= kLdsBytes - kLdsReserve) {
         // Four agents per lane halve the waves: that form needs tune.quad_min_lanes lanes (default: enough to put one
@@ -839,6 +871,20 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
         unsigned bitmap_block = 512u;
         if (tune.bitmap_block == 1024u || (tune.bitmap_block == 0u && args.n_envs * 8u >= uint64_t(n_cu) * 1024u)) bitmap_block = 1024u;
         if (bitmap_block == 1024u && (args.n_envs % (1024u / 8u) != 0 || bitmap_lds + (1024u / 8u) * per_env > kLdsBytes)) bitmap_block = 512u;
+        // ... behind 4-byte delta rows where the map's ids allow them (six columns in 79 KB on the 64x64 maps: 128 bitmaps fit, no
+        // STAY row to make up, one-instruction action clamp)
+        const size_t delta_lds = kMoveAt + size_t(args.c.n_cells) * kDeltaCols * kDeltaEntry;
+        unsigned delta_block = (tune.bitmap_block == 1024u || (tune.bitmap_block == 0u && args.n_envs * 8u >= uint64_t(n_cu) * 1024u)) ? 1024u : 512u;
+        if (delta_block == 1024u && (args.n_envs % (1024u / 8u) != 0 || delta_lds + (1024u / 8u) * per_env > kLdsBytes)) delta_block = 512u;
+        if (tune.bitmap_pairs && tune.bitmap_delta_rows && args.mv_delta8 && n_agents == 32 && tune.force_k != 8 && tune.force_k != 2 &&
+            layout_fits(n_agents, 4, args, delta_lds, &block, &Q) && args.n_envs % (delta_block / 8u) == 0 &&
+            delta_lds + (delta_block / 8u) * per_env <= kLdsBytes) {
+            block = delta_block;
+            K = 4;
+            bitmap = true;
+            delta_rows = true;
+            lds_bytes = delta_lds;
+        } else
         if (tune.bitmap_pairs && n_agents == 32 && tune.force_k != 8 && tune.force_k != 2 && layout_fits(n_agents, 4, args, bitmap_lds, &block, &Q) &&
             args.n_envs % (bitmap_block / 8u) == 0 && bitmap_lds + (bitmap_block / 8u) * per_env <= kLdsBytes) {
             block = bitmap_block;
@@ -865,7 +911,7 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
         *err = hipErrorInvalidValue;
         return true;
     }
-    const int form = full_rows_bitmap ? 4 : (bitmap ? (stay_column ? 3 : 2) : (compact ? 1 : 0));
+    const int form = delta_rows ? 5 : (full_rows_bitmap ? 4 : (bitmap ? (stay_column ? 3 : 2) : (compact ? 1 : 0)));
     if (K == 8) *err = record ? launch_rollout_lq_k8_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k8_r0(Q, form, args, A, block, lds_bytes, stream);
     else if (K == 4) *err = record ? launch_rollout_lq_k4_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k4_r0(Q, form, args, A, block, lds_bytes, stream);
     else *err = record ? launch_rollout_lq_k2_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k2_r0(Q, form, args, A, block, lds_bytes, stream);

@@ -424,11 +424,14 @@ def _goal_scenario_tables(n_agents, n_envs, seed):
     (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_PAIRS': '0'}),
     # (32 agents, 8-byte rows: collisions through per-env LDS occupancy bitmaps instead of the 496 agent pairs -- the default)
     # (five-column table where it leaves room for the bitmaps -- here it does -- else four columns and a made-up STAY row)
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP5> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_STAYCOL': '0'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP5> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_DELTA': '0'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_STAYCOL': '0', 'MAPF_BITMAP_DELTA': '0'}),
     # (... in 1024-thread blocks, 128 bitmaps behind the table: what a batch that fills every CU with such a block gets)
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024', 'MAPF_BITMAP_STAYCOL': '0'}),
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP5> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024', 'MAPF_BITMAP_STAYCOL': '0', 'MAPF_BITMAP_DELTA': '0'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP5> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024', 'MAPF_BITMAP_DELTA': '0'}),
+    # (... behind 4-byte delta rows -- the default wherever a map's neighbour ids lie within +-127 of their cell's)
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAPD> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAPD> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024'}),
     (64, 16384, 'lq_rollout_kernel<Q=16,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
     (8, 300, 'lg_rollout_kernel<L=4,FULL,MV_GLOBAL', {}), (5, 600, 'lg_rollout_kernel<L=4,RAGGED', {}),
     (8, 16417, 'lg_rollout_kernel<L=4,FULL,MV_LDS', {}), (6, 512, 'rollout_kernel<A=6>', {})])
@@ -490,8 +493,9 @@ def test_goal_reaching_episodes_against_c_oracle(n_agents, n_envs, layout, env_v
 
 
 @pytest.mark.parametrize('env_vars,want', [
-    ({'MAPF_MV_LDS_MAX_BYTES': '2048'}, 'COMPACT,NO_TERMINAL,BITMAP5> block=512'),
-    ({'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024', 'MAPF_BITMAP_STAYCOL': '0'}, 'COMPACT,NO_TERMINAL,BITMAP> block=1024'),
+    ({'MAPF_MV_LDS_MAX_BYTES': '2048'}, 'COMPACT,NO_TERMINAL,BITMAPD> block=512'),
+    ({'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_DELTA': '0'}, 'COMPACT,NO_TERMINAL,BITMAP5> block=512'),
+    ({'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024', 'MAPF_BITMAP_STAYCOL': '0', 'MAPF_BITMAP_DELTA': '0'}, 'COMPACT,NO_TERMINAL,BITMAP> block=1024'),
     ({'MAPF_LQ_K': '4'}, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL,BITMAP> block='),
     ({'MAPF_LQ_K': '4', 'MAPF_BITMAP_PAIRS': '0'}, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL> block=')])
 def test_systolic_probability_chain_over_short_and_split_launches(env_vars, want, monkeypatch):
@@ -598,15 +602,19 @@ def test_large_map_maze128_32agents_16384_envs(monkeypatch, criteria):
     assert n > 100                                                # (32 agents leaving one scenario's start cells do collide)
 
 
-@pytest.mark.parametrize('criteria', ['Makespan', 'SoC'])
-def test_reference_room64_maps_32agents_under_default_dispatch(monkeypatch, criteria):
+@pytest.mark.parametrize('criteria,delta_rows', [('Makespan', True), ('SoC', True), ('Makespan', False), ('SoC', False)])
+def test_reference_room64_maps_32agents_under_default_dispatch(monkeypatch, criteria, delta_rows):
     """32 agents on the reference's own 64x64 room maps (room-64-64-16: 3646 free cells, room-64-64-8: 3232; scenarios that
     construct with 32 agents), 8192 envs over several scenarios each: the occupancy-bitmap / systolic-chain form of the packed
     rollout under default dispatch -- the four-column table where five columns would not leave room for the bitmaps, the
-    five-column one where they do -- and the packed single step, every env of every step against the C oracle."""
+    five-column one where they do (MAPF_BITMAP_DELTA=0), or 4-byte delta rows (the default on these maps) -- and the packed
+    single step, every env of every step against the C oracle."""
     monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    if not delta_rows:
+        monkeypatch.setenv('MAPF_BITMAP_DELTA', '0')
     crit, ocrit = (OptimizationCriteria.SoC, mo.SOC) if criteria == 'SoC' else (OptimizationCriteria.Makespan, mo.MAKESPAN)
     for map_name, want in (('room-64-64-16', ',BITMAP> block=512'), ('room-64-64-8', ',BITMAP5> block=512')):
+        want = ',BITMAPD> block=512' if delta_rows else want
         scen_ids = []
         for sid in range(1, 26):                                   # (a scenario whose first 32 agents do not construct is skipped)
             try:
@@ -723,14 +731,14 @@ def test_config5_bench_tables_16384_envs_under_default_dispatch(monkeypatch):
 
 def test_config5_whole_131072_envs_under_default_dispatch(monkeypatch):
     """BASELINE configs[4] whole on ONE GPU (131072 envs x 32 agents, as `bench.py --config c5` builds it): every CU gets a
-    1024-thread block, so the default dispatch is the occupancy-bitmap form with 128 bitmaps behind the table -- every env of
+    1024-thread block, so the default dispatch is the occupancy-bitmap form with 128 bitmaps behind the (delta-row) table -- every env of
     every step against the C oracle (single steps, a streamed recorded rollout, a policy-stream rollout)."""
     import bench
     monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
     cfg = bench.CONFIGS['c5']
     grid, _, nbr, start, goal = bench.workload_tables(cfg, cfg['envs'], 0)
     assert _full_size_check(grid, nbr, cfg['agents'], start, goal, cfg['fail_prob'], OptimizationCriteria.Makespan, mo.MAKESPAN, 2, 8,
-                            want_rollout='lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=1024',
+                            want_rollout='lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAPD> block=1024',
                             n_streamed=8) > 4000
 
 
