@@ -34,7 +34,8 @@
 // 32 agents on such maps (BASELINE configs[4]): four agents per lane, eight lanes per env, and two things that are O(A)
 // instead of what the other instances do -- the vertex / swap facts through a per-env ONE-BIT occupancy bitmap in LDS behind
 // the table (BITMAP, bitmap_pair_tests in mapf_lq.hpp: three LDS operations per agent instead of 496 agent pairs per env;
-// 128 bitmaps behind a four-column table in 1024-thread blocks, 64 behind the five-column one in 512-thread blocks), and the
+// behind 4-byte delta rows where the map's ids allow them, else 128 bitmaps behind a four-column table of 8-byte rows in
+// 1024-thread blocks, 64 behind the five-column one in 512-thread blocks), and the
 // ordered probability product as a systolic chain over the steps (SYS below: one hand-over per step and lane instead of
 // seven).  DESIGN.md section 4.1 has the measurements of each step.
 //

@@ -67,6 +67,7 @@ def main():
         ('lq_rollout_kernel<2, 4, true, true, false, false, false, 0>', ['-DMAPF_LQ_K=4', '-DMAPF_LQ_RECORD=1'], 'ILi2ELi4ELb1ELb1ELb0ELb0ELb0ELi0E'),
         ('lq_rollout_kernel<8, 4, true, true, false, true, false, 2>', ['-DMAPF_LQ_K=4', '-DMAPF_LQ_RECORD=1'], 'ILi8ELi4ELb1ELb1ELb0ELb1ELb0ELi2E'),
         ('lq_rollout_kernel<8, 4, true, true, false, true, false, 1>', ['-DMAPF_LQ_K=4', '-DMAPF_LQ_RECORD=1'], 'ILi8ELi4ELb1ELb1ELb0ELb1ELb0ELi1E'),
+        ('lq_rollout_kernel<8, 4, true, true, false, true, false, 3>', ['-DMAPF_LQ_K=4', '-DMAPF_LQ_RECORD=1'], 'ILi8ELi4ELb1ELb1ELb0ELb1ELb0ELi3E'),
         ('lq_rollout_kernel<4, 8, true, true, false, true, false, 0>', ['-DMAPF_LQ_K=8', '-DMAPF_LQ_RECORD=1'], 'ILi4ELi8ELb1ELb1ELb0ELb1ELb0ELi0E'),
         ('lq_rollout_kernel<1, 8, true, true, false, false, false, 0>', ['-DMAPF_LQ_K=8', '-DMAPF_LQ_RECORD=1'], 'ILi1ELi8ELb1ELb1ELb0ELb0ELb0ELi0E'),
     ]
