@@ -742,6 +742,25 @@ def test_config5_whole_131072_envs_under_default_dispatch(monkeypatch):
                             n_streamed=8) > 4000
 
 
+def test_tall_map_keeps_eight_byte_rows_behind_the_bitmaps(monkeypatch):
+    """A map whose columns are taller than 127 cells: a horizontal neighbour's id is more than 127 away from its cell's, so the
+    4-byte delta rows do not apply (mapf_create looks at every neighbour) and the bitmap form stages 8-byte rows -- 32 agents
+    on an open 160 x 12 map with a few walls, every env of every step against the C oracle."""
+    monkeypatch.setenv('MAPF_MV_LDS_MAX_BYTES', '2048')
+    rs = np.random.RandomState(7)
+    obst = rs.rand(160, 12) < 0.08
+    grid = MapfGrid([''.join('@' if obst[r, c] else '.' for c in range(12)) for r in range(160)])
+    valid, _, nbr = grid.tables()
+    V, E, A = len(valid), 2048, 32
+    assert int(np.abs(nbr.astype(np.int64) - np.arange(V)[:, None]).max()) > 127
+    r2 = np.random.RandomState(11)
+    start = np.argsort(r2.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    goal = np.argsort(r2.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    assert _full_size_check(grid, nbr, A, start, goal, 0.2, OptimizationCriteria.Makespan, mo.MAKESPAN, 3, 12,
+                            want_rollout='lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP5> block=512',
+                            n_streamed=12) > 50
+
+
 def test_config5_random64_32agents_16384_envs():
     """BASELINE configs[4], one GPU's share (131072 / 8): synthetic 64x64 map with 20 % obstacles
     (RandomState(20); the reference does not ship random-64-64-20), 32 agents, slip 0.2, seeded random
