@@ -381,6 +381,65 @@ def per_gpu_shape_rate(name, n_envs, T=256, n_launch=10, blocks=3, preroll_ms=60
                          "bytes_per_launch": launch_bytes}}
 
 
+def transitions_rate(n_agents, n_queries, reps=10, blocks=3, compact=False, seed=0):
+    """`env.P[s][a]` (reference mapf_env.py:448-483) as one mapf_transitions launch over `n_queries` random
+    (state, joint action) queries on room-32-32-4: distinct random cells per query, uniform joint actions, outputs reserved
+    once.  The kernel reads 3A bytes per query and WRITES every branch of the joint slip distribution -- next cells u16[A],
+    prob f64, reward f64, done u8, collision u8 = 2A + 18 bytes per branch, nothing re-read -- so its roofline is HBM write
+    bandwidth: achieved = branches x (2A + 18) / HIP-event time per launch (median of `blocks` blocks of `reps` launches).
+    compact=True: the packed output mode (rows of all queries back to back behind an exclusive scan of the branch counts)."""
+    import torch
+    from gym_mapf_amd.envs import map_name_to_files
+    from gym_mapf_amd.envs.grid import MapfGrid
+    from gym_mapf_amd.envs.utils import parse_map_file, parse_scen_file
+    from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv
+    A, N = int(n_agents), int(n_queries)
+    grid = MapfGrid(parse_map_file(map_name_to_files('room-32-32-4', 6)[0]))
+    starts, goals = parse_scen_file(map_name_to_files('room-32-32-4', 6)[1], A)
+    env = VecMapfEnv(grid, A, starts, goals, 0.2, R_CLASH, R_GOAL, R_LIVING, OptimizationCriteria.Makespan, n_envs=1,
+                     device=torch.cuda.current_device(), device_arrays=True)
+    rs = np.random.RandomState(seed)
+    V = env.n_cells
+    local = rs.randint(0, V, size=(N, A))
+    while True:                                                   # rows with a repeated cell are redrawn until none is left
+        srt = np.sort(local, axis=1)
+        bad = np.nonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1))[0]
+        if bad.size == 0:
+            break
+        local[bad] = rs.randint(0, V, size=(bad.size, A))
+    local = local.astype(np.uint16)
+    acts = rs.randint(0, 5, size=(N, A)).astype(np.uint8)
+    lt = torch.from_numpy(local.view(np.int16)).cuda().view(torch.uint16)
+    at = torch.from_numpy(acts).cuda()
+    M = 3 ** A
+    if compact:
+        res = env.transitions_compact(lt, at)
+        call = lambda: env.transitions_compact(lt, at, out=res)
+    else:
+        res = env.transitions(lt, at, max_branches=M)
+        call = lambda: env.transitions(lt, at, max_branches=M, out=res)
+    env.sync()
+    branches = int(res['count'].to(torch.int64).sum().item())
+    ms = []
+    for _ in range(blocks):
+        env.sync()
+        env.timer_begin()
+        for _ in range(reps):
+            call()
+        ms.append(env.timer_end() / reps)
+    launch_ms = sorted(ms)[(len(ms) - 1) // 2]
+    kernel = env.last_kernel('transitions')
+    env.close()
+    nbytes = float(branches) * (2 * A + 18)
+    return {"workload": "room-32-32-4, %d agents, %d random (state, joint action) queries, slip 0.2, %s output rows"
+                        % (A, N, 'compacted' if compact else '3^A reserved'),
+            "value": branches / (launch_ms * 1e-3), "unit": "branches/s", "branches": branches, "queries": N,
+            "ms_per_launch_hip_events": launch_ms, "launches": reps, "blocks": blocks, "kernel": kernel,
+            "roofline": {"bound": "hbm", "achieved": nbytes / (launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": nbytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "bytes_per_launch": nbytes,
+                         "bytes_per_branch": 2 * A + 18, "traffic": None}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)

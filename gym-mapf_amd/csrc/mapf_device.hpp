@@ -372,18 +372,47 @@ __device__ __forceinline__ uint32_t greedy_action(const uint2 *cells, uint32_t n
     return (pc.y >> (3 * k)) & 7u;
 }
 
-// Policy stream (oracle/philox.py random_actions_np): one Philox call per 4 agents.
+// Policy stream (oracle/philox.py random_actions_np; key = seed + 1): ONE call serves an agent quad for FOUR consecutive
+// steps -- counter (env, m = t >> 2, quad), word t & 3 belongs to step t, its byte (agent & 3) to the agent, and
+// action = (byte * 5) >> 8.  A fused rollout pays one call per lane per four steps and a multiply + shift per action.
+__device__ __forceinline__ Words4 policy_words(uint32_t key_lo, uint32_t key_hi, uint64_t env_id, uint64_t m, uint32_t quad) {
+    uint32_t w[4];
+    philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(m), (uint32_t(m >> 32) & 0xFFFFu) | (quad << 16), key_lo, key_hi, w);
+    return Words4{w[0], w[1], w[2], w[3]};
+}
+__device__ __forceinline__ Words4 policy_words(const EnvConsts &c, uint64_t env_id, uint64_t m, uint32_t quad) {
+    return policy_words(c.pol_lo, c.pol_hi, env_id, m, quad);
+}
+// two quads of one env in lockstep (eight agents per lane)
+__device__ __forceinline__ void policy_words_x2(uint32_t key_lo, uint32_t key_hi, uint64_t env_id, uint64_t m, uint32_t quad_a, uint32_t quad_b, Words4 &wa, Words4 &wb) {
+    uint32_t a[4], b[4];
+    const uint32_t hi = uint32_t(m >> 32) & 0xFFFFu;
+    philox4x32_10_x2(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(m), hi | (quad_a << 16), uint32_t(m), hi | (quad_b << 16), key_lo, key_hi, a, b);
+    wa = Words4{a[0], a[1], a[2], a[3]};
+    wb = Words4{b[0], b[1], b[2], b[3]};
+}
+// action of byte B (0..3) of a step's policy word: one multiply with a byte select, one (fast-issue) right shift
+template <int B>
+__device__ __forceinline__ uint32_t policy_action(uint32_t word, uint32_t five) {   // five: the constant 5 in a VECTOR register
+    uint32_t scaled;
+    if (B == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(scaled) : "v"(word), "v"(five));
+    else if (B == 1) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(scaled) : "v"(word), "v"(five));
+    else if (B == 2) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(scaled) : "v"(word), "v"(five));
+    else asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(scaled) : "v"(word), "v"(five));
+    return scaled >> 8;
+}
+__device__ __forceinline__ uint32_t policy_action_rt(uint32_t word, uint32_t byte) { return (((word >> (8u * byte)) & 0xFFu) * 5u) >> 8; }
+
+// thread-per-env form: every quad's call of the step's block, recomputed each step (that family is the small-batch /
+// cross-check path; the packed and lane-group rollouts keep a block's words for its four steps)
 template <int A>
 __device__ __forceinline__ void policy_actions(const EnvConsts &c, uint64_t env_id, uint64_t t,
                                                uint32_t (&act)[A]) {
-    uint32_t w[4];
+    Words4 w{0u, 0u, 0u, 0u};
 #pragma unroll
     for (int i = 0; i < A; ++i) {
-        if ((i & 3) == 0) {
-            const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | (uint32_t(i >> 2) << 24);
-            philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, c.pol_lo, c.pol_hi, w);
-        }
-        act[i] = __umulhi(w[i & 3], 5u);
+        if ((i & 3) == 0) w = policy_words(c, env_id, t >> 2, uint32_t(i >> 2));
+        act[i] = policy_action_rt(step_word(w, t), uint32_t(i & 3));
     }
 }
 

@@ -80,24 +80,35 @@ __global__ void __launch_bounds__(256) query_terminal_kernel(const uint16_t *sta
     out[e] = (dup || all_goal) ? 1 : 0;
 }
 
-// policy stream (oracle/philox.py random_actions_np): one thread per (row, group of 4 agents)
+// policy stream (oracle/philox.py random_actions_np): one thread per (four-step block, env, agent quad) -- one Philox
+// call, whose word t & 3 holds the quad's four action bytes of step t
 __global__ void __launch_bounds__(256) fill_actions_kernel(uint8_t *actions, EnvConsts c, uint64_t env_id_offset,
-                                                           uint64_t n_envs, uint64_t t0, uint64_t n_rows,
+                                                           uint64_t n_envs, uint64_t t0, uint64_t n_steps,
                                                            uint32_t n_agents) {
     const uint32_t quads = (n_agents + 3u) / 4u;
+    const uint64_t m0 = t0 >> 2, n_blocks = ((t0 + n_steps - 1u) >> 2) - m0 + 1u;
     const uint64_t i = uint64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n_rows * quads) return;
-    const uint64_t row = i / quads;
+    if (i >= n_blocks * n_envs * quads) return;
+    const uint64_t row = i / quads;                              // (block, env)
     const uint32_t q = uint32_t(i - row * quads);
-    const uint64_t s = row / n_envs, e = row - s * n_envs;
-    const uint64_t env_id = env_id_offset + e, t = t0 + s;
-    uint32_t w[4];
-    const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | (q << 24);
-    philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, c.pol_lo, c.pol_hi, w);
-    uint8_t *dst = actions + row * n_agents + 4u * q;
+    const uint64_t blk = row / n_envs, e = row - blk * n_envs;
+    const uint64_t m = m0 + blk;
+    const Words4 w = policy_words(c, env_id_offset + e, m, q);
 #pragma unroll
-    for (uint32_t k = 0; k < 4; ++k)
-        if (4u * q + k < n_agents) dst[k] = uint8_t(__umulhi(w[k], 5u));
+    for (uint32_t j = 0; j < 4; ++j) {
+        const uint64_t t = 4u * m + j;
+        if (t < t0 || t >= t0 + n_steps) continue;
+        const uint32_t word = pick_word(w, j);
+        uint8_t *dst = actions + ((t - t0) * n_envs + e) * n_agents + 4u * q;
+        if ((n_agents & 3u) == 0u) {                            // a quad's four bytes as one store
+            *reinterpret_cast<uint32_t *>(dst) = policy_action_rt(word, 0u) | (policy_action_rt(word, 1u) << 8) |
+                                                 (policy_action_rt(word, 2u) << 16) | (policy_action_rt(word, 3u) << 24);
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < 4; ++k)
+                if (4u * q + k < n_agents) dst[k] = uint8_t(policy_action_rt(word, k));
+        }
+    }
 }
 
 // the device-side step index of a recorded graph (StepArgs::t_dev): advanced by the graph's last node
@@ -144,12 +155,12 @@ hipError_t launch_query_terminal(int n_agents, const uint16_t *state, const uint
 
 hipError_t launch_fill_actions(int n_agents, uint8_t *actions, const EnvConsts &c, uint64_t env_id_offset,
                                uint64_t n_envs, uint64_t t0, uint64_t n_steps, hipStream_t stream) {
-    const uint64_t n_rows = n_envs * n_steps;
-    if (n_rows == 0) return hipSuccess;
+    if (n_envs == 0 || n_steps == 0) return hipSuccess;
+    const uint64_t n_blocks = ((t0 + n_steps - 1u) >> 2) - (t0 >> 2) + 1u;
     unsigned grid;
-    if (hipError_t e = grid_1d(n_rows * uint64_t((n_agents + 3) / 4), 256, grid)) return e;
+    if (hipError_t e = grid_1d(n_blocks * n_envs * uint64_t((n_agents + 3) / 4), 256, grid)) return e;
     hipLaunchKernelGGL(fill_actions_kernel, dim3(grid), dim3(256), 0, stream, actions, c, env_id_offset, n_envs, t0,
-                       n_rows, uint32_t(n_agents));
+                       n_steps, uint32_t(n_agents));
     return hipGetLastError();
 }
 

@@ -113,7 +113,7 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
     if (STREAM && p.n_steps > 0) raw = load_actions_raw<FULL>(p.actions, e, n_agents, x.g, x.v0, x.v1);
     // consume the first word here, so that the wait at the loop head is the back edge's counted one
     if (DENSE) asm volatile("" : "+v"(raw));
-    Words4 rng{0u, 0u, 0u, 0u};
+    Words4 rng{0u, 0u, 0u, 0u}, pol{0u, 0u, 0u, 0u};   // the slip / policy words of the current four-step block
     // step s-1's results, stored during step s (DENSE: the very first store writes zeros into step 0's row, which
     // step 1 then overwrites with the real values)
     uint32_t d_next0 = 0u, d_next1 = 0u, d_flags = 0u;
@@ -187,13 +187,12 @@ __global__ void __launch_bounds__(rollout_max_block<L>()) lg_rollout_kernel(cons
         } else if (p.policy_cells) {   // greedy policy (ghost slots read cell 0: their actions are never used)
             act0 = greedy_action(p.policy_cells, p.c.n_cells, cur0, goal_rc0);
             act1 = greedy_action(p.policy_cells, p.c.n_cells, cur1, goal_rc1);
-        } else {   // policy stream: one Philox call covers agents 4q..4q+3; this lane needs words 2(g&1), 2(g&1)+1
-            uint32_t w[4];
-            const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | ((x.g >> 1) << 24);
-            philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, p.c.pol_lo, p.c.pol_hi, w);
-            const bool hi = (x.g & 1u) != 0u;
-            act0 = __umulhi(hi ? w[2] : w[0], 5u);
-            act1 = __umulhi(hi ? w[3] : w[1], 5u);
+        } else {   // policy stream: one Philox call covers agents 4q..4q+3 for the four steps of a block; this lane's
+            // agents are bytes 2(g&1), 2(g&1)+1 of the step's word
+            if ((t & 3u) == 0u || s == 0u) pol = policy_words(p.c, env_id, t >> 2, x.g >> 1);
+            const uint32_t mine = step_word(pol, t) >> (16u * (x.g & 1u));
+            act0 = policy_action_rt(mine, 0u);
+            act1 = policy_action_rt(mine, 1u);
         }
         if (RECORD && (DENSE || s > 0)) {                    // (2) the previous step's outputs
             store_record();

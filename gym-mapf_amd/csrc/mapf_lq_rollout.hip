@@ -338,6 +338,21 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         for (int k = 0; k < K; ++k) goal_rc[k] = p.policy_cells[(k & 1) ? g[k / 2] >> 16 : g[k / 2] & 0xFFFFu].x;
     }
 
+    // In-kernel policy stream (!STREAM, no greedy table): the words of the current four-step block, one call per agent quad
+    constexpr int kPolicyCalls = K == 8 ? 2 : 1;
+    Words4 pol[kPolicyCalls];
+#pragma unroll
+    for (int j = 0; j < kPolicyCalls; ++j) pol[j] = Words4{0u, 0u, 0u, 0u};
+    // (eight agents per lane: the key waits in two VECTOR registers -- those instances have them to spare, while their SoC
+    // form is two scalar registers short of keeping it beside the slip stream's)
+    uint32_t pol_key_lo = p.c.pol_lo, pol_key_hi = p.c.pol_hi;
+    if (K == 8) asm volatile("" : "+v"(pol_key_lo), "+v"(pol_key_hi));
+    auto refresh_policy = [&](const uint64_t m) __attribute__((always_inline)) {
+        if constexpr (K == 8) policy_words_x2(__builtin_amdgcn_readfirstlane(pol_key_lo), __builtin_amdgcn_readfirstlane(pol_key_hi), env_id, m,
+                                              2u * x.g, 2u * x.g + 1u, pol[0], pol[1]);
+        else pol[0] = policy_words(p.c, env_id, m, K == 4 ? x.g : x.g >> 1);
+    };
+
     // One step.  W = which word of the slip calls this step uses (t & 3) when that is a compile-time fact, -1 = generic
     // (word picked at run time, call refreshed when t is a multiple of four).  FIRST = the launch's first step: nothing
     // is pending yet and the slip call is refreshed whatever t is.  TAIL = the action rows may run out within kAhead
@@ -374,30 +389,26 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         } else if (p.policy_cells) {   // greedy policy
 #pragma unroll
             for (int k = 0; k < K; ++k) act[k] = greedy_action(p.policy_cells, p.c.n_cells, cur[k], goal_rc[k]);
-        } else {   // policy stream: one Philox call covers agents 4j .. 4j+3
-            if constexpr (K == 8) {
+        } else {   // policy stream: the step's word of my quad's call (one call per quad per four steps), a byte per agent
+            if (FIRST) refresh_policy(t >> 2);                     // (later blocks: requested in the step before their first one, below)
+            uint32_t five;                                         // (made where it is used: the 1024-thread forms have no register to park it in)
+            asm volatile("v_mov_b32 %0, 5" : "=v"(five));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    uint32_t w[4];
-                    const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | ((2u * x.g + uint32_t(j)) << 24);
-                    philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, p.c.pol_lo, p.c.pol_hi, w);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) act[4 * j + k] = __umulhi(w[k], 5u);
-                }
-            } else {
-                uint32_t w[4];
-                const uint32_t quad = K == 4 ? x.g : x.g >> 1;
-                const uint32_t c3 = (uint32_t(t >> 32) & 0x00FFFFFFu) | (quad << 24);
-                philox4x32_10(uint32_t(env_id), uint32_t(env_id >> 32), uint32_t(t), c3, p.c.pol_lo, p.c.pol_hi, w);
-                if (K == 4) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) act[k] = __umulhi(w[k], 5u);
+            for (int j = 0; j < kPolicyCalls; ++j) {
+                uint32_t pw = W == 0 ? pol[j].w0 : W == 1 ? pol[j].w1 : W == 2 ? pol[j].w2 : W == 3 ? pol[j].w3 : step_word(pol[j], t);
+                if constexpr (K == 2) {                            // the quad is shared with the neighbour lane: bytes 2 (g & 1), + 1
+                    pw >>= 16u * (x.g & 1u);
+                    act[0] = policy_action<0>(pw, five);
+                    act[1] = policy_action<1>(pw, five);
                 } else {
-                    const bool upper = (x.g & 1u) != 0u;
-                    act[0] = __umulhi(upper ? w[2] : w[0], 5u);
-                    act[1] = __umulhi(upper ? w[3] : w[1], 5u);
+                    act[4 * j] = policy_action<0>(pw, five);
+                    act[4 * j + 1] = policy_action<1>(pw, five);
+                    act[4 * j + 2] = policy_action<2>(pw, five);
+                    act[4 * j + 3] = policy_action<3>(pw, five);
                 }
             }
+#pragma unroll
+            for (int k = 0; k < K; ++k) asm volatile("" : "+v"(act[k]));   // (an integer 0..4 from here on: the shift is not folded into the address)
         }
 
         // --- my agents' table rows (cell * 96 + action * 16, the table's LDS offset is an immediate): requested first ...
@@ -477,6 +488,9 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
                 }
             }
         }
+        // ... and the policy stream's call of the NEXT block is made in the block's last step (its words are free by then:
+        // this step's actions were taken from them at the top), so a block's first step finds its actions ready
+        if (!STREAM && !p.policy_cells && (W == 3 || (W < 0 && (t & 3u) == 3u))) refresh_policy((t >> 2) + 1u);
         STAMP(2);   // slip Philox (1 step in 4)
         double q[K];
         uint32_t n[P], word[P], d[K], q_at[K], tie_all = 0u;   // q_at: byte offset of the sampled slot's probability from kSlipAt

@@ -45,12 +45,14 @@ static double slip_uniform(uint64_t seed, uint64_t env_id, uint64_t t, uint32_t 
     return (double)((hi16 << 37) | lo37) / 9007199254740992.0;
 }
 
+/* policy stream (oracle/philox.py random_actions_np): key = seed + 1, one call per agent quad per FOUR steps --
+ * counter (env, t >> 2, quad), word t & 3, byte agent & 3; action = (byte * 5) >> 8 */
 static uint8_t policy_action(uint64_t seed, uint64_t env_id, uint64_t t, uint32_t agent) {
-    uint64_t key = seed + 1;
-    uint32_t c[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)t,
-                     ((uint32_t)(t >> 32) & 0x00FFFFFFu) | ((agent >> 2) << 24)};
+    uint64_t key = seed + 1, m = t >> 2;
+    uint32_t c[4] = {(uint32_t)env_id, (uint32_t)(env_id >> 32), (uint32_t)m,
+                     ((uint32_t)(m >> 32) & 0xFFFFu) | ((agent >> 2) << 16)};
     philox4x32_10(c, (uint32_t)key, (uint32_t)(key >> 32));
-    return (uint8_t)(((uint64_t)c[agent & 3] * 5u) >> 32);
+    return (uint8_t)((((c[t & 3] >> (8u * (agent & 3u))) & 0xFFu) * 5u) >> 8);
 }
 
 /* __init__.py:19-25 POSSIBILITIES, indexed by ACTIONS order STAY,UP,RIGHT,DOWN,LEFT (:26) */

@@ -140,20 +140,36 @@ def slip_uniforms_np(seed, env_ids, t, n_agents):
 
 
 def random_actions_np(seed, env_ids, t, n_agents):
-    """Synthetic policy used by bench/rollout: actions u8[E, A] uniform in 0..4.
+    """Synthetic policy used by bench/rollout: actions u8[E, A] over 0..4.
 
-    Stream: key = seed + 1; ctr = (env_lo, env_hi, t_lo, (t_hi & 0xffffff) |
-    ((agent >> 2) << 24)); word j = agent & 3; action = (word * 5) >> 32.
+    Stream (this build's definition, ABI 5): key = seed + 1; ONE Philox call serves an agent QUAD for FOUR
+    consecutive steps -- m = t >> 2, ctr = (env_lo, env_hi, m_lo, (m_hi & 0xffff) | ((agent >> 2) << 16)); word
+    t & 3 of the call belongs to step t, its byte agent & 3 to the agent: action = (byte * 5) >> 8.  (A byte has 256
+    values: STAY is drawn with probability 52/256, every move with 51/256 -- uniform to within 1/256; a fused rollout
+    pays one policy call per lane per four steps and one multiply + shift per action.  ABI <= 4 spent one call per
+    quad per STEP and a whole 32-bit word per action, which made the in-kernel policy dearer than loading actions.)
     """
     seed = (int(seed) + ACTION_STREAM_KEY_OFFSET) & 0xFFFFFFFFFFFFFFFF
     env_ids = np.asarray(env_ids, dtype=np.uint64).reshape(-1, 1)
-    quads = (np.arange(n_agents, dtype=np.uint64) >> np.uint64(2)).reshape(1, -1)
+    agents = np.arange(n_agents, dtype=np.uint64).reshape(1, -1)
+    quads = agents >> np.uint64(2)
     t = int(t)
+    m = t >> 2
     c0 = env_ids & np.uint64(MASK32)
     c1 = env_ids >> np.uint64(32)
-    c2 = np.uint64(t & MASK32)
-    c3 = np.uint64((t >> 32) & 0x00FFFFFF) | (quads << np.uint64(24))
+    c2 = np.uint64(m & MASK32)
+    c3 = np.uint64((m >> 32) & 0xFFFF) | (quads << np.uint64(16))
     w = philox4x32_10_np(c0, c1, c2, c3, seed & MASK32, (seed >> 32) & MASK32)
-    sel = (np.arange(n_agents) & 3).reshape(1, -1)
-    word = np.choose(sel, w)
-    return ((word * np.uint64(5)) >> np.uint64(32)).astype(np.uint8)
+    word = w[t & 3]
+    byte = (word >> (np.uint64(8) * (agents & np.uint64(3)))) & np.uint64(0xFF)
+    return ((byte * np.uint64(5)) >> np.uint64(8)).astype(np.uint8)
+
+
+def random_action(seed, env_id, t, agent):
+    """Scalar form of ``random_actions_np`` (one action)."""
+    key = (int(seed) + ACTION_STREAM_KEY_OFFSET) & 0xFFFFFFFFFFFFFFFF
+    env_id, t, agent = int(env_id), int(t), int(agent)
+    m = t >> 2
+    w = philox4x32_10((env_id & MASK32, (env_id >> 32) & MASK32, m & MASK32, ((m >> 32) & 0xFFFF) | ((agent >> 2) << 16)),
+                      (key & MASK32, (key >> 32) & MASK32))
+    return (((w[t & 3] >> (8 * (agent & 3))) & 0xFF) * 5) >> 8

@@ -10,11 +10,15 @@ import csv
 import sys
 
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
-for path in sys.argv[1:]:
+paths = sys.argv[1:]
+match = ("rollout_kernel", "step_kernel")
+if paths and paths[0] == "--match":          # --match <substring>: summarise the kernels whose name contains it
+    match, paths = (paths[1],), paths[2:]
+for path in paths:
     with open(path) as f:
         for r in csv.DictReader(f):
             name = r["Kernel_Name"]
-            if "rollout_kernel" in name or "step_kernel" in name:
+            if any(m in name for m in match):
                 key = name.split("(mapf::")[0].replace("void ", "").strip() + "  grid=" + r["Grid_Size"]
                 vals[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for kern, counters in vals.items():
