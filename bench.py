@@ -324,13 +324,17 @@ def spawn_ranks(n, deadline_s, command=None):
     raise SystemExit(rc)
 
 
-def per_gpu_shape_rate(name, n_envs, T=256, n_launch=10, blocks=3, preroll_ms=60.0):
+def per_gpu_shape_rate(name, n_envs, T=256, n_launch=10, blocks=3, preroll_ms=60.0, policy=False):
     """The fused rollout on what ONE GPU runs of a BASELINE configuration that is sharded over eight (configs[3]: 32768 envs
     of 8 agents, configs[4]: 16384 envs of 32 agents) -- the same launch as the headline leg (T env-steps per launch, every
     env-step's outputs recorded to HBM, actions streamed from a two-slot ring), HIP events around `n_launch` launches on the
     handle's stream, median of `blocks` blocks.  A side leg of the default run (world size 1): the per-GPU rates of those
     configurations next to the headline in ONE driver-run line; their parity is the GPU test suite's
-    (test_config4_share_* / test_config5_*)."""
+    (test_config4_share_* / test_config5_*).
+    policy=True: the same launch with actions = NULL -- the in-kernel policy stream (oracle/philox.py random_actions_np: one
+    Philox call per agent quad per four steps) stands in for the caller-side `a = policy(s)`; nothing else changes (the
+    trajectory is still recorded), and the roofline contract is the same 5 + 18/A bytes per agent-step -- the action byte is
+    then produced on the device instead of read from HBM."""
     import ctypes
     import torch
     from gym_mapf_amd import _native as nat
@@ -340,14 +344,14 @@ def per_gpu_shape_rate(name, n_envs, T=256, n_launch=10, blocks=3, preroll_ms=60
     grid, _, nbr, start, goal = workload_tables(cfg, E, 0)
     env = VecMapfEnv(grid, A, None, None, cfg['fail_prob'], R_CLASH, R_GOAL, R_LIVING, OptimizationCriteria.Makespan, seed=SEED,
                      device=torch.cuda.current_device(), device_arrays=True, start_local=start, goal_local=goal)
-    actions = env.fill_random_actions(0, 2 * T)
+    actions = None if policy else env.fill_random_actions(0, 2 * T)
     rec = {'local': env._empty((T, E, A), np.uint16), 'reward': env._empty((T, E), np.float64), 'prob': env._empty((T, E), np.float64),
            'done': env._empty((T, E), np.uint8), 'collision': env._empty((T, E), np.uint8)}
     acc = {'returns': torch.zeros(E, dtype=torch.float64, device='cuda'),
            'episodes': torch.zeros(E, dtype=torch.int32, device='cuda').view(torch.uint32),
            'collisions': torch.zeros(E, dtype=torch.int32, device='cuda').view(torch.uint32)}
     ios = [nat.MapfRolloutIO(struct_size=ctypes.sizeof(nat.MapfRolloutIO), n_steps=T, step_flags=nat.MAPF_STEP_AUTO_RESET, accumulate=1,
-                             actions=actions[slot * T].data_ptr(), out_returns=acc['returns'].data_ptr(),
+                             actions=None if policy else actions[slot * T].data_ptr(), out_returns=acc['returns'].data_ptr(),
                              out_episodes=acc['episodes'].data_ptr(), out_collisions=acc['collisions'].data_ptr(),
                              rec_local=rec['local'].data_ptr(), rec_reward=rec['reward'].data_ptr(), rec_done=rec['done'].data_ptr(),
                              rec_collision=rec['collision'].data_ptr(), rec_prob=rec['prob'].data_ptr()) for slot in range(2)]
@@ -373,12 +377,130 @@ def per_gpu_shape_rate(name, n_envs, T=256, n_launch=10, blocks=3, preroll_ms=60
     env.close()
     launch_bytes = float(T) * E * A * bytes_per_agent_step(A)
     traffic = measured_traffic(kernel, E, A, T)
-    return {"workload": "%s's share of one GPU: %s map, %d agents, slip=%g, %d envs" % (cfg['baseline'], cfg['map'], A, cfg['fail_prob'], E),
+    return {"workload": "%s%s: %s map, %d agents, slip=%g, %d envs%s" % (cfg['baseline'], "" if E == cfg['envs'] else "'s share of one GPU", cfg['map'], A,
+                                                                   cfg['fail_prob'], E, ", actions from the in-kernel policy stream (actions = NULL)" if policy else ""),
             "value": float(T) * E * A / (launch_ms * 1e-3), "unit": "agent-steps/s", "ms_per_launch_hip_events": launch_ms,
             "launches": n_launch, "blocks": blocks, "kernel": kernel,
             "roofline": {"bound": "hbm", "achieved": launch_bytes / (launch_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": launch_bytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch": launch_bytes}}
+
+
+def baseline_config_leg(name, rank, world, dist, coll_dev, device, T=256, n_launch=10, blocks=3, preroll_ms=60.0, check_steps=6):
+    """One of the BASELINE configurations that are DEFINED over several GPUs -- configs[3] (262144 envs of 8 agents) or
+    configs[4] (131072 envs of 32 agents) -- sharded over the ranks of this run: rank r steps
+    its block-aligned shard of the global env ids (sharding.split_evenly, the granule of the packed kernels) with the same
+    fused launch as the headline leg (T env-steps per launch, every env-step's outputs recorded, actions streamed from a
+    two-slot ring); `blocks` timed blocks of `n_launch` launches, each between barrier + synchronize on both sides, MAX over
+    ranks; the per-env returns are gathered (the path's one collective); rank 0's shard is checked against the C oracle
+    first.  Every rank calls this; the dict is meaningful on rank 0."""
+    import ctypes
+    import torch
+    from gym_mapf_amd import _native as nat
+    from gym_mapf_amd import sharding
+    from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv
+    cfg = CONFIGS[name]
+    A = cfg['agents']
+    counts = [sharding.split_evenly(cfg['envs'], r, world, granule=SHARD_GRANULE)[1] for r in range(world)]
+    offset, E = sharding.split_evenly(cfg['envs'], rank, world, granule=SHARD_GRANULE)
+    grid, _, nbr, start, goal = workload_tables(cfg, E, offset)
+    env = VecMapfEnv(grid, A, None, None, cfg['fail_prob'], R_CLASH, R_GOAL, R_LIVING, OptimizationCriteria.Makespan, seed=SEED,
+                     env_id_offset=offset, device=device, device_arrays=True, start_local=start, goal_local=goal)
+    actions = env.fill_random_actions(0, 2 * T)
+    rec = {'local': env._empty((T, E, A), np.uint16), 'reward': env._empty((T, E), np.float64), 'prob': env._empty((T, E), np.float64),
+           'done': env._empty((T, E), np.uint8), 'collision': env._empty((T, E), np.uint8)}
+    acc = {'returns': torch.zeros(E, dtype=torch.float64, device='cuda'),
+           'episodes': torch.zeros(E, dtype=torch.int32, device='cuda').view(torch.uint32),
+           'collisions': torch.zeros(E, dtype=torch.int32, device='cuda').view(torch.uint32)}
+
+    def barrier():
+        torch.cuda.synchronize()
+        env.sync()
+        if dist is not None:
+            dist.barrier()
+
+    parity = None
+    if rank == 0:        # rank 0's shard, every env, the first steps of the fused kernel this leg times
+        sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+        import c_oracle
+        import mapf_oracle as mo
+        co = c_oracle.COracle(nbr, A, start, goal, cfg['fail_prob'], R_CLASH, R_GOAL, R_LIVING, mo.MAKESPAN, seed=SEED, env_id_offset=offset)
+        res = env.rollout(check_steps, actions=actions[:check_steps], auto_reset=True, record=True)
+        env.sync()
+        ok = True
+        for t in range(check_steps):
+            ref = co.step(actions[t].cpu().numpy(), auto_reset=True)
+            ok &= bool(np.array_equal(res['local'][t].cpu().numpy(), ref['local']))
+            ok &= bool(np.array_equal(res['reward'][t].cpu().numpy().view(np.uint64), ref['reward'].view(np.uint64)))
+            ok &= bool(np.array_equal(res['prob'][t].cpu().numpy().view(np.uint64), ref['prob'].view(np.uint64)))
+            ok &= bool(np.array_equal(res['done'][t].cpu().numpy(), ref['done']))
+            ok &= bool(np.array_equal(res['collision'][t].cpu().numpy(), ref['collision']))
+        if not ok:
+            raise SystemExit('PARITY FAILURE (%s shard of rank 0): HIP path differs from the oracle' % name)
+        parity = {"checked_env_steps": check_steps * E, "bit_exact": True, "against": "oracle/mapf_oracle.c",
+                  "covers": "a %d-step fused rollout (recorded trajectory), every env of rank 0's shard" % check_steps}
+        del res
+        env.reset()
+        env.set_state(None, t=0)
+    ios = [nat.MapfRolloutIO(struct_size=ctypes.sizeof(nat.MapfRolloutIO), n_steps=T, step_flags=nat.MAPF_STEP_AUTO_RESET, accumulate=1,
+                             actions=actions[slot * T].data_ptr(), out_returns=acc['returns'].data_ptr(),
+                             out_episodes=acc['episodes'].data_ptr(), out_collisions=acc['collisions'].data_ptr(),
+                             rec_local=rec['local'].data_ptr(), rec_reward=rec['reward'].data_ptr(), rec_done=rec['done'].data_ptr(),
+                             rec_collision=rec['collision'].data_ptr(), rec_prob=rec['prob'].data_ptr()) for slot in range(2)]
+    k = 0
+    barrier()
+    t_end = time.perf_counter() + preroll_ms * 1e-3
+    while time.perf_counter() < t_end:
+        for _ in range(4):
+            nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(ios[k % 2])))
+            k += 1
+        env.sync()
+    timed = []
+    for _ in range(blocks):
+        barrier()
+        env.timer_begin()
+        t0 = time.perf_counter()
+        for _ in range(n_launch):
+            nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(ios[k % 2])))
+            k += 1
+        gpu_ms = env.timer_end()
+        torch.cuda.synchronize()
+        env.sync()
+        wall = time.perf_counter() - t0
+        barrier()
+        if dist is not None:
+            tmax = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            wall = float(tmax.item())
+        timed.append((wall, gpu_ms))
+    order = sorted(range(len(timed)), key=lambda i: timed[i][0])
+    wall, gpu_ms = timed[order[(len(timed) - 1) // 2]]
+    kernel = env.last_kernel('rollout')
+    packed = 1 if kernel.startswith('lq_rollout_kernel') else 0
+    gathered_n = E
+    if dist is not None:
+        env.sync()
+        gathered = sharding.gather_returns(acc['returns'] if coll_dev == 'cuda' else acc['returns'].cpu(), counts=counts)
+        torch.cuda.synchronize()
+        gathered_n = int(gathered.numel())
+        flag = torch.tensor([packed], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        packed = int(flag.item())
+    env.close()
+    del rec, acc, actions
+    torch.cuda.empty_cache()
+    launch_ms = gpu_ms / n_launch
+    launch_bytes = float(T) * E * A * bytes_per_agent_step(A)
+    return {"workload": "%s: %s map, %d agents, slip=%g, %d envs in total over %d GPU(s)" % (cfg['baseline'], cfg['map'], A, cfg['fail_prob'], cfg['envs'], world),
+            "value": float(n_launch) * T * cfg['envs'] * A / wall, "unit": "agent-steps/s", "scaling": "strong",
+            "ms_per_step": wall * 1e3 / n_launch, "steps": n_launch, "blocks": blocks, "env_steps_per_step": T, "envs_total": cfg['envs'],
+            "shards": counts, "kernel": kernel, "packed_kernel_on_every_rank": bool(packed),
+            "gather": {"elements": gathered_n, "collective": None if dist is None else ("all_gather_into_tensor" if coll_dev == 'cuda' else "all_gather")},
+            "roofline": {"bound": "hbm", "of": "rank 0's shard (%d envs), HIP events" % E, "achieved": launch_bytes / (launch_ms * 1e-3) / 1e9,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": launch_bytes / (launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "bytes_per_launch": launch_bytes, "ms_per_launch_hip_events": launch_ms,
+                         "traffic": measured_traffic(kernel, E, A, T)},
+            "parity": parity}
 
 
 def transitions_rate(n_agents, n_queries, reps=10, blocks=3, compact=False, seed=0):
@@ -455,6 +577,10 @@ def main():
     ap.add_argument('--no-scalar-env', action='store_true', help='skip the scalar_env leg (its ~100k one-env launches swamp a profile)')
     ap.add_argument('--no-per-gpu-shapes', action='store_true',
                     help='skip the per_gpu_shapes leg (profiling runs: it launches the headline kernel at another batch size)')
+    ap.add_argument('--no-baseline-configs', action='store_true',
+                    help='multi-rank runs: skip the baseline_configs leg (configs[3] and configs[4] sharded over the ranks)')
+    ap.add_argument('--baseline-config-steps', type=int, default=10, help='launches per timed block of the baseline_configs leg')
+    ap.add_argument('--no-policy-rollout', action='store_true', help='skip the policy_rollout leg (the same batch with actions = NULL)')
     ap.add_argument('--kernel', default='auto', choices=['auto', 'thread_per_env', 'lane_group'])
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' + --share-device rehearses the N > 1 path on a one-GPU box")
@@ -669,6 +795,15 @@ def main():
         gather_info = {"backend": args.dist_backend, "elements": int(gathered.numel()), "shards": counts,
                        "collective": "all_gather_into_tensor" if coll_dev == 'cuda' else "all_gather"}
 
+    # ---- the BASELINE configurations that are defined over several GPUs, sharded over THIS run's ranks (multi-rank runs:
+    # what a driver scaling run must report for configs[3] / configs[4]; the headline above stays configs[2] per GPU)
+    baseline_legs = None
+    if dist is not None and not args.no_baseline_configs and args.config == 'c3':
+        baseline_legs = {}
+        for leg_name, key in (('c4', 'configs[3]'), ('c5', 'configs[4]')):
+            baseline_legs[key] = baseline_config_leg(leg_name, rank, world, dist, coll_dev, local_rank, T=T,
+                                                     n_launch=args.baseline_config_steps)
+
     # ---- second leg: env-steps as single-step mapf_step launches (one kernel launch per env-step)
     single = None
     if not args.no_side_legs:
@@ -750,6 +885,12 @@ def main():
                 line["roofline"][key] = None
         if gather_info is not None:
             line["gather"] = gather_info
+        if baseline_legs is not None:
+            line["baseline_configs"] = baseline_legs
+            if args.share_device and world > 1:
+                for leg in baseline_legs.values():
+                    leg["rehearsal"] = True
+                    leg["roofline"]["traffic"] = None
         if single is not None:
             line["single_step_launches"] = single
         if world == 1 and not args.no_side_legs and not args.no_scalar_env:
@@ -758,6 +899,10 @@ def main():
             # what each GPU runs of the two BASELINE configurations that are sharded over eight
             line["per_gpu_shapes"] = {"c4_share": per_gpu_shape_rate('c4', CONFIGS['c4']['envs'] // 8),
                                       "c5_share": per_gpu_shape_rate('c5', CONFIGS['c5']['envs'] // 8)}
+        if world == 1 and not args.no_side_legs and not args.no_policy_rollout and args.envs is None and args.kernel == 'auto':
+            # the same batch with the policy ON the device: mapf_rollout(actions = NULL), trajectory recorded
+            line["policy_rollout"] = per_gpu_shape_rate(args.config, E, T=T, n_launch=20, blocks=5, policy=True)
+            line["policy_rollout"]["vs_streamed_hip_events"] = line["policy_rollout"]["value"] / line["value_hip_events"]
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         sys.stdout.flush()

@@ -111,7 +111,8 @@ struct mapf_handle_s {
     // host-pointer mode staging
     DeviceBuf s_actions, s_uniforms, s_local, s_reward, s_prob, s_done, s_coll, s_term, s_mask, s_ret, s_epi, s_ncoll;
     DeviceBuf x_local, x_reward, x_prob, x_done, x_coll;   // stand-ins for trajectory arrays the caller left out
-    DeviceBuf q_local, q_actions, q_env, q_count, q_next, q_prob, q_reward, q_done, q_coll, q_next_in;   // mapf_transitions staging
+    DeviceBuf q_local, q_actions, q_env, q_count, q_next, q_prob, q_reward, q_done, q_coll, q_next_in, q_offset;   // mapf_transitions staging
+    DeviceBuf q_rel, q_blocks;        // mapf_transitions_compact: the scan's scratch (in-block offsets, block bases)
     PinnedBlock pinned;               // zero-copy staging of tiny host-mode steps
     // scenario table (StepArgs::scen): built at create when the batch has <= 256 distinct (start row, goal row) pairs
     uint8_t *scen = nullptr;
@@ -289,7 +290,7 @@ void destroy_impl(mapf_handle_t h) {
     for (DeviceBuf *b : {&h->s_actions, &h->s_uniforms, &h->s_local, &h->s_reward, &h->s_prob, &h->s_done,
                          &h->s_coll, &h->s_term, &h->s_mask, &h->s_ret, &h->s_epi, &h->s_ncoll, &h->x_local, &h->x_reward,
                          &h->x_prob, &h->x_done, &h->x_coll, &h->q_local, &h->q_actions, &h->q_env, &h->q_count, &h->q_next,
-                         &h->q_prob, &h->q_reward, &h->q_done, &h->q_coll, &h->q_next_in})
+                         &h->q_prob, &h->q_reward, &h->q_done, &h->q_coll, &h->q_next_in, &h->q_offset, &h->q_rel, &h->q_blocks})
         b->release();
     h->pinned.release();
     if (h->scen) (void)hipFree(h->scen);
@@ -314,7 +315,9 @@ extern "C" {
 
 const char *mapf_last_error(void) { return g_last_error.c_str(); }
 
-const char *mapf_version(void) { return "mapf_hip 0.4.0 (abi 4, gfx950)"; }
+const char *mapf_version(void) { return "mapf_hip 0.5.0 (abi 5, gfx950)"; }
+
+int mapf_abi_version(void) { return MAPF_ABI_VERSION; }
 
 int mapf_device_count(int *out_count) {
     if (!out_count) return fail(MAPF_EINVAL, "out_count is null");
@@ -833,6 +836,7 @@ int mapf_transitions_window(mapf_handle_t h, uint64_t n_queries, const uint16_t 
     mapf::TransitionsArgs a{};
     a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.goal = h->goal; a.goal_broadcast = h->goal_broadcast;
     a.n_queries = n_queries; a.max_branches = max_branches; a.n_agents = h->A; a.first_branch = first_branch;
+    a.capacity = ~uint64_t(0);
     if (int rc = stage_in(h, h->q_local, local, NA, &a.local, "local")) return rc;
     if (int rc = stage_in(h, h->q_actions, actions, NA, &a.actions, "actions")) return rc;
     if (int rc = stage_in(h, h->q_env, env_index, N, &a.env_index, "env_index")) return rc;
@@ -861,6 +865,60 @@ int mapf_transitions(mapf_handle_t h, uint64_t n_queries, const uint16_t *local,
                                    out_reward, out_done, out_collision);
 }
 
+int mapf_transitions_compact(mapf_handle_t h, uint64_t n_queries, const uint16_t *local, const uint8_t *actions,
+                             const uint32_t *env_index, uint64_t first_branch, uint32_t max_branches, uint64_t capacity_rows,
+                             uint64_t *out_offset, uint32_t *out_count, uint16_t *out_next, double *out_prob, double *out_reward,
+                             uint8_t *out_done, uint8_t *out_collision) {
+    if (int rc = check_handle(h)) return rc;
+    if (!local || !actions) return fail(MAPF_EINVAL, "local / actions are null");
+    if (!out_offset) return fail(MAPF_EINVAL, "transitions_compact: out_offset (u64[n_queries + 1]) is required");
+    if (max_branches == 0) return fail(MAPF_EINVAL, "max_branches must be >= 1");
+    if (h->A > uint32_t(mapf::kTransitionsMaxAgents)) return fail(MAPF_EUNSUPPORTED, "mapf_transitions supports n_agents <= 16 (3^A branches per query)");
+    const size_t N = size_t(n_queries), NA = N * h->A, R = size_t(capacity_rows);
+    if (!h->device_ptrs) {
+        for (size_t i = 0; i < NA; ++i) if (local[i] >= h->V) return fail(MAPF_EINVAL, "transitions: cell out of range");
+        if (env_index) for (size_t i = 0; i < N; ++i) if (env_index[i] >= h->E) return fail(MAPF_EINVAL, "transitions: env_index out of range");
+    }
+    mapf::TransitionsArgs a{};
+    a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.goal = h->goal; a.goal_broadcast = h->goal_broadcast;
+    a.n_queries = n_queries; a.max_branches = max_branches; a.n_agents = h->A; a.first_branch = first_branch;
+    a.capacity = capacity_rows;
+    if (int rc = stage_in(h, h->q_local, local, NA, &a.local, "local")) return rc;
+    if (int rc = stage_in(h, h->q_actions, actions, NA, &a.actions, "actions")) return rc;
+    if (int rc = stage_in(h, h->q_env, env_index, N, &a.env_index, "env_index")) return rc;
+    if (int rc = stage_out(h, h->q_offset, out_offset, N + 1, &a.out_offset, "out_offset")) return rc;
+    if (int rc = stage_out(h, h->q_count, out_count, N, &a.out_count, "out_count")) return rc;
+    if (int rc = stage_out(h, h->q_next, out_next, R * h->A, &a.out_next, "out_next")) return rc;
+    if (int rc = stage_out(h, h->q_prob, out_prob, R, &a.out_prob, "out_prob")) return rc;
+    if (int rc = stage_out(h, h->q_reward, out_reward, R, &a.out_reward, "out_reward")) return rc;
+    if (int rc = stage_out(h, h->q_done, out_done, R, &a.out_done, "out_done")) return rc;
+    if (int rc = stage_out(h, h->q_coll, out_collision, R, &a.out_collision, "out_collision")) return rc;
+    // the scan's scratch (handle-owned; a growing buffer is reallocated behind hipFree's implicit device synchronisation)
+    HIP_TRY(h->q_rel.reserve((N ? N : 1) * sizeof(uint32_t)));
+    HIP_TRY(h->q_blocks.reserve((mapf::transitions_scan_blocks(n_queries) + 1) * sizeof(uint64_t)));
+    uint32_t *rel = static_cast<uint32_t *>(h->q_rel.ptr);
+    uint64_t *blocks = static_cast<uint64_t *>(h->q_blocks.ptr);
+    if (N == 0) HIP_TRY(hipMemsetAsync(a.out_offset, 0, sizeof(uint64_t), h->stream));
+    HIP_TRY(mapf::launch_transitions_offsets(a, rel, blocks, a.out_offset + N, h->stream));
+    a.rel = rel; a.block_base = blocks;
+    HIP_TRY(mapf::launch_transitions(a, h->stream));
+    if (h->last_transitions_kernel != g_noted_kernel) h->last_transitions_kernel = g_noted_kernel;
+    if (!h->device_ptrs) {
+        // host arrays: the offsets first -- only the rows that exist (and fit) are copied back
+        HIP_TRY(hipMemcpyAsync(out_offset, a.out_offset, (N + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        const size_t rows = size_t(std::min<uint64_t>(out_offset[N], capacity_rows));
+        if (int rc = fetch_out(h, a.out_count, out_count, N)) return rc;
+        if (int rc = fetch_out(h, a.out_next, out_next, rows * h->A)) return rc;
+        if (int rc = fetch_out(h, a.out_prob, out_prob, rows)) return rc;
+        if (int rc = fetch_out(h, a.out_reward, out_reward, rows)) return rc;
+        if (int rc = fetch_out(h, a.out_done, out_done, rows)) return rc;
+        if (int rc = fetch_out(h, a.out_collision, out_collision, rows)) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return MAPF_OK;
+}
+
 int mapf_transition_rewards(mapf_handle_t h, uint64_t n_queries, const uint16_t *prev_local, const uint8_t *actions,
                             const uint16_t *next_local, const uint32_t *env_index, double *out_reward, uint8_t *out_done,
                             uint8_t *out_collision) {
@@ -874,7 +932,7 @@ int mapf_transition_rewards(mapf_handle_t h, uint64_t n_queries, const uint16_t 
     }
     mapf::TransitionsArgs a{};
     a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.goal = h->goal; a.goal_broadcast = h->goal_broadcast;
-    a.n_queries = n_queries; a.max_branches = 1; a.n_agents = h->A;
+    a.n_queries = n_queries; a.max_branches = 1; a.n_agents = h->A; a.capacity = ~uint64_t(0);
     const uint16_t *d_next = nullptr;
     if (int rc = stage_in(h, h->q_local, prev_local, NA, &a.local, "prev_local")) return rc;
     if (int rc = stage_in(h, h->q_actions, actions, NA, &a.actions, "actions")) return rc;

@@ -156,9 +156,21 @@ struct TransitionsArgs {
     uint64_t first_branch;         // first branch of the returned window (0 = from the start)
     uint32_t max_branches, n_agents;
     bool goal_broadcast;
+    // Compacted output (mapf_transitions_compact): the window rows of query q start at row block_base[q / 256] + rel[q] of
+    // every output array -- an exclusive scan of the windows' lengths, made by launch_transitions_offsets -- and
+    // out_offset[q] receives that row.  rel == null: reserved rows (row j of query q's window at q * max_branches + j).
+    // Rows at or beyond `capacity` are not written.
+    const uint32_t *rel;
+    const uint64_t *block_base;
+    uint64_t *out_offset;
+    uint64_t capacity;
 };
 constexpr int kTransitionsMaxAgents = 16;   // 3^16 = 43 M branches per query, returned in windows
 hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream);
+// passes 1 and 2 of the compacted form: rel u32[N], block_base u64[transitions_scan_blocks(N)], *out_total = rows in total
+// (also fills args.out_count)
+uint64_t transitions_scan_blocks(uint64_t n_queries);
+hipError_t launch_transitions_offsets(const TransitionsArgs &args, uint32_t *rel, uint64_t *block_base, uint64_t *out_total, hipStream_t stream);
 // calc_transition_reward_from_local_states for N (prev = args.local, args.actions, next) triples; fills
 // args.out_reward / out_done / out_collision [N] (max_branches, out_count, out_next, out_prob unused)
 hipError_t launch_transition_rewards(const TransitionsArgs &args, const uint16_t *next, hipStream_t stream);

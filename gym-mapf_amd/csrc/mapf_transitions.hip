@@ -1,22 +1,315 @@
 // env.P[s][a] on the device: every branch of the joint slip distribution of a (state, joint action) query
 // (reference mapf_env.py:448-478 `_get_transitions`, the enumeration planners iterate over).
 //
-// One thread per (query, branch).  Branch b of a query selects entry k_i of agent i's merged movement list
-// (single_agent_movements, :163-184) in itertools.product order -- agent 0 varies slowest -- so
-// k_i = digit i of b in the mixed radix (n_0, ..., n_{A-1}).  prob is the left-to-right float64 product of the
-// selected probabilities (functools.reduce at :467); reward / done / collision come from the same rules as
-// step() (:225-235).  A terminal state has the single branch ((1.0, False), s, 0, True) (:455-456).
-// A call returns the WINDOW [first_branch, first_branch + max_branches) of every query's enumeration, so a caller
-// pages through the 3^A branches of a large team in pieces (A <= 16: at most 43 M branches per query).
+// Branch b of a query selects entry k_i of agent i's merged movement list (single_agent_movements, :163-184) in
+// itertools.product order -- agent 0 varies slowest -- so k_i = digit i of b in the mixed radix (n_0, ..., n_{A-1}).
+// prob is the left-to-right float64 product of the selected probabilities (functools.reduce at :467); reward / done /
+// collision come from the same rules as step() (:225-235).  A terminal state has the single branch
+// ((1.0, False), s, 0, True) (:455-456).  A call returns the WINDOW [first_branch, first_branch + max_branches) of every
+// query's enumeration, so a caller pages through the 3^A branches of a large team in pieces.
+//
+// Two output layouts: RESERVED rows (row j of query q's window at q * max_branches + j: mapf_transitions /
+// mapf_transitions_window) and COMPACTED rows (the windows of all queries back to back behind an exclusive scan of their
+// lengths: mapf_transitions_compact -- a room map uses a fifth of the 3^A rows a query reserves).
+//
+// Two kernels:
+//   * transitions_rows_kernel<MAXA> (A <= 8, i.e. everything planners enumerate in practice).  The kernel is bound by its
+//     vector instructions, not by the bytes it writes (profiles/r05_transitions_*), so it is built around the per-ROW
+//     instruction count.  A wave owns QW consecutive queries.  SET-UP is one LANE per query: cells, goals, actions, table
+//     rows, list lengths, is_terminal(prev), the SoC living reward -- and, per (agent, list entry), a 16-byte LDS record
+//     {cell | off-goal bit, CONFLICT MASK, probability}: bit 3j + k_j of the mask of (i, k_i) says that entry k_i of agent
+//     i collides (vertex or swap, :378-389) with entry k_j of a LATER agent j.  EMISSION is one lane per output ROW of the
+//     wave's queries taken together (a binary search over the wave's prefix sums names the row's query): per agent one
+//     digit, one ds_read_b128 of its record, `hit |= mask & chosen; chosen |= 1 << (3i + k)` -- the O(A^2) pair tests of
+//     a row become O(A) and the off-goal test one OR per agent.  Consecutive lanes write consecutive rows.
+//     (The form this replaces -- 64 lanes per query each repeating the query's set-up, 28 pair tests x 6 instructions per
+//     row -- measured 330 vector instructions per 64 rows at 8 agents and one wave per ~35 rows at 4 agents.)
+//   * transitions_kernel<A, EXACT> for 9..16 agents (48-bit choice sets do not fit the records): a group of 64 lanes owns a
+//     chunk of one query's window, query set-up per lane, all agent pairs per row.
 #include <algorithm>
 #include "mapf_kernels.hpp"
 #include "mapf_device.hpp"
 
 namespace mapf {
 
+namespace {
+
+// rows of a query's window: branches [first, first + max) of `count`
+__device__ __forceinline__ uint32_t window_rows(uint32_t count, uint64_t first, uint32_t max_branches, uint32_t &lo) {
+    lo = first < count ? uint32_t(first) : count;
+    const uint64_t end = first + max_branches;
+    const uint32_t hi = end < count ? uint32_t(end) : count;
+    return hi - lo;
+}
+
+// number of branches of query q (product of the agents' list lengths; 1 for a terminal state), run-time A
+__device__ uint32_t query_branch_count(const TransitionsArgs &p, const SlipRow *slip, uint64_t q) {
+    const uint32_t A = p.n_agents;
+    const uint64_t env = p.env_index ? p.env_index[q] : 0;
+    const uint16_t *goal_row = p.goal + (p.goal_broadcast ? 0 : env * A);
+    const uint16_t *state_row = p.local + q * A;
+    const uint8_t *act_row = p.actions + q * A;
+    uint32_t count = 1u, off_goal = 0u;
+    bool dup = false;
+    for (uint32_t i = 0; i < A; ++i) {
+        const uint32_t cell = state_row[i], a = act_row[i];
+        const MoveEntry entry = move_entry(p.mv, p.c.n_cells, cell, a > 4u ? 0u : a);
+        count *= slip[entry_code(entry)].n;
+        off_goal |= cell ^ goal_row[i];
+        for (uint32_t j = i + 1; j < A; ++j) dup |= cell == state_row[j];
+    }
+    return (dup || off_goal == 0u) ? 1u : count;                 // is_terminal: mapf_env.py:210-223
+}
+
+// inclusive scan over the wave's lanes (every lane active)
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t up = uint32_t(__shfl_up(int(v), int(d), 64));
+        v += lane >= d ? up : 0u;
+    }
+    return v;
+}
+
+}  // namespace
+
+// ---- compacted output, pass 1: every query's window length; exclusive scan inside blocks of 256 queries (rel[q]) and the
+// blocks' totals.  Pass 2 (one block) scans the totals into block_base[] and writes the grand total.
+constexpr uint32_t kScanBlock = 256;
+__global__ void __launch_bounds__(kScanBlock) transitions_count_kernel(const TransitionsArgs p, uint32_t *rel, uint64_t *block_total) {
+    __shared__ SlipRow slip[8];
+    __shared__ uint32_t wave_total[kScanBlock / 64];
+    stage_slip_table(p.slip, slip);
+    const uint64_t q = uint64_t(blockIdx.x) * kScanBlock + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t rows = 0u;
+    if (q < p.n_queries) {
+        const uint32_t count = query_branch_count(p, slip, q);
+        uint32_t lo;
+        rows = window_rows(count, p.first_branch, p.max_branches, lo);
+        if (p.out_count) p.out_count[q] = count;
+    }
+    const uint32_t incl = wave_inclusive_scan(rows, lane);
+    if (lane == 63u) wave_total[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0u, total = 0u;
+#pragma unroll
+    for (uint32_t w = 0; w < kScanBlock / 64; ++w) {
+        before += w < wave ? wave_total[w] : 0u;
+        total += wave_total[w];
+    }
+    if (q < p.n_queries) rel[q] = before + incl - rows;
+    if (threadIdx.x == 0u) block_total[blockIdx.x] = total;
+}
+
+// pass 2: block_total[0 .. n) -> exclusive prefix in place (64-bit), grand total to *out_total and out_offset_last
+__global__ void __launch_bounds__(1024) scan_block_totals_kernel(uint64_t *block_total, uint32_t n, uint64_t *out_total) {
+    __shared__ uint64_t wave_sum[16];
+    __shared__ uint64_t carry_s;
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0u) carry_s = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n; base += 1024u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t v = i < n ? block_total[i] : 0;
+        uint64_t incl = v;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) {
+            const uint32_t lo = uint32_t(__shfl_up(int(uint32_t(incl)), int(d), 64)), hi = uint32_t(__shfl_up(int(uint32_t(incl >> 32)), int(d), 64));
+            incl += lane >= d ? (uint64_t(hi) << 32 | lo) : 0;
+        }
+        if (lane == 63u) wave_sum[wave] = incl;
+        __syncthreads();
+        uint64_t before = carry_s, all = 0;
+        for (uint32_t w = 0; w < 16u; ++w) {
+            before += w < wave ? wave_sum[w] : 0;
+            all += wave_sum[w];
+        }
+        if (i < n) block_total[i] = before + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 0u) carry_s += all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0u && out_total) *out_total = carry_s;
+}
+
+// ---------------------------------------------------------------------------------------------------- A <= 8
+namespace {
+
+constexpr uint32_t kQueryHeader = 32, kRecord = 16;
+struct QueryHeader {
+    uint32_t radix;        // 2 bits per agent: its list length (1 for absent agents and for every agent of a terminal state)
+    uint32_t first;        // first branch of the window (<= count)
+    uint32_t terminal;     // 1: the single branch ((1.0, False), s, 0, True) of a terminal state
+    uint32_t pad;
+    double living;         // _living_reward of the query (mapf_env.py:436-446)
+    uint64_t pad2;
+};
+static_assert(sizeof(QueryHeader) == kQueryHeader, "one ds_read_b128 + one ds_read_b64");
+
+template <int MAXA>
+__global__ void __launch_bounds__(256) transitions_rows_kernel(const TransitionsArgs p, const uint32_t qw_log2) {
+    static_assert(MAXA <= 10, "a choice set is 3 bits per agent in one 32-bit word");
+    __shared__ SlipRow slip[8];
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
+    stage_slip_table(p.slip, slip);                                // ends with __syncthreads(): the only block-wide one
+    constexpr uint32_t kQueryBytes = kQueryHeader + uint32_t(MAXA) * 3u * kRecord;
+    const uint32_t QW = 1u << qw_log2;                             // queries per wave (>= 4: the prefix array stays 16-byte aligned)
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned char *const wave_lds = lds_dyn + (threadIdx.x >> 6) * (QW * (kQueryBytes + 4u));
+    uint32_t *const prefix = reinterpret_cast<uint32_t *>(wave_lds);                     // [QW] exclusive prefix of the windows' lengths
+    unsigned char *const queries = wave_lds + QW * 4u;                                     // [QW] header + records
+    const uint64_t q0 = ((uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6) << qw_log2;
+    if (q0 >= p.n_queries) return;                                 // (wave-uniform)
+    const uint32_t A = p.n_agents;
+
+    // ---- set-up: lane l < QW owns query q0 + l
+    uint32_t rows = 0u;
+    if (lane < QW) {
+        const uint64_t q = q0 + lane;
+        unsigned char *const mine = queries + lane * kQueryBytes;
+        QueryHeader hdr{};
+        if (q < p.n_queries) {
+            const uint64_t env = p.env_index ? p.env_index[q] : 0;
+            const uint16_t *goal_row = p.goal + (p.goal_broadcast ? 0 : env * A);
+            const uint16_t *state_row = p.local + q * A;
+            const uint8_t *act_row = p.actions + q * A;
+            uint32_t prev[MAXA], goal[MAXA], n[MAXA], cell[MAXA][3];
+            double prob[MAXA][3];
+            uint32_t count = 1u, dup_acc = 0xFFFFFFFFu, goal_acc = 0u;
+            int stayed = 0;
+#pragma unroll
+            for (int i = 0; i < MAXA; ++i) {
+                const bool on = uint32_t(i) < A;
+                prev[i] = on ? state_row[i] : 0x10000u + uint32_t(i);   // absent agents: unique cells, never equal to a real one
+                goal[i] = on ? goal_row[i] : prev[i];
+                const uint32_t a = on ? act_row[i] : 0u, act = a > 4u ? 0u : a;
+                const MoveEntry entry = on ? move_entry(p.mv, p.c.n_cells, prev[i], act) : MoveEntry{0u, 0u, 0u, 7u * uint32_t(sizeof(SlipRow))};
+                const SlipRow &row = slip[on ? entry_code(entry) : 7u];
+                n[i] = on ? row.n : 1u;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    cell[i][k] = on ? entry_cell(entry, uint32_t(k)) : prev[i];
+                    prob[i][k] = on ? row.q[k] : 1.0;               // (x * 1.0 is exact: absent agents leave the product alone)
+                }
+                count *= n[i];
+                goal_acc |= prev[i] ^ goal[i];
+                stayed += (on && prev[i] == goal[i] && act == 0u) ? 1 : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < MAXA; ++i)
+#pragma unroll
+                for (int j = i + 1; j < MAXA; ++j) dup_acc = min(dup_acc, prev[i] ^ prev[j]);
+            const bool terminal = dup_acc == 0u || goal_acc == 0u;     // is_terminal: mapf_env.py:210-223
+            if (terminal) count = 1u;
+            if (p.out_count) p.out_count[q] = count;
+            uint32_t lo;
+            rows = window_rows(count, p.first_branch, p.max_branches, lo);
+            hdr.first = lo;
+            hdr.terminal = terminal ? 1u : 0u;
+            hdr.living = p.c.criteria == 1u ? __dmul_rn(double(int(A) - stayed), p.c.r_living) : p.c.r_living;
+#pragma unroll
+            for (int i = 0; i < MAXA; ++i) {
+                hdr.radix |= (terminal ? 1u : n[i]) << (2 * i);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    // entry k of agent i against every entry of every later agent: vertex (same next cell) or swap (each moves
+                    // onto the other's current cell) -- _is_collision_transition_from_local_states, mapf_env.py:378-389
+                    uint32_t mask = 0u;
+#pragma unroll
+                    for (int j = i + 1; j < MAXA; ++j)
+#pragma unroll
+                        for (int kj = 0; kj < 3; ++kj) {
+                            const bool hit = cell[i][k] == cell[j][kj] || (prev[i] == cell[j][kj] && prev[j] == cell[i][k]);
+                            mask |= (hit && uint32_t(kj) < n[j]) ? 1u << (3 * j + kj) : 0u;
+                        }
+                    const uint32_t c = terminal ? prev[i] : cell[i][k];
+                    const double pr = terminal ? 1.0 : prob[i][k];
+                    *reinterpret_cast<uint4 *>(mine + kQueryHeader + (3 * i + k) * kRecord) =
+                        make_uint4((c & 0xFFFFu) | (c != goal[i] ? 0x10000u : 0u), terminal ? 0u : mask, uint32_t(__double2loint(pr)), uint32_t(__double2hiint(pr)));
+                }
+            }
+        }
+        *reinterpret_cast<QueryHeader *>(mine) = hdr;
+    }
+    const uint32_t incl = wave_inclusive_scan(rows, lane);
+    if (lane < QW) prefix[lane] = incl - rows;
+    const uint32_t total = uint32_t(__shfl(int(incl), 63, 64));
+    // compacted rows: the wave's queries are consecutive, so their rows are one contiguous range from the first one's offset
+    const bool compact = p.rel != nullptr;
+    uint64_t base = 0;
+    if (compact) {
+        base = p.block_base[q0 / kScanBlock] + p.rel[q0];
+        if (p.out_offset && lane < QW && q0 + lane < p.n_queries) p.out_offset[q0 + lane] = base + (incl - rows);
+    }
+    // (the wave's lanes wrote the records / prefix sums the others read below: same wave, LDS operations execute in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- emission: one lane per row of the wave's windows
+    const double r_clash = p.c.r_clash, r_goal = p.c.r_goal;
+    for (uint32_t r0 = 0; r0 < total; r0 += 64u) {
+        const uint32_t r = r0 + lane;
+        const bool valid = r < total;
+        uint32_t pos = 0u;                                         // the row's query: the last one whose prefix is <= r
+        for (uint32_t step = QW >> 1; step != 0u; step >>= 1) {
+            const uint32_t cand = pos + step;
+            pos = prefix[cand] <= r ? cand : pos;
+        }
+        const unsigned char *const qbase = queries + pos * kQueryBytes;
+        const uint4 h = *reinterpret_cast<const uint4 *>(qbase);   // {radix, first, terminal, -}
+        const double living = *reinterpret_cast<const double *>(qbase + 16);
+        const uint32_t j = r - prefix[pos];                        // row of the query's window
+        uint32_t rest = j + h.y;                                   // branch index: digits in the mixed radix, last agent fastest
+        uint32_t chosen = 0u, hit = 0u, flags = 0u, cells[MAXA];
+        double qv[MAXA];
+#pragma unroll
+        for (int i = MAXA - 1; i >= 0; --i) {
+            const uint32_t n = (h.x >> (2 * i)) & 3u;
+            const uint32_t third = __umulhi(rest, 0xAAAAAAABu) >> 1;
+            const uint32_t quot = n == 3u ? third : (n == 2u ? rest >> 1 : rest);
+            const uint32_t idx = 3u * uint32_t(i) + (rest - quot * n);
+            rest = quot;
+            const uint4 rec = *reinterpret_cast<const uint4 *>(qbase + kQueryHeader + idx * kRecord);
+            hit |= rec.y & chosen;                                 // my entry against the entries the later agents chose
+            chosen |= 1u << idx;
+            flags |= rec.x;                                        // bit 16: off its goal
+            cells[i] = rec.x & 0xFFFFu;
+            qv[i] = __hiloint2double(int(rec.w), int(rec.z));
+        }
+        double prob = qv[0];                                       // left to right: functools.reduce at mapf_env.py:467
+#pragma unroll
+        for (int i = 1; i < MAXA; ++i) prob = __dmul_rn(prob, qv[i]);
+        const bool terminal = h.z != 0u, coll = hit != 0u, goal_next = (flags & 0x10000u) == 0u;
+        const double reward = terminal ? 0.0 : (coll ? __dadd_rn(r_clash, living) : (goal_next ? __dadd_rn(r_goal, living) : living));
+        const uint64_t o = compact ? base + r : (q0 + pos) * uint64_t(p.max_branches) + j;
+        if (valid && o < p.capacity) {
+            if (p.out_next) {
+                uint16_t *dst = p.out_next + o * A;
+                if (A == uint32_t(MAXA)) {                          // a full team: one store per row (rows are 2 MAXA bytes apart)
+                    if constexpr (MAXA == 8) *reinterpret_cast<uint4 *>(dst) = make_uint4(cells[0] | cells[1] << 16, cells[2] | cells[3] << 16, cells[4] | cells[5] << 16, cells[6] | cells[7] << 16);
+                    else if constexpr (MAXA == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(cells[0] | cells[1] << 16, cells[2] | cells[3] << 16);
+                    else {
+#pragma unroll
+                        for (int i = 0; i + 1 < MAXA; i += 2) reinterpret_cast<uint32_t *>(dst)[i / 2] = cells[i] | cells[i + 1] << 16;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < MAXA; ++i)
+                        if (uint32_t(i) < A) dst[i] = uint16_t(cells[i]);
+                }
+            }
+            if (p.out_prob) p.out_prob[o] = prob;
+            if (p.out_reward) p.out_reward[o] = reward;
+            if (p.out_done) p.out_done[o] = (terminal || coll || goal_next) ? 1 : 0;
+            if (p.out_collision) p.out_collision[o] = (coll && !terminal) ? 1 : 0;
+        }
+    }
+}
+
 // one branch's next cells, out[row * A .. row * A + A): the widest stores the row's alignment allows when the team
-// fills the instance (rows of a full even team are 4-byte aligned, of a multiple of four 8-byte aligned, given an
-// equally aligned array), two bytes at a time otherwise
+// fills the instance, two bytes at a time otherwise
 template <int MAXA>
 __device__ __forceinline__ void store_branch_cells(uint16_t *out, uint64_t row, uint32_t A, const uint32_t (&cells)[MAXA]) {
     uint16_t *dst = out + row * A;
@@ -35,15 +328,15 @@ __device__ __forceinline__ void store_branch_cells(uint16_t *out, uint64_t row, 
     }
 }
 
-// EXACT: the team has exactly MAXA agents (no ghost slots, no per-slot predicates: the 9..16-agent instances would
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------- 9..16 agents
+// EXACT: the team has exactly MAXA agents (no absent slots, no per-slot predicates: the 9..16-agent instances would
 // otherwise keep sixteen wave masks alive and spill scalar registers).
 //
 // Work split: a GROUP of `lanes` (a power of two <= 64) consecutive lanes owns one chunk of `chunk` window rows of one
-// query and walks it `lanes` rows at a time.  Everything that depends on the query only -- cells, goals, actions, the
-// agents' table rows, list lengths, is_terminal(prev), the SoC living reward -- is set up ONCE per lane and reused for
-// every branch the lane emits; lanes whose rows lie beyond the query's branch count leave after that set-up.  (One
-// thread per reserved row, the first form of this kernel, spent most of its time setting up threads whose row did not
-// exist: a query reserves 3^A rows and uses a third of them on a room map.)  A group's lanes write consecutive rows.
+// query and walks it `lanes` rows at a time.  Everything that depends on the query only is set up ONCE per lane and reused
+// for every branch the lane emits; lanes whose rows lie beyond the query's branch count leave after that set-up.
 template <int MAXA, bool EXACT = false>
 __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs p, const uint32_t lanes_log2, const uint32_t chunk,
                                                           const uint32_t chunks_per_query) {
@@ -92,9 +385,14 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
 
     const uint32_t piece_begin = piece * chunk;                  // (piece < chunks_per_query, so this stays below max_branches)
     const uint32_t piece_end = chunk < p.max_branches - piece_begin ? piece_begin + chunk : p.max_branches;
-    const uint64_t row0 = q * p.max_branches;
+    // the query's first output row: reserved rows, or its offset in the compacted arrays
+    uint64_t row0 = q * p.max_branches;
+    if (p.rel) {
+        row0 = p.block_base[q / kScanBlock] + p.rel[q];
+        if (piece == 0u && lane == 0u && p.out_offset) p.out_offset[q] = row0;
+    }
     if (terminal) {                                              // the single branch ((1.0, False), s, 0, True)
-        if (piece == 0u && lane == 0u && p.first_branch == 0u) {
+        if (piece == 0u && lane == 0u && p.first_branch == 0u && row0 < p.capacity) {
             if (p.out_next) store_branch_cells<MAXA>(p.out_next, row0, A, prev);
             if (p.out_prob) p.out_prob[row0] = 1.0;
             if (p.out_reward) p.out_reward[row0] = 0.0;
@@ -111,8 +409,7 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
         const uint64_t b = p.first_branch + slot;                // branch index in the query's full enumeration
         if (b >= count) break;
         // digits of b, last agent fastest.  b < count <= 3^16 fits 32 bits and every radix is 1, 2 or 3: the quotient is a
-        // select between rest, rest >> 1 and a multiply-high by the reciprocal of 3 (a 64-bit divide per agent costs
-        // more than the rest of the branch together)
+        // select between rest, rest >> 1 and a multiply-high by the reciprocal of 3
         uint32_t next[MAXA];
         uint32_t rest = uint32_t(b);
         double qv[MAXA];
@@ -137,14 +434,15 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
 #pragma unroll
             for (int j = i + 1; j < MAXA; ++j) {
                 // vertex: next_i == next_j; swap: prev_i == next_j and prev_j == next_i.  Integer min-of-xor accumulators
-                // (no wave-mask booleans: those cost an SGPR pair per pair test); ghost cells are >= 0x10000 and unique,
-                // so they never produce a zero.
+                // (no wave-mask booleans); ghost cells are >= 0x10000 and unique, so they never produce a zero.
                 const uint32_t swap = (prev[i] ^ next[j]) | (prev[j] ^ next[i]);
                 coll_acc = min(coll_acc, min(next[i] ^ next[j], swap));
             }
         }
         const bool coll = coll_acc == 0u, goal_next = goal_next_acc == 0u;
+        // compacted rows hold the window's rows only: row `slot` of the window is its slot-th row there too
         const uint64_t o = row0 + slot;
+        if (o >= p.capacity) break;
         if (p.out_next) store_branch_cells<MAXA>(p.out_next, o, A, next);
         if (p.out_prob) p.out_prob[o] = prob;
         if (p.out_reward) p.out_reward[o] = coll ? r_coll : (goal_next ? r_goal : living);
@@ -192,10 +490,43 @@ hipError_t launch_transition_rewards(const TransitionsArgs &args, const uint16_t
     return hipGetLastError();
 }
 
+uint64_t transitions_scan_blocks(uint64_t n_queries) { return (n_queries + kScanBlock - 1) / kScanBlock; }
+
+// compacted output, passes 1 and 2: rel[q] / block_base[] (see TransitionsArgs) and the total number of rows
+hipError_t launch_transitions_offsets(const TransitionsArgs &args, uint32_t *rel, uint64_t *block_base, uint64_t *out_total, hipStream_t stream) {
+    const uint64_t blocks = transitions_scan_blocks(args.n_queries);
+    if (blocks == 0 || blocks > 0x7FFFFFFFull) return blocks == 0 ? hipSuccess : hipErrorInvalidValue;
+    hipLaunchKernelGGL(transitions_count_kernel, dim3(unsigned(blocks)), dim3(kScanBlock), 0, stream, args, rel, block_base);
+    hipLaunchKernelGGL(scan_block_totals_kernel, dim3(1), dim3(1024), 0, stream, block_base, uint32_t(blocks), out_total);
+    return hipGetLastError();
+}
+
+template <int MAXA>
+static hipError_t launch_rows(const TransitionsArgs &args, hipStream_t stream) {
+    constexpr uint32_t kQueryBytes = kQueryHeader + uint32_t(MAXA) * 3u * kRecord;
+    // queries per wave: as many as keep a block's LDS near 32 KB (five or more blocks per CU), fewer while that leaves the
+    // device short of waves (16 per SIMD queued) -- set-up uses one lane per query, so small teams want many per wave
+    uint32_t qw_log2 = 6;
+    while (qw_log2 > 2 && 4u * (kQueryBytes + 4u) * (1u << qw_log2) > 36u * 1024u) --qw_log2;
+    while (qw_log2 > 2 && (args.n_queries >> qw_log2) < 16384u) --qw_log2;
+    const uint64_t waves = (args.n_queries + (1u << qw_log2) - 1) >> qw_log2;
+    const uint64_t grid64 = (waves + 3) / 4;
+    if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    const size_t lds = 4u * size_t(kQueryBytes + 4u) * (size_t(1) << qw_log2);
+    note_kernel("transitions_rows_kernel<%d> %u agents, %u queries per wave, %s rows", MAXA, args.n_agents, 1u << qw_log2,
+                args.rel ? "compacted" : "reserved");
+    hipLaunchKernelGGL(transitions_rows_kernel<MAXA>, dim3(unsigned(grid64)), dim3(256), lds, stream, args, qw_log2);
+    return hipGetLastError();
+}
+
 hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream) {
     if (args.n_queries == 0 || args.max_branches == 0) return hipSuccess;
-    // lanes per group: the window if it is shorter than a wave, else a wave; a group walks up to 16 x lanes rows, a long
-    // window is cut into that many-row chunks (so that a single query of a large team still fills the device)
+    if (args.n_agents <= 2) return launch_rows<2>(args, stream);
+    if (args.n_agents <= 4) return launch_rows<4>(args, stream);
+    if (args.n_agents <= 6) return launch_rows<6>(args, stream);
+    if (args.n_agents <= 8) return launch_rows<8>(args, stream);
+    // lanes per group: a wave; a group walks up to 16 x lanes rows, a long window is cut into that many-row chunks (so
+    // that a single query of a large team still fills the device)
     uint32_t lanes_log2 = 0;
     while (lanes_log2 < 6 && (1u << lanes_log2) < args.max_branches) ++lanes_log2;
     const uint32_t lanes = 1u << lanes_log2;
@@ -206,12 +537,9 @@ hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream) {
     const uint64_t grid64 = (threads + 255) / 256;
     if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const dim3 grid{unsigned(grid64)}, block{256};
-    const int inst = args.n_agents <= 4 ? 4 : (args.n_agents <= 8 ? 8 : int(args.n_agents));
-    note_kernel("transitions_kernel<%d%s> %u agents, %u lanes x %u rows per group, %u groups per query", inst, inst > 8 ? ",EXACT" : "",
-                args.n_agents, lanes, walks, chunks_per_query);
-    if (args.n_agents <= 4) hipLaunchKernelGGL(transitions_kernel<4>, grid, block, 0, stream, args, lanes_log2, chunk, chunks_per_query);
-    else if (args.n_agents <= 8) hipLaunchKernelGGL(transitions_kernel<8>, grid, block, 0, stream, args, lanes_log2, chunk, chunks_per_query);
-    else switch (args.n_agents) {
+    note_kernel("transitions_kernel<%d,EXACT> %u agents, %u lanes x %u rows per group, %u groups per query, %s rows", int(args.n_agents),
+                args.n_agents, lanes, walks, chunks_per_query, args.rel ? "compacted" : "reserved");
+    switch (args.n_agents) {
 #define X(N) case N: hipLaunchKernelGGL((transitions_kernel<N, true>), grid, block, 0, stream, args, lanes_log2, chunk, chunks_per_query); break;
         X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 #undef X

@@ -9,6 +9,7 @@ from ctypes import POINTER, Structure, byref, c_char_p, c_double, c_int, c_int32
 
 LIB_PATH = os.environ.get('MAPF_HIP_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'lib', 'libmapf_hip.so')
 
+MAPF_ABI_VERSION = 5            # include/mapf_hip.h: the version this binding was written against (checked at load)
 MAPF_OK, MAPF_EINVAL, MAPF_EHIP, MAPF_ENODEVICE, MAPF_EUNSUPPORTED = 0, -1, -2, -3, -4
 MAPF_MAX_AGENTS = 128
 MAPF_MAKESPAN, MAPF_SOC = 0, 1
@@ -54,6 +55,8 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     'mapf_transitions_window': (c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_void_p, c_void_p]),
+    'mapf_transitions_compact': (c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mapf_transition_rewards': (c_int, [c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mapf_query_terminal': (c_int, [c_void_p, c_void_p]),
     'mapf_get_state': (c_int, [c_void_p, c_void_p, POINTER(c_uint64)]),
@@ -73,6 +76,7 @@ SIGNATURES = {
     'mapf_device_count': (c_int, [POINTER(c_int)]),
     'mapf_last_error': (c_char_p, []),
     'mapf_version': (c_char_p, []),
+    'mapf_abi_version': (c_int, []),
 }
 
 _lib = None
@@ -87,6 +91,13 @@ def load():
                                   '%s is missing -- build it with `python __graft_entry__.py build` '
                                   '(make -C gym-mapf_amd/csrc); there is no CPU fallback' % LIB_PATH)
         lib = ctypes.CDLL(LIB_PATH)
+        # the ABI number covers the random streams' counter layouts too: a library of another version (MAPF_HIP_LIB pointing
+        # at an old variant build) would run, and silently draw numbers the oracle does not
+        abi = getattr(lib, 'mapf_abi_version', None)
+        found = abi() if abi is not None else None
+        if found != MAPF_ABI_VERSION:
+            raise MapfNativeError(MAPF_EUNSUPPORTED, '%s has ABI %s, this binding needs ABI %d -- rebuild it (make -C gym-mapf_amd/csrc)'
+                                  % (LIB_PATH, 'older than 5 (no mapf_abi_version)' if found is None else found, MAPF_ABI_VERSION))
         for name, (restype, argtypes) in SIGNATURES.items():
             fn = getattr(lib, name)
             fn.restype, fn.argtypes = restype, argtypes

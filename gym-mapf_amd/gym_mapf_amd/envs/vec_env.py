@@ -161,7 +161,7 @@ class VecMapfEnv:
             return None
         if self.device_arrays:
             t = self._torch
-            want = {np.uint8: t.uint8, np.uint16: t.uint16, np.float64: t.float64, np.uint32: t.uint32}[dtype]
+            want = {np.uint8: t.uint8, np.uint16: t.uint16, np.float64: t.float64, np.uint32: t.uint32, np.uint64: t.uint64}[dtype]
             if not (isinstance(arr, t.Tensor) and arr.is_cuda and arr.dtype == want and arr.is_contiguous()
                     and tuple(arr.shape) == tuple(shape)):
                 raise ValueError('%s must be a contiguous CUDA %s tensor of shape %r' % (name, want, tuple(shape)))
@@ -174,7 +174,7 @@ class VecMapfEnv:
     def _empty(self, shape, dtype):
         if self.device_arrays:
             t = self._torch
-            td = {np.uint8: t.uint8, np.uint16: t.uint16, np.float64: t.float64, np.uint32: t.uint32}[dtype]
+            td = {np.uint8: t.uint8, np.uint16: t.uint16, np.float64: t.float64, np.uint32: t.uint32, np.uint64: t.uint64}[dtype]
             return t.empty(shape, dtype=td, device=self._tdev)
         return np.empty(shape, dtype=dtype)
 
@@ -356,6 +356,37 @@ class VecMapfEnv:
             self._ptr(res['next'], np.uint16, (N, M, A), 'next'), self._ptr(res['prob'], np.float64, (N, M), 'prob'),
             self._ptr(res['reward'], np.float64, (N, M), 'reward'), self._ptr(res['done'], np.uint8, (N, M), 'done'),
             self._ptr(res['collision'], np.uint8, (N, M), 'collision')))
+        return res
+
+    def transitions_compact(self, local, actions, env_index=None, first_branch=0, max_branches=None, capacity=None, out=None):
+        """``env.P[s][a]`` for N queries with COMPACTED rows (``mapf_transitions_compact``): the branches of query q are
+        rows ``offset[q] .. offset[q + 1] - 1`` of ``next`` uint16 [R, A], ``prob`` / ``reward`` float64 [R], ``done`` /
+        ``collision`` uint8 [R], in the reference's order (mapf_env.py:448-478); ``offset`` uint64 [N + 1], ``count``
+        uint32 [N] (full branch counts).  ``capacity`` = R, the rows the arrays hold (default: N * min(3**A, max_branches),
+        which always suffices); rows beyond it are not written -- check ``offset[N] <= R`` (after ``sync()`` in device
+        mode).  ``out`` reuses the arrays of an earlier call."""
+        A = self.n_agents
+        local = np.asarray(local) if not self.device_arrays else local
+        N = int(local.shape[0])
+        M = min(int(max_branches), 3 ** A) if max_branches is not None else 3 ** A
+        local = self._coerce(local, np.uint16, (N, A), 'local')
+        actions = self._coerce(actions, np.uint8, (N, A), 'actions')
+        env_index = self._coerce(env_index, np.uint32, (N,), 'env_index')
+        if out is not None:
+            res, R = out, int(out['prob'].shape[0])
+        else:
+            R = int(capacity) if capacity is not None else N * M
+            res = {'offset': self._empty((N + 1,), np.uint64), 'count': self._empty((N,), np.uint32),
+                   'next': self._empty((R, A), np.uint16), 'prob': self._empty((R,), np.float64),
+                   'reward': self._empty((R,), np.float64), 'done': self._empty((R,), np.uint8),
+                   'collision': self._empty((R,), np.uint8)}
+        nat.check(self._lib.mapf_transitions_compact(
+            self._h, N, self._ptr(local, np.uint16, (N, A), 'local'), self._ptr(actions, np.uint8, (N, A), 'actions'),
+            self._ptr(env_index, np.uint32, (N,), 'env_index'), int(first_branch), max(1, M), R,
+            self._ptr(res['offset'], np.uint64, (N + 1,), 'offset'), self._ptr(res['count'], np.uint32, (N,), 'count'),
+            self._ptr(res['next'], np.uint16, (R, A), 'next'), self._ptr(res['prob'], np.float64, (R,), 'prob'),
+            self._ptr(res['reward'], np.float64, (R,), 'reward'), self._ptr(res['done'], np.uint8, (R,), 'done'),
+            self._ptr(res['collision'], np.uint8, (R,), 'collision')))
         return res
 
     def transition_rewards(self, prev_local, actions, next_local, env_index=None):

@@ -19,8 +19,12 @@ def split_evenly(n_total, rank, world, granule=1):
     ``granule`` envs -- the packed kernels take a launch only when the batch fills their blocks (64 to
     1024 envs per block depending on the form), and a ragged shard would fall back to the guarded
     lane-group kernel on EVERY rank of a world size that does not divide the population -- with the
-    remaining granules going to the lowest ranks and the last ``n_total % granule`` envs to the last rank."""
+    remaining granules going to the lowest ranks and the last ``n_total % granule`` envs to the last rank.  A population
+    of fewer than ``granule * world`` envs would leave ranks EMPTY that way (4096 envs over 8 ranks: four idle GPUs
+    behind an ``n_gpus: 8`` line), so the granule is halved until every rank owns at least one."""
     n_total, rank, world, granule = int(n_total), int(rank), int(world), max(1, int(granule))
+    while granule > 1 and n_total // granule < world:
+        granule //= 2
     blocks, tail = divmod(n_total, granule)
     base, rem = divmod(blocks, world)
     count = (base + (1 if rank < rem else 0)) * granule + (tail if rank == world - 1 else 0)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define MAPF_ABI_VERSION 4
+#define MAPF_ABI_VERSION 5
 
 /* status codes */
 #define MAPF_OK            0
@@ -109,7 +109,7 @@ int mapf_reset(mapf_handle_t h, const uint8_t *mask);
  *   uniforms  f64[E*A]   the rand() values the reference would draw in agent order
  *                        (:255), or NULL: drawn on device from Philox4x32-10 keyed by
  *                        (seed; global env id, step index t, agent) -- the exact counter layout is
- *                        oracle/philox.py's (ABI 4: one call per agent QUAD per two steps; ABI 3
+ *                        oracle/philox.py's (since ABI 4: one call per agent QUAD per two steps; ABI 3
  *                        used one per agent pair per four steps, so the same seed draws other
  *                        numbers than it did there)
  *   out_local u16[E*A]   the state step() returns, as per-agent cells
@@ -152,7 +152,9 @@ typedef struct mapf_rollout_io {
 int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io);
 
 /* Synthetic policy used by bench/rollout: fills actions u8[n_steps*E*A] for step indices
- * t0 .. t0+n_steps-1 from the policy stream (oracle/philox.py random_actions_np). */
+ * t0 .. t0+n_steps-1 from the policy stream (oracle/philox.py random_actions_np; ABI 5: key seed + 1, ONE Philox
+ * call per agent quad per FOUR steps -- counter (env, t >> 2, quad), word t & 3, byte agent & 3, action =
+ * (byte * 5) >> 8; ABI <= 4 drew one call per quad per step and a 32-bit word per action). */
 int mapf_fill_random_actions(mapf_handle_t h, uint8_t *actions, uint64_t t0, uint32_t n_steps);
 
 /*
@@ -189,6 +191,23 @@ int mapf_transitions_window(mapf_handle_t h, uint64_t n_queries, const uint16_t 
                             const uint32_t *env_index, uint64_t first_branch, uint32_t max_branches, uint32_t *out_count,
                             uint16_t *out_next, double *out_prob, double *out_reward, uint8_t *out_done,
                             uint8_t *out_collision);
+
+/*
+ * The same enumeration with COMPACTED rows (ABI 5): the window [first_branch, first_branch + max_branches) of every query,
+ * back to back -- query q's rows are rows out_offset[q] .. out_offset[q + 1] - 1 of every output array, in the reference's
+ * branch order (mapf_env.py:465-476 builds exactly such a list per (s, a); a query reserves 3^A rows in the calls above and
+ * a room map fills a fifth of them, so a planner that sweeps many states wants them dense).
+ *   out_offset u64[N + 1] (required): exclusive scan of the windows' lengths; out_offset[N] = the number of rows needed;
+ *   capacity_rows: rows the out_* arrays hold -- rows at or beyond it are NOT written (no overrun): a caller checks
+ *     out_offset[N] <= capacity_rows (after mapf_sync in device-pointer mode) and calls again with larger arrays if not;
+ *   out_count u32[N] (optional): the FULL branch count of every query, as above;
+ *   out_next u16[R*A], out_prob f64[R], out_reward f64[R], out_done u8[R], out_collision u8[R] with R = capacity_rows.
+ * Three launches: window lengths + block-local scan, scan of the block totals, rows.  n_agents <= 16.
+ */
+int mapf_transitions_compact(mapf_handle_t h, uint64_t n_queries, const uint16_t *local, const uint8_t *actions,
+                             const uint32_t *env_index, uint64_t first_branch, uint32_t max_branches, uint64_t capacity_rows,
+                             uint64_t *out_offset, uint32_t *out_count, uint16_t *out_next, double *out_prob, double *out_reward,
+                             uint8_t *out_done, uint8_t *out_collision);
 
 /*
  * MapfEnv.calc_transition_reward_from_local_states (mapf_env.py:225-235, with _living_reward :436-446 and
@@ -275,6 +294,9 @@ const char *mapf_last_kernel(mapf_handle_t h, int which);
 int mapf_device_count(int *out_count);
 const char *mapf_last_error(void);
 const char *mapf_version(void);
+/* MAPF_ABI_VERSION of the loaded library: a binding written against another number must refuse to drive it (the Philox
+ * counter layouts are part of the ABI: the same seed draws other numbers under another version). */
+int mapf_abi_version(void);
 
 #ifdef __cplusplus
 }

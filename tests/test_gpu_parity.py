@@ -827,7 +827,34 @@ def test_transitions_random_queries_against_oracle(n_agents, criteria):
     small = env.transitions(local, acts, max_branches=2, env_index=env_index)       # truncated rows, true counts
     assert np.array_equal(small['count'], res['count'])
     assert np.array_equal(small['next'][:, 0], res['next'][:, 0]) and np.array_equal(_bits(small['prob'][:, 0]), _bits(res['prob'][:, 0]))
+    _check_compact_against_reserved(env, local, acts, env_index, res)
     env.close()
+
+
+def _check_compact_against_reserved(env, local, acts, env_index, res, first=0, window=None):
+    """mapf_transitions_compact: the same rows as the reserved form (already checked against the oracle), back to back
+    behind the exclusive scan of the windows' lengths; a capacity that is too small drops rows instead of overrunning."""
+    N = local.shape[0]
+    kw = dict(env_index=env_index, first_branch=first)
+    if window is not None:
+        kw['max_branches'] = window
+    cmp = env.transitions_compact(local, acts, **kw)
+    M = res['prob'].shape[1]
+    rows = np.minimum(np.maximum(res['count'].astype(np.int64) - first, 0), M)
+    assert np.array_equal(cmp['count'], res['count'])
+    assert np.array_equal(cmp['offset'].astype(np.int64), np.concatenate([[0], np.cumsum(rows)]))
+    for q in range(N):
+        o, n = int(cmp['offset'][q]), int(rows[q])
+        assert np.array_equal(cmp['next'][o:o + n], res['next'][q, :n]), q
+        assert np.array_equal(_bits(cmp['prob'][o:o + n]), _bits(res['prob'][q, :n])), q
+        assert np.array_equal(_bits(cmp['reward'][o:o + n]), _bits(res['reward'][q, :n])), q
+        assert np.array_equal(cmp['done'][o:o + n], res['done'][q, :n]) and np.array_equal(cmp['collision'][o:o + n], res['collision'][q, :n]), q
+    total = int(cmp['offset'][N])
+    if total > 3:                                                 # too small a capacity: the needed size is reported, nothing overruns
+        cap = total // 2
+        part = env.transitions_compact(local, acts, capacity=cap, **kw)
+        assert int(part['offset'][N]) == total and part['prob'].shape[0] == cap
+        assert np.array_equal(_bits(part['prob']), _bits(cmp['prob'][:cap])) and np.array_equal(part['next'], cmp['next'][:cap])
 
 
 def test_transitions_of_large_teams_come_in_windows():
@@ -880,8 +907,9 @@ def test_transitions_of_large_teams_come_in_windows():
 
 @pytest.mark.parametrize('n_agents', list(range(7, 17)))
 def test_every_transitions_kernel_instance_against_oracle(n_agents):
-    """mapf_transitions dispatches transitions_kernel<8> for 5..8 agents and an exact-size instance for each of 9..16
-    (mapf_transitions.hip launch_transitions): every one of them against the pinned Python oracle's enumeration
+    """mapf_transitions dispatches transitions_rows_kernel<2|4|6|8> up to 8 agents (the 1..6-agent instances: the test
+    above) and an exact-size transitions_kernel instance for each of 9..16 (mapf_transitions.hip launch_transitions), each
+    with reserved and with compacted rows: every one of them against the pinned Python oracle's enumeration
     (reference mapf_env.py:448-478), both criteria, per-query goals, several window sizes and offsets.  At most seven
     agents of a query move (the others STAY: one-entry lists), which keeps the oracle's list at <= 3^7 branches while
     every agent still takes part in the pair tests, the goal test and the SoC living reward."""
@@ -923,9 +951,13 @@ def test_every_transitions_kernel_instance_against_oracle(n_agents):
                     assert res['next'][q, b].tolist() == list(enxt), (A, window, q, first + b)
                     assert _bits(res['prob'][q, b]) == _bits(ep) and _bits(res['reward'][q, b]) == _bits(er), (A, window, q, first + b)
                     assert (bool(res['done'][q, b]), bool(res['collision'][q, b])) == (ed, ec), (A, window, q, first + b)
+            _check_compact_against_reserved(env, local, acts, env_index, res, first=first, window=window)   # ... and the compacted rows
             first += window
     assert sum(1 for x in exp for t in x if t[0][1]) > 0              # collision branches were among them
-    assert env.last_kernel('transitions').startswith('transitions_kernel<8>' if A <= 8 else 'transitions_kernel<%d,EXACT>' % A)
+    name = env.last_kernel('transitions')
+    assert name.startswith('transitions_rows_kernel<8>' if A <= 8 else 'transitions_kernel<%d,EXACT>' % A) and 'compacted' in name, name
+    env.transitions(local, acts, max_branches=257, env_index=env_index)
+    assert 'reserved' in env.last_kernel('transitions')
     env.close()
 
 

@@ -94,7 +94,7 @@ def test_split_evenly_keeps_shards_on_block_boundaries():
     """bench.py splits a fixed population in multiples of 1024 envs: with a world size that does not divide it (3, 5, 6,
     7 GPUs) every rank would otherwise get a ragged shard and lose the packed kernels (round-3 advisor finding)."""
     import bench
-    for n in (262144, 131072, 100000, 1023):
+    for n in (262144, 131072, 100000):                             # (populations below granule x world: the next test)
         for world in (1, 2, 3, 5, 6, 7, 8):
             spans = [sharding.split_evenly(n, r, world, granule=bench.SHARD_GRANULE) for r in range(world)]
             assert sum(c for _, c in spans) == n
@@ -106,6 +106,18 @@ def test_split_evenly_keeps_shards_on_block_boundaries():
             if n % bench.SHARD_GRANULE == 0:
                 assert max(c for _, c in spans) - min(c for _, c in spans) <= bench.SHARD_GRANULE
     assert [sharding.split_evenly(262144, r, 3, granule=1024)[1] for r in range(3)] == [88064, 87040, 87040]
+
+
+def test_split_evenly_leaves_no_rank_empty():
+    """A population smaller than granule x world (round-4 advisor finding: 4096 envs over 8 ranks gave four ranks nothing,
+    n = 1023 gave everything to the last one): the granule shrinks until every rank owns envs."""
+    assert [sharding.split_evenly(4096, r, 8, granule=1024)[1] for r in range(8)] == [512] * 8
+    assert [sharding.split_evenly(1023, r, 2, granule=1024) for r in range(2)] == [(0, 512), (512, 511)]
+    for n, world in ((4096, 8), (1023, 2), (1023, 8), (5000, 3), (9, 8), (8, 8)):
+        spans = [sharding.split_evenly(n, r, world, granule=1024) for r in range(world)]
+        assert all(c > 0 for _, c in spans) and sum(c for _, c in spans) == n, (n, world, spans)
+        assert all(spans[r][0] + spans[r][1] == spans[r + 1][0] for r in range(world - 1))
+    assert [sharding.split_evenly(3, r, 8, granule=1024)[1] for r in range(8)] == [1, 1, 1, 0, 0, 0, 0, 0]   # fewer envs than ranks
 
 
 def test_bench_workloads_depend_on_global_env_ids_only():
