@@ -104,6 +104,7 @@ struct mapf_handle_s {
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     mapf::MoveEntry *mv = nullptr;
     mapf::CompactEntry *mv8 = nullptr;   // the 8-byte-row form of the move table (the packed single step gathers from it)
+    uint32_t *mv4 = nullptr;          // the 4-byte delta-row form (kernels that keep the table of a 64x64 map in LDS); null unless mv_delta8
     mapf::SlipRow *slip = nullptr;
     std::vector<uint16_t> nbr;        // host copy of the neighbour table (policy tables are derived from it)
     uint2 *policy_cells = nullptr;    // greedy policy table (mapf_set_policy); null = random policy stream
@@ -298,6 +299,7 @@ void destroy_impl(mapf_handle_t h) {
     if (h->t_dev) (void)hipFree(h->t_dev);
     if (h->mv) (void)hipFree(h->mv);
     if (h->mv8) (void)hipFree(h->mv8);
+    if (h->mv4) (void)hipFree(h->mv4);
     if (h->policy_cells) (void)hipFree(h->policy_cells);
     if (h->slip) (void)hipFree(h->slip);
     if (h->state) (void)hipFree(h->state);
@@ -470,6 +472,17 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
         CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->mv8), compact.size() * sizeof(mapf::CompactEntry)));
         CREATE_TRY(hipMemcpy(h->mv8, compact.data(), compact.size() * sizeof(mapf::CompactEntry), hipMemcpyHostToDevice));
     }
+    if (h->mv_delta8) {   // 4-byte delta rows, six columns (mapf_kernels.hpp kDeltaCols); the padding words stay zero
+        std::vector<uint32_t> delta(mapf::delta_table_words(V), 0u);
+        for (uint32_t v = 0; v < V; ++v)
+            for (uint32_t col = 0; col < mapf::kDeltaCols; ++col) {
+                const mapf::MoveEntry &e = packed[size_t(v) * mapf::kMvCols + (col < mapf::kMvCols ? col : 0u)];
+                delta[size_t(v) * mapf::kDeltaCols + col] = ((e.x - v) & 0xFFu) | ((((e.x >> 16) - v) & 0xFFu) << 8) | (((e.y - v) & 0xFFu) << 16) |
+                                                            (((e.w + mapf::kDeltaRowBias) >> 3) << 24);
+            }
+        CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->mv4), delta.size() * sizeof(uint32_t)));
+        CREATE_TRY(hipMemcpy(h->mv4, delta.data(), delta.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     if (n_start) CREATE_TRY(hipMemcpy(h->start, d->start, n_start * sizeof(uint16_t), hipMemcpyHostToDevice));
     if (n_goal) CREATE_TRY(hipMemcpy(h->goal, d->goal, n_goal * sizeof(uint16_t), hipMemcpyHostToDevice));
     CREATE_TRY(hipMalloc(reinterpret_cast<void **>(&h->t_dev), sizeof(uint64_t)));
@@ -588,7 +601,7 @@ int mapf_step(mapf_handle_t h, const uint8_t *actions, const double *uniforms, u
     if (int rc = check_extent(h, h->E, uniforms != nullptr)) return rc;
     const size_t E = size_t(h->E), EA = E * h->A;
     mapf::StepArgs a{};
-    a.c = h->c; a.mv = h->mv; a.mv8 = h->mv8; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
+    a.c = h->c; a.mv = h->mv; a.mv8 = h->mv8; a.mv4 = h->mv4; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
     a.n_envs = h->E; a.env_id_offset = h->env_id_offset;
     // a recorded launch: offset inside the recording + the device-side index (see StepArgs::t_dev)
     a.t = h->capturing ? h->cap_steps : h->t;
@@ -707,7 +720,7 @@ int mapf_rollout(mapf_handle_t h, const mapf_rollout_io *io) {
     if (int rc = check_extent(h, uint64_t(h->E) * io->n_steps, false)) return rc;
     const size_t E = size_t(h->E), T = io->n_steps, TE = T * E, TEA = TE * h->A;
     mapf::RolloutArgs a{};
-    a.c = h->c; a.mv = h->mv; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
+    a.c = h->c; a.mv = h->mv; a.mv4 = h->mv4; a.slip = h->slip; a.state = h->state; a.start = h->start; a.goal = h->goal;
     a.n_envs = h->E; a.env_id_offset = h->env_id_offset; a.n_steps = io->n_steps;
     a.t = h->capturing ? h->cap_steps : h->t;
     a.t_dev = h->capturing ? h->t_dev : nullptr;
@@ -821,6 +834,17 @@ int mapf_fill_random_actions(mapf_handle_t h, uint8_t *actions, uint64_t t0, uin
     return MAPF_OK;
 }
 
+namespace {
+// the scan's scratch (handle-owned; a growing buffer is reallocated behind hipFree's implicit device synchronisation)
+int transitions_scratch(mapf_handle_t h, mapf::TransitionsArgs &a) {
+    HIP_TRY(h->q_rel.reserve((a.n_queries ? a.n_queries : 1) * sizeof(uint32_t)));
+    HIP_TRY(h->q_blocks.reserve((mapf::transitions_scan_blocks(a.n_queries) + 1) * sizeof(uint64_t)));
+    a.rel = static_cast<uint32_t *>(h->q_rel.ptr);
+    a.block_base = static_cast<uint64_t *>(h->q_blocks.ptr);
+    return MAPF_OK;
+}
+}  // namespace
+
 int mapf_transitions_window(mapf_handle_t h, uint64_t n_queries, const uint16_t *local, const uint8_t *actions,
                             const uint32_t *env_index, uint64_t first_branch, uint32_t max_branches, uint32_t *out_count, uint16_t *out_next,
                      double *out_prob, double *out_reward, uint8_t *out_done, uint8_t *out_collision) {
@@ -846,6 +870,7 @@ int mapf_transitions_window(mapf_handle_t h, uint64_t n_queries, const uint16_t 
     if (int rc = stage_out(h, h->q_reward, out_reward, NM, &a.out_reward, "out_reward")) return rc;
     if (int rc = stage_out(h, h->q_done, out_done, NM, &a.out_done, "out_done")) return rc;
     if (int rc = stage_out(h, h->q_coll, out_collision, NM, &a.out_collision, "out_collision")) return rc;
+    if (int rc = transitions_scratch(h, a)) return rc;
     HIP_TRY(mapf::launch_transitions(a, h->stream));
     if (h->last_transitions_kernel != g_noted_kernel) h->last_transitions_kernel = g_noted_kernel;
     if (int rc = fetch_out(h, a.out_count, out_count, N)) return rc;
@@ -893,14 +918,9 @@ int mapf_transitions_compact(mapf_handle_t h, uint64_t n_queries, const uint16_t
     if (int rc = stage_out(h, h->q_reward, out_reward, R, &a.out_reward, "out_reward")) return rc;
     if (int rc = stage_out(h, h->q_done, out_done, R, &a.out_done, "out_done")) return rc;
     if (int rc = stage_out(h, h->q_coll, out_collision, R, &a.out_collision, "out_collision")) return rc;
-    // the scan's scratch (handle-owned; a growing buffer is reallocated behind hipFree's implicit device synchronisation)
-    HIP_TRY(h->q_rel.reserve((N ? N : 1) * sizeof(uint32_t)));
-    HIP_TRY(h->q_blocks.reserve((mapf::transitions_scan_blocks(n_queries) + 1) * sizeof(uint64_t)));
-    uint32_t *rel = static_cast<uint32_t *>(h->q_rel.ptr);
-    uint64_t *blocks = static_cast<uint64_t *>(h->q_blocks.ptr);
+    if (int rc = transitions_scratch(h, a)) return rc;
+    a.compact = true;
     if (N == 0) HIP_TRY(hipMemsetAsync(a.out_offset, 0, sizeof(uint64_t), h->stream));
-    HIP_TRY(mapf::launch_transitions_offsets(a, rel, blocks, a.out_offset + N, h->stream));
-    a.rel = rel; a.block_base = blocks;
     HIP_TRY(mapf::launch_transitions(a, h->stream));
     if (h->last_transitions_kernel != g_noted_kernel) h->last_transitions_kernel = g_noted_kernel;
     if (!h->device_ptrs) {

@@ -49,6 +49,15 @@ struct SlipRow {
 // The thresholds (MoveEntry::z) are SlipRow::th_biased of the code's row, its members (exact path) SlipRow::members.
 using CompactEntry = uint2;
 
+// 4-byte DELTA form of a move-table row, for maps on which every candidate cell lies within +-127 ids of its own cell (ids run
+// down the columns, so every map of at most 127 rows; mapf_create checks): bytes 0..2 = the three list cells minus the row's
+// own cell (signed), byte 3 = (byte offset of the code's slip row + kDeltaRowBias) / 8.  SIX columns per cell (column 5 = STAY
+// again: an action byte is extracted and clamped by one v_min_u32), padded with zero words to a multiple of 16 bytes -- the
+// image the 32-agent rollout and the LDS-table single step keep in LDS (24 bytes per cell: 79 KB on a 64x64 map, where the
+// 16-byte rows take 316 KB), built once on the host.
+constexpr uint32_t kDeltaCols = 6, kDeltaRowBias = 16;
+__host__ __device__ constexpr size_t delta_table_words(uint32_t n_cells) { return (size_t(n_cells) * kDeltaCols + 3u) & ~size_t(3); }
+
 struct EnvConsts {
     double r_clash, r_goal, r_living;
     double p_cand[3];              // probabilities of the three candidates: intended move, right slip, left slip
@@ -90,6 +99,7 @@ struct StepArgs {
     EnvConsts c;
     const MoveEntry *mv;           // [V*5] move table (see MoveEntry, kMvCols)
     const uint2 *mv8;              // [V*5] the same table with 8-byte rows (CompactEntry: cells + the code's slip-row offset)
+    const uint32_t *mv4;           // [delta_table_words(V)] the same table as 4-byte delta rows, six columns; null when the map's ids do not allow them
     const SlipRow *slip;           // [8] device copy of the slip table (the first part of a TableImage)
     uint16_t *state;               // [E*A] persistent env state
     const uint16_t *start, *goal;  // [E*A] or [A]
@@ -117,6 +127,7 @@ struct StepArgs {
 struct RolloutArgs {
     EnvConsts c;
     const MoveEntry *mv;
+    const uint32_t *mv4;           // see StepArgs (non-null <=> mv_delta8)
     const SlipRow *slip;
     uint16_t *state;
     const uint16_t *start, *goal;
@@ -156,24 +167,20 @@ struct TransitionsArgs {
     uint64_t first_branch;         // first branch of the returned window (0 = from the start)
     uint32_t max_branches, n_agents;
     bool goal_broadcast;
-    // Compacted output (mapf_transitions_compact): the window rows of query q start at row block_base[q / 256] + rel[q] of
-    // every output array -- an exclusive scan of the windows' lengths, made by launch_transitions_offsets -- and
-    // out_offset[q] receives that row.  rel == null: reserved rows (row j of query q's window at q * max_branches + j).
-    // Rows at or beyond `capacity` are not written.
-    const uint32_t *rel;
-    const uint64_t *block_base;
+    // The scan of the windows' lengths (launch_transitions makes it when the output is compacted or a query's window is cut
+    // into several waves' pieces): query q's window starts at row block_base[q / 256] + rel[q] of the COMPACTED arrays,
+    // block_base[number of blocks] = the rows in total.  compact: the output arrays ARE compacted (mapf_transitions_compact;
+    // out_offset[q] receives q's first row, out_offset[N] the total) -- else reserved rows (row j of query q's window at
+    // q * max_branches + j).  Rows at or beyond `capacity` are not written.
+    uint32_t *rel;                 // scratch u32[N]
+    uint64_t *block_base;          // scratch u64[transitions_scan_blocks(N) + 1]
     uint64_t *out_offset;
     uint64_t capacity;
+    bool compact;
 };
 constexpr int kTransitionsMaxAgents = 16;   // 3^16 = 43 M branches per query, returned in windows
 hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream);
-// passes 1 and 2 of the compacted form: rel u32[N], block_base u64[transitions_scan_blocks(N)], *out_total = rows in total
-// (also fills args.out_count)
 uint64_t transitions_scan_blocks(uint64_t n_queries);
-hipError_t launch_transitions_offsets(const TransitionsArgs &args, uint32_t *rel, uint64_t *block_base, uint64_t *out_total, hipStream_t stream);
-// calc_transition_reward_from_local_states for N (prev = args.local, args.actions, next) triples; fills
-// args.out_reward / out_done / out_collision [N] (max_branches, out_count, out_next, out_prob unused)
-hipError_t launch_transition_rewards(const TransitionsArgs &args, const uint16_t *next, hipStream_t stream);
 
 hipError_t launch_step(int n_agents, const StepArgs &args, hipStream_t stream);
 hipError_t launch_rollout(int n_agents, const RolloutArgs &args, hipStream_t stream);
@@ -213,6 +220,8 @@ struct RolloutTuning {
     int step_big = 1;                // MAPF_STEP_BIG: the packed single step's resident-grid / LDS-table form -- 0 never, 1 for batches
                                      //   of at least four times what the device holds at once (default), 2 whenever it fits (tests)
     unsigned step_block = 0;         // MAPF_STEP_BLOCK=64|128|256|512: block size of the plain packed single step (experiments; 0 = by batch)
+    int step_delta = 1;              // MAPF_STEP_DELTA: the single step's LDS table of 4-byte delta rows -- 0 never, 1 where the 16-byte rows
+                                     //   do not fit and the batch gives every CU a block (default), 2 whenever it fits (tests, experiments)
     bool scen_table = true;          // MAPF_SCEN_TABLE=0: never build the scenario table (StepArgs::scen) -- tests compare both forms
 };
 RolloutTuning default_rollout_tuning(int device);

@@ -263,6 +263,7 @@ RolloutTuning default_rollout_tuning(int device) {
     if (const char *e = getenv("MAPF_BITMAP_DELTA")) t.bitmap_delta_rows = atoi(e) != 0;
     if (const char *e = getenv("MAPF_STEP_BIG")) t.step_big = atoi(e);
     if (const char *e = getenv("MAPF_STEP_BLOCK")) t.step_block = unsigned(atoi(e));
+    if (const char *e = getenv("MAPF_STEP_DELTA")) t.step_delta = atoi(e);
     return t;
 }
 

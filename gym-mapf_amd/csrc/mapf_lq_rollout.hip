@@ -60,12 +60,12 @@ static_assert(sizeof(SlipRow) * 8 + sizeof(OutcomeRow) * 16 <= kLdsReserve, "sta
 constexpr uint32_t kSlipAt = 0, kOutcomeAt = sizeof(SlipRow) * 8, kMoveAt = kLdsReserve, kMoveCols = 6;
 constexpr uint32_t kCompactCols = 5, kCompactEntry = 8;   // COMPACT: cells + code only, no sixth column
 constexpr uint32_t kBitmapCols = 4;                       // COMPACT + BITMAP == 1: no STAY column either
-constexpr uint32_t kDeltaCols = 6, kDeltaEntry = 4;       // COMPACT + BITMAP == 3: 4-byte delta rows, STAY twice (as the full table)
+constexpr uint32_t kDeltaEntry = 4;                       // COMPACT + BITMAP == 3: 4-byte delta rows, six columns (kDeltaCols, mapf_kernels.hpp: STAY twice, as the full table)
 static_assert(kOutcomeAt + sizeof(OutcomeRow) * 16 <= kMoveAt, "LDS image: slip rows, outcome rows, then the move table");
 // The LDS copy of a table row carries its slip row's byte offset PLUS kRowBias, so that sample_slot_packed's probability
 // address -- that operand minus 8 per threshold not passed -- is never negative and packs into an unsigned field (the
 // systolic probability chain below files four of them per word); the immediates of the LDS reads absorb the bias.
-constexpr uint32_t kRowBias = 16;
+constexpr uint32_t kRowBias = kDeltaRowBias;              // (the host-built delta rows carry it too)
 // index (in doubles from kSlipAt) of a +0.0: the all-equal code's list has ONE entry, so thr[1] of its row is the integer 0
 constexpr uint32_t kZeroFactor = (7u * uint32_t(sizeof(SlipRow)) + uint32_t(offsetof(SlipRow, thr)) + 8u) / 8u;
 static_assert(offsetof(SlipRow, thr) % 8 == 0 && kZeroFactor < 128u, "a zero factor the packed probability indices can name");
@@ -82,8 +82,10 @@ static_assert(offsetof(SlipRow, thr) % 8 == 0 && kZeroFactor < 128u, "a zero fac
 // from a cell's by less than a column's height, which mapf_create checks: RolloutArgs::mv_delta8) plus the slip row's offset
 // in the fourth byte -- so that SIX columns (STAY twice: an action byte is extracted and clamped by one v_min_u32, and no STAY
 // row is made up) take half the room of the five 8-byte ones: 128 bitmaps fit behind them on the 64x64 maps.
+// (the four-column form with the in-kernel policy holds its actions across the table reads -- the made-up STAY row asks for
+// them -- and does not fit the 128 registers of a 1024-thread block: launched with 512 threads, see try_launch_rollout_lq)
 template <int Q, int K, bool RECORD, bool STREAM, bool SOC, bool COMPACT, bool TERM, int BITMAP = 0>
-__global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents, const uint32_t bitmap_base) {
+__global__ void __launch_bounds__((K == 8 || (COMPACT && BITMAP == 1 && !STREAM)) ? 512 : 1024) lq_rollout_kernel(const RolloutArgs p, const uint32_t n_agents, const uint32_t bitmap_base) {
     constexpr int P = K / 2;   // packed dwords per lane
     static_assert(K == 2 || K == 4 || K == 8, "two, four or eight agents per lane");
     // the kernel's LDS image is its dynamic segment, used as a raw scratchpad from LDS address 0 (LdsAbsolute, mapf_lq.hpp: no
@@ -111,6 +113,20 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
 #pragma unroll
         for (int i = 0; i < P; ++i) { c[i] = cells.v[i]; g[i] = gl.v[i]; start_c[i] = sc.v[i]; }
     }
+    if constexpr (COMPACT && BITMAP == 3) {
+        // the host-built delta rows (RolloutArgs::mv4) as they are: 16 bytes per thread and load, four loads in flight (the
+        // 16-byte rows this form was first staged from are 13 times the bytes: 263 KB per block against 79 KB on a 64x64 map)
+        const uint32_t n_vec = uint32_t(delta_table_words(p.c.n_cells) / 4u);
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(p.mv4);
+        for (uint32_t w0 = threadIdx.x; w0 < n_vec; w0 += 4u * blockDim.x) {
+            u32x4 part[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) part[k] = src[min(w0 + k * blockDim.x, n_vec - 1u)];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k)
+                if (w0 + k * blockDim.x < n_vec) *(__attribute__((address_space(3))) u32x4 *)lds_addr(lds, kMoveAt + 16u * (w0 + k * blockDim.x)) = part[k];
+        }
+    } else
     {   // move table -> LDS with six columns per cell (0..4 = the actions, 5 = STAY again: where out-of-range action
         // bytes are clamped to), batches of four independent loads per thread
         // (COMPACT: five columns, the first 8 bytes of every row)
@@ -340,6 +356,10 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
 
     // In-kernel policy stream (!STREAM, no greedy table): the words of the current four-step block, one call per agent quad
     constexpr int kPolicyCalls = K == 8 ? 2 : 1;
+    constexpr uint32_t kColShift = COMPACT ? (BITMAP == 3 ? 2u : 3u) : 4u;     // log2 of a table row's bytes
+    // the policy word's bytes go straight into the table address (no action integer is formed) where nothing else asks for
+    // the action: not in the SoC instances (_living_reward counts STAY) nor behind the four-column table (STAY has no row there)
+    constexpr bool FAST_POLICY = !STREAM && !SOC && !(COMPACT && BITMAP == 1);
     Words4 pol[kPolicyCalls];
 #pragma unroll
     for (int j = 0; j < kPolicyCalls; ++j) pol[j] = Words4{0u, 0u, 0u, 0u};
@@ -347,10 +367,36 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
     // form is two scalar registers short of keeping it beside the slip stream's)
     uint32_t pol_key_lo = p.c.pol_lo, pol_key_hi = p.c.pol_hi;
     if (K == 8) asm volatile("" : "+v"(pol_key_lo), "+v"(pol_key_hi));
+    // PRECOL: the four steps' column offsets are formed when the call is made (behind that step's table reads, off the path
+    // from the step's top to its own reads) and kept instead of the words: pol[j] = the even bytes' pairs of the four steps,
+    // pol_odd[j] = the odd bytes' -- four registers more, which the 32-agent (bitmap) instances do not have
+    constexpr bool PRECOL = FAST_POLICY && !(COMPACT && BITMAP != 0);
+    Words4 pol_odd[kPolicyCalls];
+#pragma unroll
+    for (int j = 0; j < kPolicyCalls; ++j) pol_odd[j] = Words4{0u, 0u, 0u, 0u};
+    // the column offsets (action << kColShift) of two agents at a time, never leaving their half-words: byte * (5 << kColShift)
+    // has the action in bits 8 + kColShift .. of its half -- i.e. byte 1 of the half IS the column offset once the fraction
+    // below it is masked off; the table address adds it with a byte select
+    auto column_pairs = [&](uint32_t pw, uint32_t &even_pair, uint32_t &odd_pair) __attribute__((always_inline)) {
+        if constexpr (K == 2) pw >>= 16u * (x.g & 1u);             // the quad is shared with the neighbour lane: bytes 2 (g & 1), + 1
+        const uint32_t even = __builtin_amdgcn_perm(pw, pw, 0x0C020C00u), odd = __builtin_amdgcn_perm(pw, pw, 0x0C030C01u);   // {b0, 0, b2, 0}, {b1, 0, b3, 0}
+        even_pair = __umul24(even, 5u << kColShift) & (0x00070007u << (8 + kColShift));
+        odd_pair = __umul24(odd, 5u << kColShift) & (0x00070007u << (8 + kColShift));
+    };
     auto refresh_policy = [&](const uint64_t m) __attribute__((always_inline)) {
         if constexpr (K == 8) policy_words_x2(__builtin_amdgcn_readfirstlane(pol_key_lo), __builtin_amdgcn_readfirstlane(pol_key_hi), env_id, m,
                                               2u * x.g, 2u * x.g + 1u, pol[0], pol[1]);
         else pol[0] = policy_words(p.c, env_id, m, K == 4 ? x.g : x.g >> 1);
+        if constexpr (PRECOL) {
+#pragma unroll
+            for (int j = 0; j < kPolicyCalls; ++j) {
+                const Words4 w = pol[j];
+                column_pairs(w.w0, pol[j].w0, pol_odd[j].w0);
+                column_pairs(w.w1, pol[j].w1, pol_odd[j].w1);
+                column_pairs(w.w2, pol[j].w2, pol_odd[j].w2);
+                column_pairs(w.w3, pol[j].w3, pol_odd[j].w3);
+            }
+        }
     };
 
     // One step.  W = which word of the slip calls this step uses (t & 3) when that is a compile-time fact, -1 = generic
@@ -368,12 +414,22 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         constexpr bool MAYBE_TERMINAL = TERM || FIRST;   // (the launch's first step finds whatever state the last launch left)
         const uint64_t t = t_first + s;
         double qv[K];                                              // SYS: the factors of this step's chain round
-#ifdef MAPF_EXP_EARLY_FETCH   // (experiment builds only: measured equal -- 531-537 G against 531-532 G on C5's share -- and 8 registers dearer)
-        if (SYS && !FIRST) chain_fetch(qv);
-#endif
         uint32_t cur[K], act[K];
 #pragma unroll
         for (int k = 0; k < K; ++k) cur[k] = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu;
+        // --- my agents' table rows: cell * (row bytes) + (action << kColShift), the table's LDS offset is an immediate
+        uint32_t cell_at[K], col_at[K];
+        auto rows_of_cells = [&]() __attribute__((always_inline)) {   // (all the word-select multiplies first: back to back with their users each one costs an s_nop)
+#pragma unroll
+            for (int k = 0; k < K; ++k) cell_at[k] = (k & 1) ? half_times<1>(c[k / 2], row_bytes) : half_times<0>(c[k / 2], row_bytes);
+#pragma unroll
+            for (int k = 0; k < K; ++k) asm volatile("" : "+v"(cell_at[k]));
+        };
+        auto columns_from_actions = [&]() __attribute__((always_inline)) {   // (behind the actions: the 1024-thread forms have no register to hold both for long)
+            rows_of_cells();
+#pragma unroll
+            for (int k = 0; k < K; ++k) col_at[k] = (act[k] << kColShift) + cell_at[k];
+        };
         if (STREAM) {
 #pragma unroll
             for (int k = 0; k < K; ++k) {
@@ -382,63 +438,65 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) asm volatile("" : "+v"(act[k]));   // the wait for `raw` sits here
-#ifndef MAPF_EXP_NO_ACT_ADVANCE   // (experiment builds only: every step re-reads one row, i.e. the action stream hits in L2)
             act_lane += (!TAIL || s + kAhead <= last_row) ? step_cells : 0u;   // row min(s + kAhead, last)
-#endif
             raw = load_raw();
         } else if (p.policy_cells) {   // greedy policy
 #pragma unroll
             for (int k = 0; k < K; ++k) act[k] = greedy_action(p.policy_cells, p.c.n_cells, cur[k], goal_rc[k]);
+            if constexpr (FAST_POLICY) columns_from_actions();
         } else {   // policy stream: the step's word of my quad's call (one call per quad per four steps), a byte per agent
             if (FIRST) refresh_policy(t >> 2);                     // (later blocks: requested in the step before their first one, below)
-            uint32_t five;                                         // (made where it is used: the 1024-thread forms have no register to park it in)
-            asm volatile("v_mov_b32 %0, 5" : "=v"(five));
+            if constexpr (FAST_POLICY) rows_of_cells();
 #pragma unroll
             for (int j = 0; j < kPolicyCalls; ++j) {
                 uint32_t pw = W == 0 ? pol[j].w0 : W == 1 ? pol[j].w1 : W == 2 ? pol[j].w2 : W == 3 ? pol[j].w3 : step_word(pol[j], t);
-                if constexpr (K == 2) {                            // the quad is shared with the neighbour lane: bytes 2 (g & 1), + 1
-                    pw >>= 16u * (x.g & 1u);
-                    act[0] = policy_action<0>(pw, five);
-                    act[1] = policy_action<1>(pw, five);
+                if constexpr (FAST_POLICY) {
+                    uint32_t pair[2];
+                    if constexpr (PRECOL) {
+                        pair[0] = pw;
+                        pair[1] = W == 0 ? pol_odd[j].w0 : W == 1 ? pol_odd[j].w1 : W == 2 ? pol_odd[j].w2 : W == 3 ? pol_odd[j].w3 : step_word(pol_odd[j], t);
+                    } else column_pairs(pw, pair[0], pair[1]);
+#pragma unroll
+                    for (int b = 0; b < (K == 2 ? 2 : 4); ++b) {       // byte b of the word: pair b & 1, low / high half
+                        const int k = K == 2 ? b : 4 * j + b;
+                        if (K == 2 || b < 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(col_at[k]) : "v"(cell_at[k]), "v"(pair[b & 1]));
+                        else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(col_at[k]) : "v"(cell_at[k]), "v"(pair[b & 1]));
+                    }
                 } else {
-                    act[4 * j] = policy_action<0>(pw, five);
-                    act[4 * j + 1] = policy_action<1>(pw, five);
-                    act[4 * j + 2] = policy_action<2>(pw, five);
-                    act[4 * j + 3] = policy_action<3>(pw, five);
+                    // (the instances that need the action itself -- SoC's STAY count, the four-column table's made-up STAY row)
+                    if constexpr (K == 2) pw >>= 16u * (x.g & 1u);  // the quad is shared with the neighbour lane: bytes 2 (g & 1), + 1
+                    act[K == 2 ? 0 : 4 * j] = policy_action_rt(pw, 0u);
+                    act[K == 2 ? 1 : 4 * j + 1] = policy_action_rt(pw, 1u);
+                    if constexpr (K != 2) {
+                        act[4 * j + 2] = policy_action_rt(pw, 2u);
+                        act[4 * j + 3] = policy_action_rt(pw, 3u);
+                    }
                 }
             }
+            if constexpr (!FAST_POLICY) {
 #pragma unroll
-            for (int k = 0; k < K; ++k) asm volatile("" : "+v"(act[k]));   // (an integer 0..4 from here on: the shift is not folded into the address)
+                for (int k = 0; k < K; ++k) asm volatile("" : "+v"(act[k]));   // (an integer 0..4 from here on: the shift is not folded into the address)
+            }
         }
+        if constexpr (!FAST_POLICY) columns_from_actions();       // (FAST_POLICY: each branch above has formed its columns)
 
-        // --- my agents' table rows (cell * 96 + action * 16, the table's LDS offset is an immediate): requested first ...
+        // --- the rows are requested first ...
         MoveEntry entry[K];
         u32x2 cells_code[K];
         uint32_t delta_row[K];
-        uint32_t cell_at[K];   // (all the word-select multiplies first: back to back with their users each one costs an s_nop)
-#pragma unroll
-        for (int k = 0; k < K; ++k) cell_at[k] = (k & 1) ? half_times<1>(c[k / 2], row_bytes) : half_times<0>(c[k / 2], row_bytes);
-#pragma unroll
-        for (int k = 0; k < K; ++k) asm volatile("" : "+v"(cell_at[k]));
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-            if (COMPACT && BITMAP == 3) delta_row[k] = lds_at<uint32_t>(lds, kMoveAt + (act[k] << 2) + cell_at[k]);
-            else if (COMPACT && BITMAP == 1) cells_code[k] = lds_at<u32x2>(lds, kMoveAt - kCompactEntry + (act[k] << 3) + cell_at[k]);   // column act - 1 (STAY: see below)
-            else if (COMPACT) cells_code[k] = lds_at<u32x2>(lds, kMoveAt + (act[k] << 3) + cell_at[k]);
-            else entry[k] = lds_entry_at(lds, kMoveAt + (act[k] << 4) + cell_at[k]);
+            if (COMPACT && BITMAP == 3) delta_row[k] = lds_at<uint32_t>(lds, kMoveAt + col_at[k]);
+            else if (COMPACT && BITMAP == 1) cells_code[k] = lds_at<u32x2>(lds, kMoveAt - kCompactEntry + col_at[k]);   // column act - 1 (STAY: see below)
+            else if (COMPACT) cells_code[k] = lds_at<u32x2>(lds, kMoveAt + col_at[k]);
+            else entry[k] = lds_entry_at(lds, kMoveAt + col_at[k]);
         }
         STAMP(0);   // loop top: action fetch / policy, table read issue
         // --- ... then the previous step is finished while they are in flight
         if (!FIRST) {
-#ifndef MAPF_EXP_EARLY_FETCH
             if (SYS) chain_fetch(qv);                              // behind the table reads: its factors arrive with the rows
-#endif
             finish_pending(qv);
-#ifdef MAPF_EXP_NO_ADVANCE   // (experiment builds only: every step overwrites row 0, i.e. no HBM write stream)
-            if (false) {
-#else
             if (RECORD) {
-#endif
                 rec_lane += step_cells;
                 // SYS: the last lane's probability rows trail by Q - 1 steps -- its pointer rests on row 0 (which the early,
                 // incomplete products overwrite until the right one arrives) while s < Q; the unrolled loop only runs beyond that
@@ -702,7 +760,11 @@ __global__ void __launch_bounds__(K == 8 ? 512 : 1024) lq_rollout_kernel(const R
         Packed<P> fin;
 #pragma unroll
         for (int i = 0; i < P; ++i) fin.v[i] = c[i];
-        fin.store(at(p.state, lane_cell));
+        // (the address is formed again from the env index -- laundered, so that it is not the kernel's first address kept in
+        // two registers across the whole step loop: the 1024-thread instances have none to spare and would spill it)
+        uint32_t e_end = x.e;
+        asm volatile("" : "+v"(e_end));
+        fin.store(at(p.state, e_end * n_agents + uint32_t(K) * x.g));
     }
     if (leader) {
         if (!HOLD_TOTALS) totals_at(ret_p, epi_p, col_p);
@@ -727,7 +789,9 @@ hipError_t launch_impl(const RolloutArgs &args, uint32_t A, unsigned block, size
     const uint32_t bitmap_base = uint32_t(lds_bytes);           // the bitmaps follow the table
     if (BITMAP) lds_bytes += size_t(block / unsigned(Q)) * bitmap_stride(args.c.n_cells);
     if (lds_bytes > 32 * 1024) {
-        if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), int(kLdsBytes - kLdsReserve))) return e;
+        // (this kernel has no static LDS object: its dynamic segment may be the CU's whole 160 KB -- the limit every form's
+        // "does it fit" test in try_launch_rollout_lq compares against)
+        if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), int(kLdsBytes))) return e;
     }
     const unsigned grid = unsigned(args.n_envs / (block / unsigned(Q)));
     note_kernel("lq_rollout_kernel<Q=%d,K=%d,%s,%s,%s%s%s%s> block=%u (packed layout: %d agents per lane%s%s)", Q, K, RECORD ? "RECORD" : "TOTALS",
@@ -886,12 +950,13 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
         unsigned bitmap_block = 512u;
         if (tune.bitmap_block == 1024u || (tune.bitmap_block == 0u && args.n_envs * 8u >= uint64_t(n_cu) * 1024u)) bitmap_block = 1024u;
         if (bitmap_block == 1024u && (args.n_envs % (1024u / 8u) != 0 || bitmap_lds + (1024u / 8u) * per_env > kLdsBytes)) bitmap_block = 512u;
+        if (args.actions == nullptr) bitmap_block = 512u;           // (in-kernel policy behind 8-byte rows: that instance is built for 512 threads)
         // ... behind 4-byte delta rows where the map's ids allow them (six columns in 79 KB on the 64x64 maps: 128 bitmaps fit, no
         // STAY row to make up, one-instruction action clamp)
-        const size_t delta_lds = kMoveAt + size_t(args.c.n_cells) * kDeltaCols * kDeltaEntry;
+        const size_t delta_lds = kMoveAt + delta_table_words(args.c.n_cells) * kDeltaEntry;   // (the host-built image, zero-padded to 16 bytes)
         unsigned delta_block = (tune.bitmap_block == 1024u || (tune.bitmap_block == 0u && args.n_envs * 8u >= uint64_t(n_cu) * 1024u)) ? 1024u : 512u;
         if (delta_block == 1024u && (args.n_envs % (1024u / 8u) != 0 || delta_lds + (1024u / 8u) * per_env > kLdsBytes)) delta_block = 512u;
-        if (tune.bitmap_pairs && tune.bitmap_delta_rows && args.mv_delta8 && n_agents == 32 && tune.force_k != 8 && tune.force_k != 2 &&
+        if (tune.bitmap_pairs && tune.bitmap_delta_rows && args.mv_delta8 && args.mv4 && n_agents == 32 && tune.force_k != 8 && tune.force_k != 2 &&
             layout_fits(n_agents, 4, args, delta_lds, &block, &Q) && args.n_envs % (delta_block / 8u) == 0 &&
             delta_lds + (delta_block / 8u) * per_env <= kLdsBytes) {
             block = delta_block;

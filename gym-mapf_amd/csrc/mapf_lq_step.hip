@@ -97,7 +97,14 @@ constexpr uint32_t kStepArgsOffset = 5 * 8 + 4 * 4;
 static_assert(kStepArgsOffset % alignof(StepArgs) == 0, "the block follows the leading scalars without padding");
 static_assert(kStepLds <= kStepMoveAt, "LDS image of the BIG form: slip rows, outcome rows, then the move table");
 
-template <int Q, int K, bool SCEN, bool TERM, bool BIG = false>
+// BIG == 2: the same resident grid with the table as 4-BYTE DELTA ROWS (StepArgs::mv4, six columns, 24 bytes per cell): what
+//     lets a 64x64 map's table (79 KB; 316 KB as 16-byte rows) sit in LDS at all.  That is the 32-agent configurations' form:
+//     their plain step is bound by the texture path's line rate too -- 2048 lanes x 4 divergent gathers per CU are ~3.4 us of a
+//     4.9 us launch at 16384 envs (profiles/r05_step_delta_*) -- at every batch size, not just the large ones.  The row gives the
+//     three candidates as signed byte offsets from the lane's own cell and the slip row's offset; the thresholds come from that
+//     row in LDS (a second, dependent LDS read), the sampled cell from one add with a sign-extending byte select
+//     (sample_slot_delta, as in the 32-agent rollout).
+template <int Q, int K, bool SCEN, bool TERM, int BIG = 0>
 __global__ void __launch_bounds__(BIG ? 1024 : 512) lq_step_kernel(uint16_t *const state, const uint8_t *const actions, const uint8_t *const scen,
                                                       const SlipRow *const slip_rows, const uint64_t *const t_dev,
                                                       const uint32_t agents_block, const uint32_t t_lo, const uint32_t seed_lo,
@@ -109,13 +116,42 @@ __global__ void __launch_bounds__(BIG ? 1024 : 512) lq_step_kernel(uint16_t *con
 #endif
     // the kernel's LDS image (mapf_lq.hpp): 1 KB static (the table image: slip rows, outcome rows) reached through the
     // object; the BIG form's image is the dynamic segment -- the move table behind those 1 KB -- used as a raw scratchpad
-    using Image = std::conditional_t<BIG, LdsAbsolute, LdsObject>;
+    using Image = std::conditional_t<BIG != 0, LdsAbsolute, LdsObject>;
     Image lds;
     if constexpr (!BIG) {
         __shared__ __attribute__((aligned(16))) unsigned char lds_static[kStepLds];
         lds.base = (lds_ptr)lds_static;
     }
     const uint32_t n_agents = agents_block & 0xFFu, block_threads = agents_block >> 8;
+    // BIG == 3: ... and per-env ONE-BIT occupancy bitmaps behind the table (bitmap_pair_tests, mapf_lq.hpp: the 32-agent rollout's
+    // O(A) collision tests) -- with the gathers gone the 32-agent step is bound by its 496 agent pairs per env
+    const uint32_t bitmap_stride = (((p_block.c.n_cells + 31u) >> 5) * 4u + 15u) & ~15u;    // bytes per env: one bit per cell
+    const uint32_t bitmap_base = kStepMoveAt + uint32_t(delta_table_words(p_block.c.n_cells)) * 4u;
+    const uint32_t bitmap_at = bitmap_base + (threadIdx.x / uint32_t(Q)) * bitmap_stride;
+    // BIG == 2: the host-built delta rows as they are (StepArgs::mv4), 16 bytes per thread and load, TEN loads in flight -- a
+    // 64x64 map's 79 KB are one round trip for a 512-thread block (in rounds of four loads the copy alone was ~3 us of the
+    // launch) -- requested BEHIND the block's first trip (see the chunk loop), so that state and actions travel with the table
+    auto stage_delta_table = [&]() __attribute__((always_inline)) {
+        constexpr uint32_t kInFlight = 10;
+        const uint32_t n_vec = uint32_t(delta_table_words(p_block.c.n_cells) / 4u);
+        const u32x4 *src = reinterpret_cast<const u32x4 *>(p_block.mv4);
+        for (uint32_t w0 = threadIdx.x; w0 < n_vec; w0 += kInFlight * block_threads) {
+            u32x4 part[kInFlight];
+#pragma unroll
+            for (uint32_t k = 0; k < kInFlight; ++k) part[k] = src[min(w0 + k * block_threads, n_vec - 1u)];
+#pragma unroll
+            for (uint32_t k = 0; k < kInFlight; ++k)
+                if (w0 + k * block_threads < n_vec) *(__attribute__((address_space(3))) u32x4 *)lds_addr(lds, kStepMoveAt + 16u * (w0 + k * block_threads)) = part[k];
+        }
+        if constexpr (BIG == 3) {   // the block's occupancy bitmaps (one per env of a chunk; every use clears what it set)
+            const uint32_t n_words = (block_threads / uint32_t(Q)) * (bitmap_stride >> 2);
+            for (uint32_t w = threadIdx.x; w < n_words; w += block_threads) *(lds_u32)lds_addr(lds, bitmap_base + 4u * w) = 0u;
+        }
+        stage_outcome_table(p_block.c, lds_generic<OutcomeRow>(lds, kStepOutcomeAt));
+        stage_slip_table(slip_rows, lds_generic<SlipRow>(lds, kStepSlipAt));   // ends with __syncthreads()
+    };
+    if constexpr (BIG >= 2) {
+    } else
     if (BIG) {   // move table -> LDS: 16-byte rows, SIX columns per cell (kBigCols: column 5 = STAY again, so that an action byte is
         // extracted and clamped by one v_min_u32 -- in LDS the sixth column costs room, not gather traffic); four independent
         // loads per thread and round; the thresholds bias-shifted as the packed sampling compares them
@@ -237,8 +273,11 @@ __global__ void __launch_bounds__(BIG ? 1024 : 512) lq_step_kernel(uint16_t *con
     uint32_t cur[K], act[K];
     MoveEntry entry[K];
     CompactEntry compact[K];
+    uint32_t delta_row[K];
     const uint32_t last_cell = p.c.n_cells - 1u;
     constexpr uint32_t kCols = BIG ? kBigCols : kMvCols;
+    uint32_t row_bytes = kDeltaCols * 4u, eight = 8u;
+    asm volatile("" : "+v"(row_bytes), "+v"(eight));   // (SDWA operands must be vector registers)
     // the LDS image first (it arrived with the first trip): the plain form reads its thresholds from it right behind the gathers
     if (stager) *(__attribute__((address_space(3))) u32x4 *)lds_addr(lds, 16u * x.lane) = image_word;
 #pragma unroll
@@ -253,7 +292,9 @@ __global__ void __launch_bounds__(BIG ? 1024 : 512) lq_step_kernel(uint16_t *con
         // BIG: 16-byte rows from the LDS copy.  Plain: 8-BYTE rows from global memory (CompactEntry) -- a launch's gathers are
         // bound by the texture path's line rate and every launch re-fetches the table into eight L2s, so half the bytes is
         // what counts; the code's thresholds then come from the slip row in LDS (profiles/r04_step_table_forms.txt)
-        if (BIG) entry[k] = lds_entry_at(lds, kStepMoveAt + row * 16u);
+        // BIG == 2: 4-byte delta rows from the LDS copy, cell * 24 + action * 4 (an out-of-range LDS address reads zeros: no clamp)
+        if (BIG >= 2) delta_row[k] = lds_at<uint32_t>(lds, kStepMoveAt + (act[k] << 2) + ((k & 1) ? half_times<1>(c[k / 2], row_bytes) : half_times<0>(c[k / 2], row_bytes)));
+        else if (BIG) entry[k] = lds_entry_at(lds, kStepMoveAt + row * 16u);
         else compact[k] = p.mv8[row];
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -271,6 +312,16 @@ __global__ void __launch_bounds__(BIG ? 1024 : 512) lq_step_kernel(uint16_t *con
 #pragma unroll
         for (int i = 0; i < P; ++i) asm volatile("" : "+v"(sc[i]));
     }
+    if constexpr (BIG >= 2) {   // the code's thresholds: a second LDS read that depends on the first; the row completes to a MoveEntry
+        uint32_t row_off[K], th[K];
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(row_off[k]) : "v"(delta_row[k]), "v"(eight));
+            th[k] = lds_at<uint32_t>(lds, kStepSlipAt + uint32_t(offsetof(SlipRow, th_biased)) - kDeltaRowBias + row_off[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < K; ++k) entry[k] = make_uint4(delta_row[k], 0u, th[k], row_off[k]);
+    }
     if constexpr (!BIG) {   // complete the rows: thresholds (bias-shifted, as the packed sampling compares them) by the code's row offset
         uint32_t th[K];
 #pragma unroll
@@ -282,7 +333,8 @@ __global__ void __launch_bounds__(BIG ? 1024 : 512) lq_step_kernel(uint16_t *con
 
     // ---- sampling (the fused rollout's packed form): both threshold compares of an agent in one saturating packed
     // subtract, the slot's probability address and cell selector from one dot product each
-    uint32_t pk_eights = 0x00080008u, pk_steps = 0x02020202u, sel_base = 0x0C0C0504u;
+    // (delta rows: the slot selects a byte -- steps of one, the row's byte 2 down to 0, zeros above it)
+    uint32_t pk_eights = 0x00080008u, pk_steps = BIG >= 2 ? 0x00010001u : 0x02020202u, sel_base = BIG >= 2 ? 0x0C0C0C02u : 0x0C0C0504u;
     asm volatile("" : "+v"(pk_eights), "+v"(pk_steps), "+v"(sel_base));
     double q[K];
     uint32_t n[P], word[P], d[K], tie_all = 0u;
@@ -297,10 +349,17 @@ __global__ void __launch_bounds__(BIG ? 1024 : 512) lq_step_kernel(uint16_t *con
         uint32_t q_at[2], cell[2];
         MoveEntry e0 = entry[2 * i], e1 = entry[2 * i + 1];
         // (the thresholds are bias-shifted already: th_biased / the BIG form's LDS copy of the table)
+        if constexpr (BIG >= 2) {
+            d[2 * i] = sample_slot_delta<0>(e0.x, e0.z, e0.w, __builtin_amdgcn_perm(biased, biased, 0x01000100u), pk_eights, pk_steps, sel_base, c[i], q_at[0], cell[0]);
+            d[2 * i + 1] = sample_slot_delta<1>(e1.x, e1.z, e1.w, __builtin_amdgcn_perm(biased, biased, 0x03020302u), pk_eights, pk_steps, sel_base, c[i], q_at[1], cell[1]);
+            q[2 * i] = lds_at<double>(lds, kStepSlipAt + 16u - kDeltaRowBias + q_at[0]);
+            q[2 * i + 1] = lds_at<double>(lds, kStepSlipAt + 16u - kDeltaRowBias + q_at[1]);
+        } else {
         d[2 * i] = sample_slot_packed(e0, __builtin_amdgcn_perm(biased, biased, 0x01000100u), pk_eights, pk_steps, sel_base, q_at[0], cell[0]);
         d[2 * i + 1] = sample_slot_packed(e1, __builtin_amdgcn_perm(biased, biased, 0x03020302u), pk_eights, pk_steps, sel_base, q_at[1], cell[1]);
         q[2 * i] = lds_at<double>(lds, kStepSlipAt + 16u + q_at[0]);
         q[2 * i + 1] = lds_at<double>(lds, kStepSlipAt + 16u + q_at[1]);
+        }
         n[i] = cell[0] | (cell[1] << 16);
         tie_all = i == 0 ? pk_min_u16(d[0], d[1]) : pk_min_u16(tie_all, pk_min_u16(d[2 * i], d[2 * i + 1]));
     }
@@ -318,6 +377,13 @@ __global__ void __launch_bounds__(BIG ? 1024 : 512) lq_step_kernel(uint16_t *con
                 MoveEntry full = entry[k];
                 // (8-byte rows: the list's members, where slip_move_exact_members looks for them, from the code's slip row)
                 if (!BIG) full.y = (full.y & 0xFFFFu) | (lds_at<uint32_t>(lds, kStepSlipAt + uint32_t(offsetof(SlipRow, members)) + full.w) << 19);
+                if (BIG >= 2) {   // the candidates' cells back from their deltas, the members from the slip row
+                    const uint32_t mine = (k & 1) ? c[k / 2] >> 16 : c[k / 2] & 0xFFFFu, row = full.x;
+                    const uint32_t c0 = (mine + uint32_t(int32_t(int8_t(row)))) & 0xFFFFu, c1 = (mine + uint32_t(int32_t(int8_t(row >> 8)))) & 0xFFFFu,
+                                   c2 = (mine + uint32_t(int32_t(int8_t(row >> 16)))) & 0xFFFFu;
+                    full.x = c0 | (c1 << 16);
+                    full.y = c2 | (lds_at<uint32_t>(lds, kStepSlipAt + uint32_t(offsetof(SlipRow, members)) - kDeltaRowBias + full.w) << 19);
+                }
                 slip_move_exact_members(p.c, full, refine_mantissa(p.c, env_id, t, uint32_t(K) * x.g + uint32_t(k), hi), nx, q[k]);
                 n[k / 2] = (k & 1) ? (n[k / 2] & 0xFFFFu) | (nx << 16) : (n[k / 2] & 0xFFFF0000u) | nx;
             }
@@ -326,7 +392,16 @@ __global__ void __launch_bounds__(BIG ? 1024 : 512) lq_step_kernel(uint16_t *con
 
     // ---- is_terminal(prev) and the collision tests in one pass over the agent pairs; the per-env facts as ONE integer
     // code = vertex | swap << 1 | off_goal << 2 | was_terminal << 3 (mapf_env.py:210-223, :225-235, :378-389)
-    const PairAcc<true> acc = packed_pair_tests<Q, P, TERM, true>(x, c, n);
+    PairAcc<true> acc;
+    if constexpr (BIG == 3) {
+        acc = bitmap_pair_tests<Q, K>(x, lds, bitmap_at, c, n);   // (a terminal env's bits are set and cleared like any other's: its outcome row ignores them)
+        if (TERM) {                                                // is_terminal(prev)'s duplicate test stays with the agent pairs
+            const uint32_t none[P] = {};
+            acc.dup = packed_pair_tests<Q, P, true, false>(x, c, none).dup;
+        }
+    } else {
+        acc = packed_pair_tests<Q, P, TERM, true>(x, c, n);
+    }
     uint32_t away_next = n[0] ^ g[0], away_prev = TERM ? c[0] ^ g[0] : 1u;
 #pragma unroll
     for (int i = 1; i < P; ++i) { away_next |= n[i] ^ g[i]; if (TERM) away_prev |= c[i] ^ g[i]; }
@@ -417,6 +492,10 @@ __global__ void __launch_bounds__(BIG ? 1024 : 512) lq_step_kernel(uint16_t *con
         // register move of values still in flight, i.e. a wait for the very loads the prefetch is there to hide.
         const uint32_t stride = gridDim.x;
         FirstTrip a = first_trip(blockIdx.x);
+        if constexpr (BIG >= 2) {
+            __builtin_amdgcn_sched_barrier(0);                           // (the first trip's requests go out ahead of the table's)
+            stage_delta_table();
+        }
 #pragma nounroll
         for (uint32_t chunk = blockIdx.x; chunk < n_chunks; chunk += 2u * stride) {
             const uint32_t second = chunk + stride, third = second + stride;
@@ -478,7 +557,7 @@ bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning 
                     scen ? ",SCEN" : "", term ? "" : ",NO_TERMINAL", scen ? ", start / goal rows from the scenario table" : "");
 #define MAPF_LQ_BIG8(QQ, SS, TT, SCEN_PTR)                                                                                          \
         {                                                                                                                           \
-            auto kern = lq_step_kernel<QQ, 8, SS, TT, true>;                                                                        \
+            auto kern = lq_step_kernel<QQ, 8, SS, TT, 1>;                                                                        \
             if (big_lds > 32u * 1024u) { if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), int(160u * 1024u - 1024u))) { *err = e; return true; } } \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(block), big_lds, stream, args.state, args.actions, SCEN_PTR, args.slip, args.t_dev, \
                                A | (block << 8), uint32_t(args.t), args.c.seed_lo, args.c.seed_hi, args, n_chunks);                 \
@@ -496,13 +575,76 @@ bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning 
 #undef MAPF_LQ_BIG8_Q
 #undef MAPF_LQ_BIG8
     }
+    // The delta-row forms (BIG == 2, 3): where the 16-byte rows do not fit (64x64 maps) but the 4-byte ones do, from a batch of one
+    // full residency on (65536 envs of 32 agents) -- below that the table copy per block (79 KB through the XCD's L2 for each of
+    // its 32 CUs: 1.8 us in front of the first instruction that needs a row, profiles/r05_step_stamps_c5_share.txt) costs more
+    // than the gathers it replaces: configs[4]'s share of one GPU (16384 envs) runs 4.95 us plain against 5.7-5.9 us.
+    const size_t delta_lds = kStepMoveAt + delta_table_words(args.c.n_cells) * sizeof(uint32_t);
+    if (K == 4 && Q <= 8 && args.mv4 && tune.step_delta != 0 && delta_lds <= 160u * 1024u && args.n_envs > 0 &&
+        (tune.step_delta == 2 || (!big_fits && lanes >= resident_lanes))) {
+        // 32 agents: the occupancy bitmaps of a chunk's envs behind the table -- one block per CU then, so 1024 threads as soon as
+        // every CU gets such a block (measured on configs[4]'s map, profiles/r05_step32_forms.txt: 131072 envs 15.6 us with
+        // bitmaps in 1024-thread blocks, 18.0 without, 21.5 for the plain step; at 65536 envs 512-thread blocks with bitmaps
+        // 11.7, without 10.8, plain 11.9)
+        const size_t per_env = (size_t((args.c.n_cells + 31u) / 32u) * 4u + 15u) & ~size_t(15);
+        const bool bitmaps_1024 = Q == 8 && tune.bitmap_pairs && delta_lds + (1024u / 8u) * per_env <= 160u * 1024u && args.n_envs % (1024u / 8u) == 0 &&
+                                  lanes >= uint64_t(n_cu) * 1024u;
+        unsigned block = (bitmaps_1024 || lanes >= 2u * resident_lanes) ? 1024u : 512u;
+        if (args.n_envs % (block / unsigned(Q)) != 0) block = 512u;
+        bool bitmaps = Q == 8 && tune.bitmap_pairs && delta_lds + (block / 8u) * per_env <= 160u * 1024u;
+        if (!bitmaps && Q == 8 && tune.bitmap_pairs && block == 1024u && delta_lds + (512u / 8u) * per_env <= 160u * 1024u) { block = 512u; bitmaps = true; }
+        const size_t form_lds = delta_lds + (bitmaps ? (block / 8u) * per_env : 0u);
+        if (args.n_envs % (block / unsigned(Q)) == 0) {
+            unsigned per_cu = unsigned((160u * 1024u) / form_lds);
+            if (per_cu > 2048u / block) per_cu = 2048u / block;
+            const unsigned n_chunks = unsigned(lanes / block), grid = n_chunks < per_cu * unsigned(n_cu) ? n_chunks : per_cu * unsigned(n_cu);
+            note_kernel("lq_step_kernel<Q=%d,K=%d%s%s,DELTA%s> block=%u resident grid (packed layout: 4 agents per lane, 4-byte delta rows of the move table in LDS%s%s)", Q, K,
+                        scen ? ",SCEN" : "", term ? "" : ",NO_TERMINAL", bitmaps ? ",BITMAP" : "", block, bitmaps ? ", collisions through per-env occupancy bitmaps" : "",
+                        scen ? ", start / goal rows from the scenario table" : "");
+            if (bitmaps) {   // (Q == 8)
+#define MAPF_LQ_DELTA_BITMAP(SS, TT, SCEN_PTR)                                                                                      \
+                {                                                                                                                   \
+                    auto kern = lq_step_kernel<8, 4, SS, TT, 3>;                                                                    \
+                    if (form_lds > 32u * 1024u) { if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), int(160u * 1024u))) { *err = e; return true; } } \
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(block), form_lds, stream, args.state, args.actions, SCEN_PTR, args.slip, args.t_dev, \
+                                       A | (block << 8), uint32_t(args.t), args.c.seed_lo, args.c.seed_hi, args, n_chunks);         \
+                }
+                if (scen && term) MAPF_LQ_DELTA_BITMAP(true, true, args.scen)
+                else if (scen) MAPF_LQ_DELTA_BITMAP(true, false, args.scen)
+                else if (term) MAPF_LQ_DELTA_BITMAP(false, true, no_scen)
+                else MAPF_LQ_DELTA_BITMAP(false, false, no_scen)
+#undef MAPF_LQ_DELTA_BITMAP
+                *err = hipGetLastError();
+                return true;
+            }
+#define MAPF_LQ_DELTA(QQ, SS, TT, SCEN_PTR)                                                                                         \
+            {                                                                                                                       \
+                auto kern = lq_step_kernel<QQ, 4, SS, TT, 2>;                                                                       \
+                if (delta_lds > 32u * 1024u) { if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), int(160u * 1024u))) { *err = e; return true; } } \
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(block), delta_lds, stream, args.state, args.actions, SCEN_PTR, args.slip, args.t_dev, \
+                                   A | (block << 8), uint32_t(args.t), args.c.seed_lo, args.c.seed_hi, args, n_chunks);             \
+            }
+#define MAPF_LQ_DELTA_Q(QQ)                                                                      \
+            if (Q == QQ) {                                                                        \
+                if (scen && term) MAPF_LQ_DELTA(QQ, true, true, args.scen)                        \
+                else if (scen) MAPF_LQ_DELTA(QQ, true, false, args.scen)                          \
+                else if (term) MAPF_LQ_DELTA(QQ, false, true, no_scen)                            \
+                else MAPF_LQ_DELTA(QQ, false, false, no_scen)                                     \
+                *err = hipGetLastError();                                                         \
+                return true;                                                                      \
+            }
+            MAPF_LQ_DELTA_Q(1) MAPF_LQ_DELTA_Q(2) MAPF_LQ_DELTA_Q(4) MAPF_LQ_DELTA_Q(8)
+#undef MAPF_LQ_DELTA_Q
+#undef MAPF_LQ_DELTA
+        }
+    }
     if (big) {
         const unsigned block = 1024u, n_chunks = unsigned(lanes / block), grid = n_chunks < 2u * unsigned(n_cu) ? n_chunks : 2u * unsigned(n_cu);
         note_kernel("lq_step_kernel<Q=%d,K=%d%s%s,BIG> block=1024 resident grid (packed layout: 4 agents per lane, move table in LDS%s)", Q, K,
                     scen ? ",SCEN" : "", term ? "" : ",NO_TERMINAL", scen ? ", start / goal rows from the scenario table" : "");
 #define MAPF_LQ_BIG(QQ, SS, TT, SCEN_PTR)                                                                                           \
         {                                                                                                                           \
-            auto kern = lq_step_kernel<QQ, 4, SS, TT, true>;                                                                        \
+            auto kern = lq_step_kernel<QQ, 4, SS, TT, 1>;                                                                        \
             if (big_lds > 32u * 1024u) { if (hipError_t e = allow_large_lds(reinterpret_cast<const void *>(kern), int(160u * 1024u - 1024u))) { *err = e; return true; } } \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(block), big_lds, stream, args.state, args.actions, SCEN_PTR, args.slip, args.t_dev, \
                                A | (block << 8), uint32_t(args.t), args.c.seed_lo, args.c.seed_hi, args, n_chunks);                 \

@@ -130,7 +130,10 @@ __global__ void __launch_bounds__(1024) scan_block_totals_kernel(uint64_t *block
         if (threadIdx.x == 0u) carry_s += all;
         __syncthreads();
     }
-    if (threadIdx.x == 0u && out_total) *out_total = carry_s;
+    if (threadIdx.x == 0u) {
+        block_total[n] = carry_s;                                  // (the array has n + 1 entries)
+        if (out_total) *out_total = carry_s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------- A <= 8
@@ -147,8 +150,13 @@ struct QueryHeader {
 };
 static_assert(sizeof(QueryHeader) == kQueryHeader, "one ds_read_b128 + one ds_read_b64");
 
-template <int MAXA>
-__global__ void __launch_bounds__(256) transitions_rows_kernel(const TransitionsArgs p, const uint32_t qw_log2) {
+// ALL_OUT: every output array is given (what the Python wrapper and the bench pass): no per-array branches around the stores.
+// A batch (the QW queries of a wave) whose windows hold more than `rows_per_wave` rows is cut into PIECES, one wave each
+// (pieces_max > 1: the scan has run, a wave whose piece lies beyond its batch's rows leaves at once) -- a room map's 8-agent
+// queries have 1 to 6561 branches, and with whole batches per wave the longest waves decided the launch's length.
+template <int MAXA, bool ALL_OUT>
+__global__ void __launch_bounds__(256) transitions_rows_kernel(const TransitionsArgs p, const uint32_t qw_log2, const uint32_t pieces_max,
+                                                               const uint32_t rows_per_wave) {
     static_assert(MAXA <= 10, "a choice set is 3 bits per agent in one 32-bit word");
     __shared__ SlipRow slip[8];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
@@ -159,9 +167,21 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
     unsigned char *const wave_lds = lds_dyn + (threadIdx.x >> 6) * (QW * (kQueryBytes + 4u));
     uint32_t *const prefix = reinterpret_cast<uint32_t *>(wave_lds);                     // [QW] exclusive prefix of the windows' lengths
     unsigned char *const queries = wave_lds + QW * 4u;                                     // [QW] header + records
-    const uint64_t q0 = ((uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6) << qw_log2;
+    const uint64_t wave = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    uint64_t batch = wave;
+    uint32_t piece = 0u;
+    if (pieces_max > 1u) { batch = wave / pieces_max; piece = uint32_t(wave - batch * pieces_max); }
+    const uint64_t q0 = batch << qw_log2;
     if (q0 >= p.n_queries) return;                                 // (wave-uniform)
     const uint32_t A = p.n_agents;
+    const uint32_t row_begin = piece * rows_per_wave;              // my piece of the batch's rows
+    uint64_t base = 0;                                             // first row of the batch in the compacted arrays
+    if (p.compact || pieces_max > 1u) {
+        const uint64_t q1 = q0 + QW, blocks = (p.n_queries + kScanBlock - 1) / kScanBlock;
+        base = p.block_base[q0 / kScanBlock] + p.rel[q0];
+        const uint64_t end = q1 < p.n_queries ? p.block_base[q1 / kScanBlock] + p.rel[q1] : p.block_base[blocks];
+        if (pieces_max > 1u && piece > 0u && uint64_t(row_begin) >= end - base) return;   // (piece 0 stays: it reports the counts)
+    }
 
     // ---- set-up: lane l < QW owns query q0 + l
     uint32_t rows = 0u;
@@ -202,7 +222,7 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
                 for (int j = i + 1; j < MAXA; ++j) dup_acc = min(dup_acc, prev[i] ^ prev[j]);
             const bool terminal = dup_acc == 0u || goal_acc == 0u;     // is_terminal: mapf_env.py:210-223
             if (terminal) count = 1u;
-            if (p.out_count) p.out_count[q] = count;
+            if (p.out_count && piece == 0u) p.out_count[q] = count;
             uint32_t lo;
             rows = window_rows(count, p.first_branch, p.max_branches, lo);
             hdr.first = lo;
@@ -236,12 +256,8 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
     if (lane < QW) prefix[lane] = incl - rows;
     const uint32_t total = uint32_t(__shfl(int(incl), 63, 64));
     // compacted rows: the wave's queries are consecutive, so their rows are one contiguous range from the first one's offset
-    const bool compact = p.rel != nullptr;
-    uint64_t base = 0;
-    if (compact) {
-        base = p.block_base[q0 / kScanBlock] + p.rel[q0];
-        if (p.out_offset && lane < QW && q0 + lane < p.n_queries) p.out_offset[q0 + lane] = base + (incl - rows);
-    }
+    const bool compact = p.compact;
+    if (compact && piece == 0u && p.out_offset && lane < QW && q0 + lane < p.n_queries) p.out_offset[q0 + lane] = base + (incl - rows);
     // (the wave's lanes wrote the records / prefix sums the others read below: same wave, LDS operations execute in order)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -249,9 +265,10 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
 
     // ---- emission: one lane per row of the wave's windows
     const double r_clash = p.c.r_clash, r_goal = p.c.r_goal;
-    for (uint32_t r0 = 0; r0 < total; r0 += 64u) {
+    const uint32_t row_end = (pieces_max > 1u && total - row_begin > rows_per_wave && row_begin < total) ? row_begin + rows_per_wave : total;
+    for (uint32_t r0 = row_begin; r0 < row_end; r0 += 64u) {
         const uint32_t r = r0 + lane;
-        const bool valid = r < total;
+        const bool valid = r < row_end;
         uint32_t pos = 0u;                                         // the row's query: the last one whose prefix is <= r
         for (uint32_t step = QW >> 1; step != 0u; step >>= 1) {
             const uint32_t cand = pos + step;
@@ -285,7 +302,7 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
         const double reward = terminal ? 0.0 : (coll ? __dadd_rn(r_clash, living) : (goal_next ? __dadd_rn(r_goal, living) : living));
         const uint64_t o = compact ? base + r : (q0 + pos) * uint64_t(p.max_branches) + j;
         if (valid && o < p.capacity) {
-            if (p.out_next) {
+            if (ALL_OUT || p.out_next) {
                 uint16_t *dst = p.out_next + o * A;
                 if (A == uint32_t(MAXA)) {                          // a full team: one store per row (rows are 2 MAXA bytes apart)
                     if constexpr (MAXA == 8) *reinterpret_cast<uint4 *>(dst) = make_uint4(cells[0] | cells[1] << 16, cells[2] | cells[3] << 16, cells[4] | cells[5] << 16, cells[6] | cells[7] << 16);
@@ -300,10 +317,10 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
                         if (uint32_t(i) < A) dst[i] = uint16_t(cells[i]);
                 }
             }
-            if (p.out_prob) p.out_prob[o] = prob;
-            if (p.out_reward) p.out_reward[o] = reward;
-            if (p.out_done) p.out_done[o] = (terminal || coll || goal_next) ? 1 : 0;
-            if (p.out_collision) p.out_collision[o] = (coll && !terminal) ? 1 : 0;
+            if (ALL_OUT || p.out_prob) p.out_prob[o] = prob;
+            if (ALL_OUT || p.out_reward) p.out_reward[o] = reward;
+            if (ALL_OUT || p.out_done) p.out_done[o] = (terminal || coll || goal_next) ? 1 : 0;
+            if (ALL_OUT || p.out_collision) p.out_collision[o] = (coll && !terminal) ? 1 : 0;
         }
     }
 }
@@ -387,7 +404,7 @@ __global__ void __launch_bounds__(256) transitions_kernel(const TransitionsArgs 
     const uint32_t piece_end = chunk < p.max_branches - piece_begin ? piece_begin + chunk : p.max_branches;
     // the query's first output row: reserved rows, or its offset in the compacted arrays
     uint64_t row0 = q * p.max_branches;
-    if (p.rel) {
+    if (p.compact) {
         row0 = p.block_base[q / kScanBlock] + p.rel[q];
         if (piece == 0u && lane == 0u && p.out_offset) p.out_offset[q] = row0;
     }
@@ -492,12 +509,14 @@ hipError_t launch_transition_rewards(const TransitionsArgs &args, const uint16_t
 
 uint64_t transitions_scan_blocks(uint64_t n_queries) { return (n_queries + kScanBlock - 1) / kScanBlock; }
 
-// compacted output, passes 1 and 2: rel[q] / block_base[] (see TransitionsArgs) and the total number of rows
-hipError_t launch_transitions_offsets(const TransitionsArgs &args, uint32_t *rel, uint64_t *block_base, uint64_t *out_total, hipStream_t stream) {
+// passes 1 and 2: args.rel / args.block_base (see TransitionsArgs), the total to args.out_offset[N] when compacting; also fills
+// args.out_count
+static hipError_t launch_transitions_offsets(const TransitionsArgs &args, hipStream_t stream) {
     const uint64_t blocks = transitions_scan_blocks(args.n_queries);
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return blocks == 0 ? hipSuccess : hipErrorInvalidValue;
-    hipLaunchKernelGGL(transitions_count_kernel, dim3(unsigned(blocks)), dim3(kScanBlock), 0, stream, args, rel, block_base);
-    hipLaunchKernelGGL(scan_block_totals_kernel, dim3(1), dim3(1024), 0, stream, block_base, uint32_t(blocks), out_total);
+    hipLaunchKernelGGL(transitions_count_kernel, dim3(unsigned(blocks)), dim3(kScanBlock), 0, stream, args, args.rel, args.block_base);
+    hipLaunchKernelGGL(scan_block_totals_kernel, dim3(1), dim3(1024), 0, stream, args.block_base, uint32_t(blocks),
+                       (args.compact && args.out_offset) ? args.out_offset + args.n_queries : nullptr);
     return hipGetLastError();
 }
 
@@ -509,13 +528,26 @@ static hipError_t launch_rows(const TransitionsArgs &args, hipStream_t stream) {
     uint32_t qw_log2 = 6;
     while (qw_log2 > 2 && 4u * (kQueryBytes + 4u) * (1u << qw_log2) > 36u * 1024u) --qw_log2;
     while (qw_log2 > 2 && (args.n_queries >> qw_log2) < 16384u) --qw_log2;
-    const uint64_t waves = (args.n_queries + (1u << qw_log2) - 1) >> qw_log2;
+    // rows per wave: a batch's windows can hold QW x min(3^A, max_branches) rows; beyond 4096 (64 sweeps; 1024 while the
+    // queries are few) they are cut into pieces -- which needs the scan, as compacted rows do
+    uint64_t most = 1;
+    for (uint32_t i = 0; i < args.n_agents && most < args.max_branches; ++i) most *= 3u;
+    if (most > args.max_branches) most = args.max_branches;
+    most <<= qw_log2;
+    const uint32_t rows_per_wave = args.n_queries >= 16384u ? 4096u : 1024u;
+    const uint32_t pieces_max = most > 2u * rows_per_wave ? uint32_t((most + rows_per_wave - 1) / rows_per_wave) : 1u;
+    if (args.compact || pieces_max > 1u) {
+        if (hipError_t e = launch_transitions_offsets(args, stream)) return e;
+    }
+    const uint64_t waves = ((args.n_queries + (1u << qw_log2) - 1) >> qw_log2) * pieces_max;
     const uint64_t grid64 = (waves + 3) / 4;
     if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const size_t lds = 4u * size_t(kQueryBytes + 4u) * (size_t(1) << qw_log2);
-    note_kernel("transitions_rows_kernel<%d> %u agents, %u queries per wave, %s rows", MAXA, args.n_agents, 1u << qw_log2,
-                args.rel ? "compacted" : "reserved");
-    hipLaunchKernelGGL(transitions_rows_kernel<MAXA>, dim3(unsigned(grid64)), dim3(256), lds, stream, args, qw_log2);
+    const bool all_out = args.out_next && args.out_prob && args.out_reward && args.out_done && args.out_collision;
+    note_kernel("transitions_rows_kernel<%d> %u agents, %u queries per wave%s, %s rows", MAXA, args.n_agents, 1u << qw_log2,
+                pieces_max > 1u ? (rows_per_wave == 4096u ? " in pieces of 4096 rows" : " in pieces of 1024 rows") : "", args.compact ? "compacted" : "reserved");
+    if (all_out) hipLaunchKernelGGL((transitions_rows_kernel<MAXA, true>), dim3(unsigned(grid64)), dim3(256), lds, stream, args, qw_log2, pieces_max, rows_per_wave);
+    else hipLaunchKernelGGL((transitions_rows_kernel<MAXA, false>), dim3(unsigned(grid64)), dim3(256), lds, stream, args, qw_log2, pieces_max, rows_per_wave);
     return hipGetLastError();
 }
 
@@ -525,6 +557,9 @@ hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream) {
     if (args.n_agents <= 4) return launch_rows<4>(args, stream);
     if (args.n_agents <= 6) return launch_rows<6>(args, stream);
     if (args.n_agents <= 8) return launch_rows<8>(args, stream);
+    if (args.compact) {
+        if (hipError_t e = launch_transitions_offsets(args, stream)) return e;
+    }
     // lanes per group: a wave; a group walks up to 16 x lanes rows, a long window is cut into that many-row chunks (so
     // that a single query of a large team still fills the device)
     uint32_t lanes_log2 = 0;
@@ -538,7 +573,7 @@ hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream) {
     if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
     const dim3 grid{unsigned(grid64)}, block{256};
     note_kernel("transitions_kernel<%d,EXACT> %u agents, %u lanes x %u rows per group, %u groups per query, %s rows", int(args.n_agents),
-                args.n_agents, lanes, walks, chunks_per_query, args.rel ? "compacted" : "reserved");
+                args.n_agents, lanes, walks, chunks_per_query, args.compact ? "compacted" : "reserved");
     switch (args.n_agents) {
 #define X(N) case N: hipLaunchKernelGGL((transitions_kernel<N, true>), grid, block, 0, stream, args, lanes_log2, chunk, chunks_per_query); break;
         X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)

@@ -532,9 +532,14 @@ def _full_size_check(grid, nbr, A, start, goal, fail_prob, crit, ocrit, n_step, 
     policy stream and (n_streamed > 0) a recorded rollout with streamed actions.  want_step / want_rollout: substrings the
     dispatched kernel names must contain (the test is ABOUT that kernel instance)."""
     E = start.shape[0]
+    # the oracle steps on ITS OWN neighbour table, built from the map's text (mapf_env.py:43-94 restated in oracle/mapf_oracle.py):
+    # on maps without a golden an error of the product's table builder would otherwise be shared by both sides
+    lines = [''.join('@' if f else '.' for f in row) for row in grid.obstacles.tolist()]
+    own_nbr = np.asarray(mo.neighbour_table(lines), np.uint16)
+    assert np.array_equal(nbr, own_nbr)
     env = VecMapfEnv(grid, A, None, None, fail_prob, -1000.0, 100.0, -1.0, crit, seed=42, start_local=start,
                      goal_local=goal, kernel=kernel, env_id_offset=env_id_offset)
-    co = c_oracle.COracle(nbr, A, start, goal, fail_prob, -1000.0, 100.0, -1.0, ocrit, seed=42, env_id_offset=env_id_offset)
+    co = c_oracle.COracle(own_nbr, A, start, goal, fail_prob, -1000.0, 100.0, -1.0, ocrit, seed=42, env_id_offset=env_id_offset)
     ids = env_id_offset + np.arange(E)
     for t in range(n_step):
         acts = philox.random_actions_np(42, ids, t, A)
@@ -557,10 +562,20 @@ def _full_size_check(grid, nbr, A, start, goal, fail_prob, crit, ocrit, n_step, 
             assert np.array_equal(_bits(res['reward'][k]), _bits(ref['reward'])) and np.array_equal(_bits(res['prob'][k]), _bits(ref['prob'])), k
             assert np.array_equal(res['done'][k], ref['done']) and np.array_equal(res['collision'][k], ref['collision']), k
         assert np.array_equal(env.get_state()[0], co.state)
-    res = env.rollout(n_roll, auto_reset=True, record=True)          # in-kernel policy stream, recorded
-    ref = co.rollout(n_roll, auto_reset=True)
-    assert np.array_equal(_bits(res['returns']), _bits(ref['returns']))
-    assert np.array_equal(res['episodes'], ref['episodes']) and np.array_equal(res['collisions'], ref['collisions'])
+    t_pol = env.t
+    res = env.rollout(n_roll, auto_reset=True, record=True)          # in-kernel policy stream, recorded ...
+    returns, episodes, collisions = np.zeros(E), np.zeros(E, np.uint32), np.zeros(E, np.uint32)
+    for k in range(n_roll):                                           # ... and compared step by step, every env
+        acts = philox.random_actions_np(42, ids, t_pol + k, A)        # (what the kernel must have drawn: key seed + 1)
+        ref = co.step(acts, auto_reset=True)
+        assert np.array_equal(res['local'][k], ref['local']), k
+        assert np.array_equal(_bits(res['reward'][k]), _bits(ref['reward'])) and np.array_equal(_bits(res['prob'][k]), _bits(ref['prob'])), k
+        assert np.array_equal(res['done'][k], ref['done']) and np.array_equal(res['collision'][k], ref['collision']), k
+        returns = returns + ref['reward']
+        episodes += ref['done']
+        collisions += ref['collision']
+    assert np.array_equal(_bits(res['returns']), _bits(returns))
+    assert np.array_equal(res['episodes'], episodes) and np.array_equal(res['collisions'], collisions)
     assert np.array_equal(env.get_state()[0], co.state)
     # size-independent properties of the recorded trajectory
     assert np.array_equal(res['done'].sum(0), res['episodes']) and np.array_equal(res['collision'].sum(0), res['collisions'])
@@ -602,7 +617,8 @@ def test_large_map_maze128_32agents_16384_envs(monkeypatch, criteria):
     assert n > 100                                                # (32 agents leaving one scenario's start cells do collide)
 
 
-@pytest.mark.parametrize('criteria,delta_rows', [('Makespan', True), ('SoC', True), ('Makespan', False), ('SoC', False)])
+@pytest.mark.parametrize('criteria,delta_rows', [('Makespan', True), ('SoC', True), ('Makespan', False), ('SoC', False),
+                                                 ('Makespan', 'step'), ('SoC', 'step'), ('Makespan', 'step_pairs')])
 def test_reference_room64_maps_32agents_under_default_dispatch(monkeypatch, criteria, delta_rows):
     """32 agents on the reference's own 64x64 room maps (room-64-64-16: 3646 free cells, room-64-64-8: 3232; scenarios that
     construct with 32 agents), 8192 envs over several scenarios each: the occupancy-bitmap / systolic-chain form of the packed
@@ -612,6 +628,16 @@ def test_reference_room64_maps_32agents_under_default_dispatch(monkeypatch, crit
     monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
     if not delta_rows:
         monkeypatch.setenv('MAPF_BITMAP_DELTA', '0')
+    # 'step': the single step's LDS table of delta rows too, with the occupancy bitmaps behind it (by default only from a batch
+    # that fills the device on; these 8192 envs take the scenario-table instances of it, which the per-env rows of configs[4]
+    # never reach); 'step_pairs': the same table with all agent pairs (MAPF_BITMAP_PAIRS=0)
+    want_step = 'lq_step_kernel<Q=8,K=4'
+    if delta_rows in ('step', 'step_pairs'):
+        monkeypatch.setenv('MAPF_STEP_DELTA', '2')
+        want_step = 'lq_step_kernel<Q=8,K=4,SCEN,NO_TERMINAL,DELTA,BITMAP> block=512'
+        if delta_rows == 'step_pairs':
+            monkeypatch.setenv('MAPF_BITMAP_PAIRS', '0')
+            want_step = 'lq_step_kernel<Q=8,K=4,SCEN,NO_TERMINAL,DELTA> block=512'
     crit, ocrit = (OptimizationCriteria.SoC, mo.SOC) if criteria == 'SoC' else (OptimizationCriteria.Makespan, mo.MAKESPAN)
     for map_name, want in (('room-64-64-16', ',BITMAP> block=512'), ('room-64-64-8', ',BITMAP5> block=512')):
         want = ',BITMAPD> block=512' if delta_rows else want
@@ -626,13 +652,26 @@ def test_reference_room64_maps_32agents_under_default_dispatch(monkeypatch, crit
                 break
         assert len(scen_ids) >= 2, (map_name, scen_ids)
         grid, nbr, start, goal = _scen_tables(map_name, scen_ids, 32, 8192)
-        n = _full_size_check(grid, nbr, 32, start, goal, 0.2, crit, ocrit, 3, 16, want_step='lq_step_kernel<Q=8,K=4',
+        n = _full_size_check(grid, nbr, 32, start, goal, 0.2, crit, ocrit, 3, 16, want_step=want_step,
                              want_rollout='lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,%s,COMPACT' % ('SOC' if criteria == 'SoC' else 'MAKESPAN'),
                              n_streamed=16)
         assert n > 50, (map_name, n)
         env = VecMapfEnv(grid, 32, None, None, 0.2, -1000.0, 100.0, -1.0, crit, seed=42, start_local=start, goal_local=goal)
-        env.rollout(4, auto_reset=True, record=True)
-        assert want in env.last_kernel('rollout'), (map_name, env.last_kernel('rollout'))
+        if delta_rows not in ('step', 'step_pairs'):
+            env.rollout(4, auto_reset=True, record=True)
+            assert want in env.last_kernel('rollout'), (map_name, env.last_kernel('rollout'))
+        else:   # ... and the instance WITH is_terminal(prev): steps without auto-reset (finished episodes stay terminal)
+            co = c_oracle.COracle(nbr, 32, start, goal, 0.2, -1000.0, 100.0, -1.0, ocrit, seed=42)
+            for t in range(6):
+                acts = philox.random_actions_np(42, np.arange(8192), t, 32)
+                local, reward, done, info = env.step(acts, auto_reset=False)
+                ref = co.step(acts, auto_reset=False)
+                assert np.array_equal(local, ref['local']) and np.array_equal(done, ref['done']), t
+                assert np.array_equal(_bits(reward), _bits(ref['reward'])) and np.array_equal(_bits(info['prob']), _bits(ref['prob'])), t
+                assert np.array_equal(info['collision'], ref['collision']) and np.array_equal(info['was_terminal'], ref['was_terminal']), t
+            seen = env.last_kernel('step')
+            assert seen.startswith(want_step.replace(',NO_TERMINAL', '').split('>')[0]) and 'NO_TERMINAL' not in seen, seen
+            assert int(ref['was_terminal'].sum()) > 0                # terminal envs were stepped
         env.close()
 
 
@@ -726,7 +765,8 @@ def test_config5_bench_tables_16384_envs_under_default_dispatch(monkeypatch):
     assert np.array_equal(whole[3][64:], start[:4096]) and np.array_equal(whole[4][64:], goal[:4096])
     assert all(len(set(r.tolist())) == cfg['agents'] for r in start[:512])
     assert _full_size_check(grid, nbr, cfg['agents'], start, goal, cfg['fail_prob'], OptimizationCriteria.Makespan,
-                            mo.MAKESPAN, 4, 16, env_id_offset=offset) > 500
+                            mo.MAKESPAN, 4, 16, env_id_offset=offset,
+                            want_step='lq_step_kernel<Q=8,K=4,NO_TERMINAL> block=') > 500   # (below one residency: the plain step, table rows gathered)
 
 
 def test_config5_whole_131072_envs_under_default_dispatch(monkeypatch):
@@ -739,7 +779,7 @@ def test_config5_whole_131072_envs_under_default_dispatch(monkeypatch):
     grid, _, nbr, start, goal = bench.workload_tables(cfg, cfg['envs'], 0)
     assert _full_size_check(grid, nbr, cfg['agents'], start, goal, cfg['fail_prob'], OptimizationCriteria.Makespan, mo.MAKESPAN, 2, 8,
                             want_rollout='lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAPD> block=1024',
-                            n_streamed=8) > 4000
+                            want_step='lq_step_kernel<Q=8,K=4,NO_TERMINAL,DELTA,BITMAP> block=1024', n_streamed=8) > 4000
 
 
 def test_tall_map_keeps_eight_byte_rows_behind_the_bitmaps(monkeypatch):

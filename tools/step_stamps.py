@@ -2,7 +2,7 @@
 """Where a packed single step (lq_step_kernel) spends its time: per-wave stage stamps from the diagnostic build
 (`make -C gym-mapf_amd/csrc step_stamps` -> lib/variants/libmapf_hip_step_stamps.so; never shipped).
 
-    MAPF_HIP_LIB=.../lib/variants/libmapf_hip_step_stamps.so python tools/step_stamps.py [n_envs] [graph|plain]
+    MAPF_HIP_LIB=.../lib/variants/libmapf_hip_step_stamps.so python tools/step_stamps.py [n_envs] [graph|plain] [c3|c4|c5]
 
 Every wave records s_memrealtime (100 MHz, chip-wide) at entry and exit and s_memtime (shader cycles) at the stages
 in between, each stage stamp behind a full wait for the memory operations issued so far.  The waits make this build a
@@ -21,7 +21,7 @@ from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv  # noqa: 
 
 E = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 mode = sys.argv[2] if len(sys.argv) > 2 else 'graph'
-cfg = bench.CONFIGS['c3']
+cfg = bench.CONFIGS[sys.argv[3] if len(sys.argv) > 3 else 'c3']
 A = cfg['agents']
 grid, _, nbr, start, goal = bench.workload_tables(cfg, E, 0)
 env = VecMapfEnv(grid, A, None, None, cfg['fail_prob'], -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=42,
