@@ -181,6 +181,9 @@ struct TransitionsArgs {
 constexpr int kTransitionsMaxAgents = 16;   // 3^16 = 43 M branches per query, returned in windows
 hipError_t launch_transitions(const TransitionsArgs &args, hipStream_t stream);
 uint64_t transitions_scan_blocks(uint64_t n_queries);
+// calc_transition_reward_from_local_states for N (prev = args.local, args.actions, next) triples; fills
+// args.out_reward / out_done / out_collision [N] (max_branches, out_count, out_next, out_prob unused)
+hipError_t launch_transition_rewards(const TransitionsArgs &args, const uint16_t *next, hipStream_t stream);
 
 hipError_t launch_step(int n_agents, const StepArgs &args, hipStream_t stream);
 hipError_t launch_rollout(int n_agents, const RolloutArgs &args, hipStream_t stream);

@@ -194,27 +194,34 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
             const uint16_t *goal_row = p.goal + (p.goal_broadcast ? 0 : env * A);
             const uint16_t *state_row = p.local + q * A;
             const uint8_t *act_row = p.actions + q * A;
-            uint32_t prev[MAXA], goal[MAXA], n[MAXA], cell[MAXA][3];
-            double prob[MAXA][3];
-            uint32_t count = 1u, dup_acc = 0xFFFFFFFFu, goal_acc = 0u;
+            // (each agent's records are written as soon as its list is known -- cells, off-goal bits, probabilities -- and only
+            // the cells stay in registers for the conflict masks, which are filled in afterwards: held all at once, the 24
+            // probabilities alone were 48 registers and the kernel lost a wave per SIMD to its set-up)
+            uint32_t prev[MAXA], n[MAXA], cell[MAXA][3];
+            uint32_t count = 1u, dup_acc = 0xFFFFFFFFu, goal_acc = 0u, off_goal_prev = 0u;
             int stayed = 0;
 #pragma unroll
             for (int i = 0; i < MAXA; ++i) {
                 const bool on = uint32_t(i) < A;
                 prev[i] = on ? state_row[i] : 0x10000u + uint32_t(i);   // absent agents: unique cells, never equal to a real one
-                goal[i] = on ? goal_row[i] : prev[i];
+                const uint32_t goal = on ? goal_row[i] : prev[i];
                 const uint32_t a = on ? act_row[i] : 0u, act = a > 4u ? 0u : a;
                 const MoveEntry entry = on ? move_entry(p.mv, p.c.n_cells, prev[i], act) : MoveEntry{0u, 0u, 0u, 7u * uint32_t(sizeof(SlipRow))};
                 const SlipRow &row = slip[on ? entry_code(entry) : 7u];
                 n[i] = on ? row.n : 1u;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
-                    cell[i][k] = on ? entry_cell(entry, uint32_t(k)) : prev[i];
-                    prob[i][k] = on ? row.q[k] : 1.0;               // (x * 1.0 is exact: absent agents leave the product alone)
+                    const uint32_t c = on ? entry_cell(entry, uint32_t(k)) : prev[i];
+                    const double pr = on ? row.q[k] : 1.0;          // (x * 1.0 is exact: absent agents leave the product alone)
+                    *reinterpret_cast<uint4 *>(mine + kQueryHeader + (3 * i + k) * kRecord) =
+                        make_uint4((c & 0xFFFFu) | (c != goal ? 0x10000u : 0u), 0u, uint32_t(__double2loint(pr)), uint32_t(__double2hiint(pr)));
+                    // for the conflict masks: an entry past the list's end (never chosen) gets a cell nothing can equal
+                    cell[i][k] = uint32_t(k) < n[i] ? c : 0x20000u + uint32_t(3 * i + k);
                 }
                 count *= n[i];
-                goal_acc |= prev[i] ^ goal[i];
-                stayed += (on && prev[i] == goal[i] && act == 0u) ? 1 : 0;
+                goal_acc |= prev[i] ^ goal;
+                off_goal_prev |= (prev[i] != goal ? 1u : 0u) << i;
+                stayed += (on && prev[i] == goal && act == 0u) ? 1 : 0;
             }
 #pragma unroll
             for (int i = 0; i < MAXA; ++i)
@@ -229,25 +236,31 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
             hdr.terminal = terminal ? 1u : 0u;
             hdr.living = p.c.criteria == 1u ? __dmul_rn(double(int(A) - stayed), p.c.r_living) : p.c.r_living;
 #pragma unroll
-            for (int i = 0; i < MAXA; ++i) {
-                hdr.radix |= (terminal ? 1u : n[i]) << (2 * i);
+            for (int i = 0; i < MAXA; ++i) hdr.radix |= (terminal ? 1u : n[i]) << (2 * i);
+            if (terminal) {   // the single branch ((1.0, False), s, 0, True): every agent's one entry is its own cell, probability 1.0
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    // entry k of agent i against every entry of every later agent: vertex (same next cell) or swap (each moves
-                    // onto the other's current cell) -- _is_collision_transition_from_local_states, mapf_env.py:378-389
-                    uint32_t mask = 0u;
+                for (int i = 0; i < MAXA; ++i)
+                    *reinterpret_cast<uint4 *>(mine + kQueryHeader + (3 * i) * kRecord) =
+                        make_uint4((prev[i] & 0xFFFFu) | (((off_goal_prev >> i) & 1u) << 16), 0u, 0u, 0x3FF00000u);
+            } else {
 #pragma unroll
-                    for (int j = i + 1; j < MAXA; ++j)
+                for (int i = 0; i < MAXA; ++i)
 #pragma unroll
-                        for (int kj = 0; kj < 3; ++kj) {
-                            const bool hit = cell[i][k] == cell[j][kj] || (prev[i] == cell[j][kj] && prev[j] == cell[i][k]);
-                            mask |= (hit && uint32_t(kj) < n[j]) ? 1u << (3 * j + kj) : 0u;
-                        }
-                    const uint32_t c = terminal ? prev[i] : cell[i][k];
-                    const double pr = terminal ? 1.0 : prob[i][k];
-                    *reinterpret_cast<uint4 *>(mine + kQueryHeader + (3 * i + k) * kRecord) =
-                        make_uint4((c & 0xFFFFu) | (c != goal[i] ? 0x10000u : 0u), terminal ? 0u : mask, uint32_t(__double2loint(pr)), uint32_t(__double2hiint(pr)));
-                }
+                    for (int k = 0; k < 3; ++k) {
+                        // entry k of agent i against every entry of every later agent: vertex (same next cell) or swap (each moves
+                        // onto the other's current cell) -- _is_collision_transition_from_local_states, mapf_env.py:378-389
+                        uint32_t mask = 0u;
+#pragma unroll
+                        for (int j = i + 1; j < MAXA; ++j)
+#pragma unroll
+                            for (int kj = 0; kj < 3; ++kj) {
+                                // (integer arithmetic: as booleans the 252 tests of a query live in scalar mask pairs and spill them;
+                                // entries past a list's end were given cells no agent can have, so no length test is needed)
+                                const uint32_t t = min(cell[i][k] ^ cell[j][kj], (prev[i] ^ cell[j][kj]) | (prev[j] ^ cell[i][k]));
+                                mask |= ((t - 1u) >> 31) << (3 * j + kj);   // t == 0 <=> they collide (t < 2^31)
+                            }
+                        *reinterpret_cast<uint32_t *>(mine + kQueryHeader + (3 * i + k) * kRecord + 4) = mask;
+                    }
             }
         }
         *reinterpret_cast<QueryHeader *>(mine) = hdr;
@@ -527,7 +540,7 @@ static hipError_t launch_rows(const TransitionsArgs &args, hipStream_t stream) {
     // device short of waves (16 per SIMD queued) -- set-up uses one lane per query, so small teams want many per wave
     uint32_t qw_log2 = 6;
     while (qw_log2 > 2 && 4u * (kQueryBytes + 4u) * (1u << qw_log2) > 36u * 1024u) --qw_log2;
-    while (qw_log2 > 2 && (args.n_queries >> qw_log2) < 16384u) --qw_log2;
+    while (qw_log2 > (MAXA >= 8 ? 2u : 3u) && (args.n_queries >> qw_log2) < 16384u) --qw_log2;
     // rows per wave: a batch's windows can hold QW x min(3^A, max_branches) rows; beyond 4096 (64 sweeps; 1024 while the
     // queries are few) they are cut into pieces -- which needs the scan, as compacted rows do
     uint64_t most = 1;
@@ -535,19 +548,25 @@ static hipError_t launch_rows(const TransitionsArgs &args, hipStream_t stream) {
     if (most > args.max_branches) most = args.max_branches;
     most <<= qw_log2;
     const uint32_t rows_per_wave = args.n_queries >= 16384u ? 4096u : 1024u;
+
     const uint32_t pieces_max = most > 2u * rows_per_wave ? uint32_t((most + rows_per_wave - 1) / rows_per_wave) : 1u;
     if (args.compact || pieces_max > 1u) {
         if (hipError_t e = launch_transitions_offsets(args, stream)) return e;
     }
     const uint64_t waves = ((args.n_queries + (1u << qw_log2) - 1) >> qw_log2) * pieces_max;
-    const uint64_t grid64 = (waves + 3) / 4;
+    // waves per block: ONE for the large teams -- their waves live for very different times (a piece that does not exist leaves
+    // at once, a full one sweeps 64 times) and a block keeps its place until its last wave is done: four waves per block
+    // measured 0.407 ms against 0.277 ms at 8 agents x 20000 queries (profiles/r05_transitions_launch_shapes.txt); the small
+    // teams' waves all do the same work and share a block's slip table
+    const unsigned wpb = MAXA >= 6 ? 1u : 4u;
+    const uint64_t grid64 = (waves + wpb - 1) / wpb;
     if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const size_t lds = 4u * size_t(kQueryBytes + 4u) * (size_t(1) << qw_log2);
+    const size_t lds = wpb * size_t(kQueryBytes + 4u) * (size_t(1) << qw_log2);
     const bool all_out = args.out_next && args.out_prob && args.out_reward && args.out_done && args.out_collision;
     note_kernel("transitions_rows_kernel<%d> %u agents, %u queries per wave%s, %s rows", MAXA, args.n_agents, 1u << qw_log2,
                 pieces_max > 1u ? (rows_per_wave == 4096u ? " in pieces of 4096 rows" : " in pieces of 1024 rows") : "", args.compact ? "compacted" : "reserved");
-    if (all_out) hipLaunchKernelGGL((transitions_rows_kernel<MAXA, true>), dim3(unsigned(grid64)), dim3(256), lds, stream, args, qw_log2, pieces_max, rows_per_wave);
-    else hipLaunchKernelGGL((transitions_rows_kernel<MAXA, false>), dim3(unsigned(grid64)), dim3(256), lds, stream, args, qw_log2, pieces_max, rows_per_wave);
+    if (all_out) hipLaunchKernelGGL((transitions_rows_kernel<MAXA, true>), dim3(unsigned(grid64)), dim3(64 * wpb), lds, stream, args, qw_log2, pieces_max, rows_per_wave);
+    else hipLaunchKernelGGL((transitions_rows_kernel<MAXA, false>), dim3(unsigned(grid64)), dim3(64 * wpb), lds, stream, args, qw_log2, pieces_max, rows_per_wave);
     return hipGetLastError();
 }
 
