@@ -41,10 +41,19 @@ time of that region.  Rank 0 prints ONE JSON line.  Keys beyond the contract:
                 calls issued one by one from the host (host-enqueue bound)
   per_gpu_shapes   the one-GPU shares of configs[3] (32768 envs x 8 agents) and configs[4] (16384 envs x 32 agents): the same
                 fused launch, HIP-event time of 3 x 10 launches each (default configuration only)
+  policy_rollout   the headline launch with actions = NULL: the in-kernel policy stream (one Philox call per agent quad per four
+                steps, a byte per action) stands in for the caller's `a = policy(s)`; same recording, same roofline contract
+  baseline_configs   multi-rank runs only (and --force-dist): configs[3] (262144 envs x 8 agents) and configs[4] (131072 x 32)
+                sharded over THIS run's ranks in block-aligned shards -- per config: value (all ranks' agent-steps / max-over-
+                ranks time), rank 0's roofline.frac, kernel, shards, the gather of the returns, rank 0's shard against the C oracle
+  transitions   env.P[s][a] (mapf_transitions_compact): branches/s and written bytes / HIP-event time of 8 agents x 20000 and
+                4 agents x 2 M random queries on room-32-32-4 (2A + 18 bytes per branch; an HBM-write-bound kernel by contract)
   scalar_env    the reference's own regime (configs[0]: empty-8-8, 2 agents, slip 0, ONE env): MapfEnv.step()
                 calls per second through the drop-in class, beside the reference's build-container figure
   cpu_baseline  the pure-Python restatement of the reference (oracle/, kind "port") timed on this box's host
-                cores on a bounded sample (rank 0, N=1 only), the real reference's build-container rate beside it
+                cores on a bounded sample (rank 0, N=1 only), the real reference's build-container rate beside it;
+                `all_cores` = N = usable host cores independent processes of the C port and of the Python port (summed rates:
+                the whole-host figure; measured before this process touches the GPU)
   parity        bit-exact check of the first steps of this very run against the C oracle
 """
 import argparse
@@ -235,6 +244,90 @@ def cpu_baseline(cfg, budget_s=12.0):
     ref = reference_cpu_figures()
     if ref:
         out["reference_build_container"] = ref
+    return out
+
+
+def usable_cores():
+    """Host cores this process may actually use: os.cpu_count() cut down by the affinity mask and the cgroup's CPU quota (a GPU
+    box hands one GPU's job a share of the host, not all of it)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    for path in ('/sys/fs/cgroup/cpu.max', '/sys/fs/cgroup/cpu/cpu.cfs_quota_us'):
+        try:
+            with open(path) as f:
+                fields = f.read().split()
+            if path.endswith('cpu.max'):
+                if fields[0] != 'max':
+                    n = min(n, max(1, int(float(fields[0]) / float(fields[1]) + 0.999)))
+            else:
+                quota = int(fields[0])
+                if quota > 0:
+                    with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f:
+                        n = min(n, max(1, int(quota / float(f.read().split()[0]) + 0.999)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_worker(kind, config, seconds, index):
+    """One process of the whole-host CPU figure (python bench.py --cpu-worker KIND CONFIG SECONDS INDEX): the C port (kind 'c')
+    or the pure-Python port ('py') of the reference's step on its own slice of the workload, for `seconds`; prints
+    "<agent-steps> <elapsed seconds>"."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import mapf_oracle as mo
+    cfg = CONFIGS[config]
+    A = cfg['agents']
+    if kind == 'c':
+        import c_oracle
+        E = 4096
+        grid, lines, nbr, start, goal = workload_tables(cfg, E, index * E)
+        co = c_oracle.COracle(nbr, A, start, goal, cfg['fail_prob'], R_CLASH, R_GOAL, R_LIVING, mo.MAKESPAN, seed=SEED, env_id_offset=index * E)
+        co.rollout(4)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            co.rollout(16)
+            n += 16 * E * A
+    else:
+        import philox
+        grid, lines, nbr, start, goal = workload_tables(cfg, 1, index)
+        valid = grid.tables()[0]
+        env = mo.OracleEnv(lines, A, [valid[c] for c in start[0]], [valid[c] for c in goal[0]], cfg['fail_prob'], R_CLASH, R_GOAL, R_LIVING, mo.MAKESPAN)
+        chunk = 1000
+        acts = [philox.random_actions_np(SEED, [index], t, A)[0].tolist() for t in range(chunk)]
+        us = [philox.slip_uniforms_np(SEED, [index], t, A)[0].tolist() for t in range(chunk)]
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            for a, u in zip(acts, us):
+                if env.step(a, u)[2]:
+                    env.reset()
+            n += chunk * A
+    print(n, time.perf_counter() - t0, flush=True)
+
+
+def cpu_all_cores(config, seconds_c=4.0, seconds_py=6.0):
+    """The whole-host figure north_star words as "the same box's host cores": N = usable_cores() independent processes of the
+    plain-C port, then of the pure-Python port (the reference has no internal parallelism, so N processes is what its user
+    would run), each on its own envs of the same workload, for a bounded time.  MUST run before this process touches the GPU
+    (the workers are child programs).  Returns the dict that goes into cpu_baseline['all_cores']."""
+    n = usable_cores()
+    out = {"cores": n, "host_cpu_count": os.cpu_count(), "unit": "agent-steps/s"}
+    for kind, seconds, key in (('c', seconds_c, 'c_port'), ('py', seconds_py, 'python_port')):
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), '--cpu-worker', kind, config, str(seconds), str(i)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for i in range(n)]
+        total = 0.0
+        for p in procs:
+            try:
+                txt = p.communicate(timeout=seconds * 5 + 120)[0].decode().split()
+                total += float(txt[0]) / float(txt[1])
+            except Exception:
+                p.kill()
+        out[key] = total
+    out["sample"] = ("%d processes x (%g s of oracle/mapf_oracle.c on 4096 envs each, then %g s of oracle/mapf_oracle.py on one env each), "
+                     "%s workload; summed rates" % (n, seconds_c, seconds_py, CONFIGS[config]['map']))
     return out
 
 
@@ -580,6 +673,7 @@ def main():
     ap.add_argument('--no-baseline-configs', action='store_true',
                     help='multi-rank runs: skip the baseline_configs leg (configs[3] and configs[4] sharded over the ranks)')
     ap.add_argument('--baseline-config-steps', type=int, default=10, help='launches per timed block of the baseline_configs leg')
+    ap.add_argument('--no-transitions', action='store_true', help='skip the transitions leg (env.P enumeration)')
     ap.add_argument('--no-policy-rollout', action='store_true', help='skip the policy_rollout leg (the same batch with actions = NULL)')
     ap.add_argument('--kernel', default='auto', choices=['auto', 'thread_per_env', 'lane_group'])
     ap.add_argument('--dist-backend', default='nccl', choices=['nccl', 'gloo'],
@@ -591,10 +685,18 @@ def main():
     ap.add_argument('--repeats', type=int, default=5, help='timed blocks of --steps steps each; value = their median')
     ap.add_argument('--rank-timeout', type=float, default=900.0,
                     help='self-launched ranks (--gpus N without a launcher) are all terminated after this many seconds')
+    ap.add_argument('--cpu-worker', nargs=4, metavar=('KIND', 'CONFIG', 'SECONDS', 'INDEX'), default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
+    if args.cpu_worker:
+        cpu_worker(args.cpu_worker[0], args.cpu_worker[1], float(args.cpu_worker[2]), int(args.cpu_worker[3]))
+        return
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         spawn_ranks(args.gpus, args.rank_timeout)
+    # the whole-host CPU figure runs FIRST: its workers are child programs, which a process may only start before it touches the GPU
+    all_cores = None
+    if args.gpus == 1 and not args.force_dist and not args.no_cpu_baseline and int(os.environ.get('WORLD_SIZE', '1')) == 1:
+        all_cores = cpu_all_cores(args.config)
 
     # stdout carries ONE JSON line: whatever libraries print while they initialise (gloo's rank banner, ...) goes to stderr
     sys.stdout.flush()
@@ -903,8 +1005,15 @@ def main():
             # the same batch with the policy ON the device: mapf_rollout(actions = NULL), trajectory recorded
             line["policy_rollout"] = per_gpu_shape_rate(args.config, E, T=T, n_launch=20, blocks=5, policy=True)
             line["policy_rollout"]["vs_streamed_hip_events"] = line["policy_rollout"]["value"] / line["value_hip_events"]
+        if world == 1 and not args.no_side_legs and not args.no_transitions and args.envs is None and args.config == 'c3':
+            # env.P[s][a]: every branch of random queries, compacted rows; a write-bound kernel by contract
+            line["transitions"] = {"a8_q20000": transitions_rate(8, 20000, compact=True), "a4_q2000000": transitions_rate(4, 2000000, compact=True),
+                                   "a8_q20000_reserved_rows": transitions_rate(8, 20000, compact=False)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
+            if all_cores is not None:
+                line["cpu_baseline"]["all_cores"] = all_cores
+                line["cpu_baseline"]["gpu_over_all_cores_c_port"] = value / all_cores["c_port"] if all_cores.get("c_port") else None
         sys.stdout.flush()
         os.dup2(json_fd, 1)
         print(json.dumps(line), flush=True)

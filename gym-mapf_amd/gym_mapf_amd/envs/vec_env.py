@@ -288,15 +288,20 @@ class VecMapfEnv:
     _MAX_ARRAY_BYTES = (1 << 32) - 1
     _MAX_LAUNCH_STEPS = 65535
 
-    def rollout(self, n_steps, actions=None, auto_reset=True, record=False, accumulate_into=None):
+    def rollout(self, n_steps, actions=None, auto_reset=True, record=False, accumulate_into=None, out=None):
         """``n_steps`` fused steps.  ``actions`` uint8 [T, E, A] or None for the on-device policy.  Returns a dict with
         ``returns`` f64 [E], ``episodes`` u32 [E], ``collisions`` u32 [E] and, when ``record``, the per-step
         ``local``/``reward``/``done``/``collision``/``prob`` trajectories (step-major).  One launch when every array
         of the call stays below 4 GiB and T <= 65535 (the C ABI's limits); otherwise the steps are issued as a few
-        launches over consecutive slices of the same arrays (totals accumulate, the trajectory is identical)."""
+        launches over consecutive slices of the same arrays (totals accumulate, the trajectory is identical).
+        ``out``: the dict an earlier call of the same shape returned -- its arrays are written again instead of allocating
+        eight new ones per call (totals overwritten, unlike ``accumulate_into``); a training loop that calls
+        ``rollout(T=16..64)`` thousands of times wants this (profiles/r05_rollout_T_sweep.txt)."""
         E, A, T = self.n_envs, self.n_agents, int(n_steps)
         actions = self._coerce(actions, np.uint8, (T, E, A), 'actions')
-        res = accumulate_into if accumulate_into is not None else {}
+        if out is not None and accumulate_into is not None:
+            raise ValueError('pass either out= (overwrite) or accumulate_into= (add), not both')
+        res = accumulate_into if accumulate_into is not None else (out if out is not None else {})
         for name, dt in (('returns', np.float64), ('episodes', np.uint32), ('collisions', np.uint32)):
             if name not in res:
                 res[name] = self._empty((E,), dt)
@@ -304,7 +309,8 @@ class VecMapfEnv:
             for name, dt, shp in (('local', np.uint16, (T, E, A)), ('reward', np.float64, (T, E)),
                                   ('done', np.uint8, (T, E)), ('collision', np.uint8, (T, E)),
                                   ('prob', np.float64, (T, E))):
-                res[name] = self._empty(shp, dt)
+                if out is None or name not in res or tuple(res[name].shape) != shp:
+                    res[name] = self._empty(shp, dt)
         per_step = max(E * A * 2, E * 8) if (record or actions is not None) else 0    # bytes of the widest per-step row
         t_max = min(self._MAX_LAUNCH_STEPS, self._MAX_ARRAY_BYTES // per_step if per_step else self._MAX_LAUNCH_STEPS)
         if T > 0 and t_max < 1:

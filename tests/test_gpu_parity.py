@@ -128,6 +128,31 @@ def test_rollout_split_equals_single_and_accumulates(trajectory_set):
     one.close(), two.close()
 
 
+def test_rollout_out_reuses_an_earlier_calls_arrays(trajectory_set):
+    """rollout(out=previous result): the same arrays are written again (no allocation per call -- what a training loop with
+    short rollouts wants), totals OVERWRITTEN; the values are those of a fresh call."""
+    meta, g = trajectory_set
+    lo, hi = _id_runs(g['env_ids'])[0]
+    sel = np.arange(lo, hi)
+    T = min(meta['T'], 12)
+    auto = bool(meta['auto_reset'])
+    a, b = _vec(meta, g, sel), _vec(meta, g, sel)
+    first = a.rollout(T, auto_reset=auto, record=True)
+    ids = {k: id(v) for k, v in first.items()}
+    keep = {k: v.copy() for k, v in first.items()}
+    again = a.rollout(T, auto_reset=auto, record=True, out=first)             # steps T .. 2T-1, into the same arrays
+    assert again is first and {k: id(v) for k, v in again.items()} == ids
+    b.rollout(T, auto_reset=auto, record=True)
+    fresh = b.rollout(T, auto_reset=auto, record=True)
+    for k in fresh:
+        assert np.array_equal(_bits(again[k]) if again[k].dtype == np.float64 else again[k],
+                              _bits(fresh[k]) if fresh[k].dtype == np.float64 else fresh[k]), k
+    assert any(not np.array_equal(keep[k], again[k]) for k in ('local', 'returns'))
+    with pytest.raises(ValueError):
+        a.rollout(T, auto_reset=auto, out=first, accumulate_into=first)
+    a.close(), b.close()
+
+
 def test_scripted_edge_cases_match_reference():
     """Hand-picked uniforms: all-False argmax, merges, swap-not-sticky, terminal no-ops, SoC rules,
     exotic fail_prob.  Driven through reset/set_state as the reference run did."""
