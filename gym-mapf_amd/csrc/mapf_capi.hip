@@ -381,7 +381,11 @@ int mapf_create(const mapf_desc *d, mapf_handle_t *out_handle) {
     else if (d->flags & MAPF_FLAG_LANE_GROUP) h->lane_group = true;
     else h->lane_group = A > 2;
     h->lane_group_rollout = h->lane_group || A > uint32_t(mapf::kTpeRolloutMaxAgents);
-    h->tune = mapf::default_rollout_tuning(d->device);
+    {
+        std::string tune_error;
+        h->tune = mapf::default_rollout_tuning(d->device, &tune_error);
+        if (!tune_error.empty()) { destroy_impl(h); return fail(MAPF_EINVAL, tune_error); }
+    }
     h->mv_delta8 = true;
     for (uint32_t v = 0; v < V && h->mv_delta8; ++v)
         for (uint32_t a = 0; a < 5; ++a) {

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string>
 
 namespace mapf {
 
@@ -206,28 +207,28 @@ constexpr int kTpeMaxAgents = 16;         // thread-per-env step kernels are spe
 #define MAPF_TPE_ROLLOUT_MAX 6
 #endif
 constexpr int kTpeRolloutMaxAgents = MAPF_TPE_ROLLOUT_MAX;   // ... their rollout form is dispatched only where it is spill-free
-// Layout choices of the fused rollout, fixed per handle at mapf_create (environment overrides are read there, so a
-// process can hold handles with different settings -- the tests do).
+// Layout choices of the kernels, fixed per handle at mapf_create (the MAPF_TUNE override -- "key=value,..." -- is read
+// there, so a process can hold handles with different settings: the tests do).  The key of each field is named beside it.
 struct RolloutTuning {
-    bool quad_lanes = true;          // MAPF_QUAD_LANES=0 forces the pair layout
-    uint64_t quad_min_lanes = 0;     // four agents per lane need at least this many lanes (MAPF_QUAD_MIN_LANES; default: one
+    bool quad_lanes = true;          // quad_lanes=0 forces the pair layout
+    uint64_t quad_min_lanes = 0;     // four agents per lane need at least this many lanes (quad_min_lanes; default: one
                                      // wave on every SIMD of the device); below that two agents per lane
-    uint64_t oct_min_lanes = 0;      // eight agents per lane need at least this many lanes (MAPF_OCT_MIN_LANES; default:
+    uint64_t oct_min_lanes = 0;      // eight agents per lane need at least this many lanes (oct_min_lanes; default:
                                      //   two waves on every SIMD)
-    int force_k = 0;                 // MAPF_LQ_K=2|4|8 pins the agents per lane of the packed layout (tests)
-    size_t mv_lds_max_bytes = 0;     // largest move table staged into LDS (MAPF_MV_LDS_MAX_BYTES; default: two blocks per CU)
-    bool bitmap_pairs = true;        // MAPF_BITMAP_PAIRS=0: the 32-agent rollout keeps the all-pairs collision tests (tests compare both)
-    bool bitmap_delta_rows = true;   // MAPF_BITMAP_DELTA=0: the bitmap form never uses the 4-byte delta rows (tests compare the tables)
-    bool bitmap_stay_column = true;  // MAPF_BITMAP_STAYCOL=0: the bitmap form always stages the four-column table (tests)
-    unsigned bitmap_block = 0;       // MAPF_BITMAP_BLOCK=512|1024: block size of the bitmap form (experiments / tests; 0 = by batch)
-    int step_big = 1;                // MAPF_STEP_BIG: the packed single step's resident-grid / LDS-table form -- 0 never, 1 for batches
+    int force_k = 0;                 // k=2|4|8 pins the agents per lane of the packed layout (tests)
+    size_t mv_lds_max_bytes = 0;     // largest move table staged into LDS (mv_lds_max_bytes; default: two blocks per CU)
+    bool bitmap_pairs = true;        // bitmap_pairs=0: the 32-agent rollout keeps the all-pairs collision tests (tests compare both)
+    bool bitmap_delta_rows = true;   // bitmap_delta=0: the bitmap form never uses the 4-byte delta rows (tests compare the tables)
+    bool bitmap_stay_column = true;  // bitmap_staycol=0: the bitmap form always stages the four-column table (tests)
+    unsigned bitmap_block = 0;       // bitmap_block=512|1024: block size of the bitmap form (experiments / tests; 0 = by batch)
+    int step_big = 1;                // step_big: the packed single step's resident-grid / LDS-table form -- 0 never, 1 for batches
                                      //   of at least four times what the device holds at once (default), 2 whenever it fits (tests)
-    unsigned step_block = 0;         // MAPF_STEP_BLOCK=64|128|256|512: block size of the plain packed single step (experiments; 0 = by batch)
-    int step_delta = 1;              // MAPF_STEP_DELTA: the single step's LDS table of 4-byte delta rows -- 0 never, 1 where the 16-byte rows
+    unsigned step_block = 0;         // step_block=64|128|256|512: block size of the plain packed single step (experiments; 0 = by batch)
+    int step_delta = 1;              // step_delta: the single step's LDS table of 4-byte delta rows -- 0 never, 1 where the 16-byte rows
                                      //   do not fit and the batch gives every CU a block (default), 2 whenever it fits (tests, experiments)
-    bool scen_table = true;          // MAPF_SCEN_TABLE=0: never build the scenario table (StepArgs::scen) -- tests compare both forms
+    bool scen_table = true;          // scen_table=0: never build the scenario table (StepArgs::scen) -- tests compare both forms
 };
-RolloutTuning default_rollout_tuning(int device);
+RolloutTuning default_rollout_tuning(int device, std::string *err);   // (reads MAPF_TUNE: mapf_lg_rollout.hip)
 hipError_t launch_step_lg(int n_agents, const StepArgs &args, const RolloutTuning &tune, hipStream_t stream);
 // packed layout of the single step (mapf_lq_step.hip): true when it took the launch (*err = its status)
 bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err);

@@ -2,6 +2,7 @@
 #include "mapf_lg.hpp"
 
 #include <cstdlib>
+#include <string>
 
 namespace mapf {
 
@@ -242,28 +243,50 @@ static_assert(sizeof(SlipRow) * 8 + sizeof(OutcomeRow) * 16 <= kLdsReserve, "sta
 
 // Defaults of the layout choices: a move table is staged into LDS while two blocks per CU still fit (a table that
 // allows only one block per CU starves the SIMDs of waves); four agents per lane need one wave on every SIMD.
-RolloutTuning default_rollout_tuning(int device) {
+// ONE override: the environment variable MAPF_TUNE, "key=value,key=value,...", read here -- at handle creation, so a process
+// can hold handles with different settings (the tests and the A/B tools do).  Keys (include/mapf_hip.h documents them):
+//   quad_lanes, k, quad_min_lanes, oct_min_lanes, mv_lds_max_bytes, scen_table, bitmap_pairs, bitmap_block, bitmap_staycol,
+//   bitmap_delta, step_big, step_block, step_delta.
+// An unknown key or a malformed item is an error (*err names it): a typo must not silently measure the default.
+RolloutTuning default_rollout_tuning(int device, std::string *err) {
     RolloutTuning t;
-    if (const char *e = getenv("MAPF_QUAD_LANES")) t.quad_lanes = atoi(e) != 0;
     int n_cu = 256;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) n_cu = 256;
     // measured on 8 agents x 32768 envs (one wave per SIMD with four agents per lane, two with two): 517 G vs 467 G
     // agent-steps/s -- fewer, fatter waves win as long as no SIMD stays empty
     t.quad_min_lanes = uint64_t(n_cu) * 4u * 64u;        // CUs x SIMDs x lanes
-    if (const char *e = getenv("MAPF_LQ_K")) t.force_k = atoi(e);
-    if (const char *e = getenv("MAPF_QUAD_MIN_LANES")) t.quad_min_lanes = uint64_t(strtoull(e, nullptr, 10));
     t.oct_min_lanes = uint64_t(n_cu) * 4u * 64u * 2u;    // (eight agents per lane: see try_launch_rollout_lq)
-    if (const char *e = getenv("MAPF_OCT_MIN_LANES")) t.oct_min_lanes = uint64_t(strtoull(e, nullptr, 10));
     t.mv_lds_max_bytes = (kLdsBytes - kLdsReserve) / 2;
-    if (const char *e = getenv("MAPF_MV_LDS_MAX_BYTES")) t.mv_lds_max_bytes = size_t(strtoull(e, nullptr, 10));
-    if (const char *e = getenv("MAPF_SCEN_TABLE")) t.scen_table = atoi(e) != 0;
-    if (const char *e = getenv("MAPF_BITMAP_PAIRS")) t.bitmap_pairs = atoi(e) != 0;
-    if (const char *e = getenv("MAPF_BITMAP_BLOCK")) t.bitmap_block = unsigned(atoi(e));
-    if (const char *e = getenv("MAPF_BITMAP_STAYCOL")) t.bitmap_stay_column = atoi(e) != 0;
-    if (const char *e = getenv("MAPF_BITMAP_DELTA")) t.bitmap_delta_rows = atoi(e) != 0;
-    if (const char *e = getenv("MAPF_STEP_BIG")) t.step_big = atoi(e);
-    if (const char *e = getenv("MAPF_STEP_BLOCK")) t.step_block = unsigned(atoi(e));
-    if (const char *e = getenv("MAPF_STEP_DELTA")) t.step_delta = atoi(e);
+    const char *text = getenv("MAPF_TUNE");
+    if (!text) return t;
+    std::string items(text);
+    size_t pos = 0;
+    while (pos <= items.size()) {
+        size_t end = items.find(',', pos);
+        if (end == std::string::npos) end = items.size();
+        const std::string item = items.substr(pos, end - pos);
+        pos = end + 1;
+        if (item.empty()) continue;
+        const size_t eq = item.find('=');
+        char *rest = nullptr;
+        const std::string key = item.substr(0, eq), val = eq == std::string::npos ? "" : item.substr(eq + 1);
+        const unsigned long long v = val.empty() ? 0 : strtoull(val.c_str(), &rest, 10);
+        if (eq == std::string::npos || val.empty() || (rest && *rest)) { if (err) *err = "MAPF_TUNE: malformed item '" + item + "' (want key=integer)"; return t; }
+        if (key == "quad_lanes") t.quad_lanes = v != 0;
+        else if (key == "k") t.force_k = int(v);
+        else if (key == "quad_min_lanes") t.quad_min_lanes = v;
+        else if (key == "oct_min_lanes") t.oct_min_lanes = v;
+        else if (key == "mv_lds_max_bytes") t.mv_lds_max_bytes = size_t(v);
+        else if (key == "scen_table") t.scen_table = v != 0;
+        else if (key == "bitmap_pairs") t.bitmap_pairs = v != 0;
+        else if (key == "bitmap_block") t.bitmap_block = unsigned(v);
+        else if (key == "bitmap_staycol") t.bitmap_stay_column = v != 0;
+        else if (key == "bitmap_delta") t.bitmap_delta_rows = v != 0;
+        else if (key == "step_big") t.step_big = int(v);
+        else if (key == "step_block") t.step_block = unsigned(v);
+        else if (key == "step_delta") t.step_delta = int(v);
+        else { if (err) *err = "MAPF_TUNE: unknown key '" + key + "'"; return t; }
+    }
     return t;
 }
 

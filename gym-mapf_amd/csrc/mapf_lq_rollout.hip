@@ -113,37 +113,67 @@ __global__ void __launch_bounds__((K == 8 || (COMPACT && BITMAP == 1 && !STREAM)
 #pragma unroll
         for (int i = 0; i < P; ++i) { c[i] = cells.v[i]; g[i] = gl.v[i]; start_c[i] = sc.v[i]; }
     }
+    // (requested HERE, with the state / goal / start rows and ahead of the table copy: a launch's fixed cost -- 8-12 us, a third
+    // of a T = 32 launch, profiles/r05_rollout_T_sweep.txt -- is mostly memory round trips in a row, so they travel together)
+    const uint8_t *act_lane = STREAM ? p.actions + lane_cell : nullptr;
+
+    // Action words are fetched kAhead steps ahead of their use (four with four agents per lane, eight with two, whose
+    // steps are shorter): the loaded-HBM round trip, with the trajectory stores of the same wave queued in front of it
+    // (vmcnt counts loads and stores in order), is longer than two steps -- fetched two ahead, the two-agents-per-lane
+    // form ran 23 % slower than with L2-resident actions, the wait for the action word being the largest stall left.
+    // Invariant at the top of step s: raw[j] holds row s+j (j < kAhead), act_lane points at row min(s+kAhead-1, last).
+    // A step consumes the register that holds its row and reloads THAT register with row s+kAhead, so in the unrolled
+    // part of the loop the registers simply take turns (rotating a register through a move would be a use, i.e. a
+    // wait); a single step outside it uses raw[0] and shifts the others down afterwards.
+    constexpr uint32_t kAhead = K == 2 ? 8 : 4;
+    using RawWord = std::conditional_t<K == 8, uint64_t, uint32_t>;   // one action byte per agent of the lane
+    const uint32_t last_row = p.n_steps ? p.n_steps - 1u : 0u;
+    auto load_raw = [&]() __attribute__((always_inline)) {
+        if constexpr (K == 8) return *reinterpret_cast<const uint64_t *>(act_lane);
+        else return K == 4 ? *reinterpret_cast<const uint32_t *>(act_lane) : uint32_t(*reinterpret_cast<const uint16_t *>(act_lane));
+    };
+    RawWord raw[kAhead] = {};
+    if (STREAM && p.n_steps > 0) {
+        raw[0] = load_raw();
+#pragma unroll
+        for (uint32_t j = 1; j < kAhead; ++j) {
+            act_lane += last_row >= j ? uint64_t(uint32_t(p.n_envs)) * n_agents : 0u;   // clamped, not guarded: late rows are re-read
+            raw[j] = load_raw();
+        }
+    }
     if constexpr (COMPACT && BITMAP == 3) {
-        // the host-built delta rows (RolloutArgs::mv4) as they are: 16 bytes per thread and load, four loads in flight (the
+        // the host-built delta rows (RolloutArgs::mv4) as they are: 16 bytes per thread and load, ten loads in flight (the
         // 16-byte rows this form was first staged from are 13 times the bytes: 263 KB per block against 79 KB on a 64x64 map)
         const uint32_t n_vec = uint32_t(delta_table_words(p.c.n_cells) / 4u);
         const u32x4 *src = reinterpret_cast<const u32x4 *>(p.mv4);
-        for (uint32_t w0 = threadIdx.x; w0 < n_vec; w0 += 4u * blockDim.x) {
-            u32x4 part[4];
+        constexpr uint32_t kInFlight = 10;                         // (79 KB of a 64x64 map: one round trip for a 512-thread block)
+        for (uint32_t w0 = threadIdx.x; w0 < n_vec; w0 += kInFlight * blockDim.x) {
+            u32x4 part[kInFlight];
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) part[k] = src[min(w0 + k * blockDim.x, n_vec - 1u)];
+            for (uint32_t k = 0; k < kInFlight; ++k) part[k] = src[min(w0 + k * blockDim.x, n_vec - 1u)];
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k)
+            for (uint32_t k = 0; k < kInFlight; ++k)
                 if (w0 + k * blockDim.x < n_vec) *(__attribute__((address_space(3))) u32x4 *)lds_addr(lds, kMoveAt + 16u * (w0 + k * blockDim.x)) = part[k];
         }
     } else
     {   // move table -> LDS with six columns per cell (0..4 = the actions, 5 = STAY again: where out-of-range action
-        // bytes are clamped to), batches of four independent loads per thread
+        // bytes are clamped to), batches of eight independent loads per thread
         // (COMPACT: five columns, the first 8 bytes of every row)
         // (COMPACT + BITMAP == 1: FOUR columns -- the moves; a STAY row is (cell, cell, cell) with the all-equal code and is made
         // up in registers -- which leaves room for the occupancy bitmaps behind the table)
         constexpr uint32_t kCols = !COMPACT ? kMoveCols : (BITMAP == 1 ? kBitmapCols : (BITMAP == 3 ? kDeltaCols : kCompactCols));
         const uint32_t n_words = p.c.n_cells * kCols;
-        for (uint32_t w0 = threadIdx.x; w0 < n_words; w0 += 4u * blockDim.x) {
-            MoveEntry part[4];
+        constexpr uint32_t kInFlight = 8;                          // (room-32-32-4's 65 KB: one round trip for a 512-thread block)
+        for (uint32_t w0 = threadIdx.x; w0 < n_words; w0 += kInFlight * blockDim.x) {
+            MoveEntry part[kInFlight];
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) {
+            for (uint32_t k = 0; k < kInFlight; ++k) {
                 const uint32_t w = min(w0 + k * blockDim.x, n_words - 1u);
                 const uint32_t cell = w / kCols, col = w - cell * kCols;
                 part[k] = p.mv[(!COMPACT || BITMAP == 3) ? cell * kMvCols + (col < kMvCols ? col : 0u) : cell * kMvCols + col + (BITMAP == 1 ? 1u : 0u)];
             }
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) {
+            for (uint32_t k = 0; k < kInFlight; ++k) {
                 const uint32_t w = w0 + k * blockDim.x;
                 if (w < n_words) {
                     // COMPACT rows: {c0 | c1 << 16, c2 | byte offset of the code's slip row << 16}
@@ -217,32 +247,6 @@ __global__ void __launch_bounds__((K == 8 || (COMPACT && BITMAP == 1 && !STREAM)
         rec_lane = (gu16)p.rec_local + lane_cell;
     }
     asm volatile("" : "+v"(wide_lane), "+v"(prob_lane), "+v"(narrow_lane), "+v"(coll_lane), "+v"(rec_lane));
-    const uint8_t *act_lane = STREAM ? p.actions + lane_cell : nullptr;
-
-    // Action words are fetched kAhead steps ahead of their use (four with four agents per lane, eight with two, whose
-    // steps are shorter): the loaded-HBM round trip, with the trajectory stores of the same wave queued in front of it
-    // (vmcnt counts loads and stores in order), is longer than two steps -- fetched two ahead, the two-agents-per-lane
-    // form ran 23 % slower than with L2-resident actions, the wait for the action word being the largest stall left.
-    // Invariant at the top of step s: raw[j] holds row s+j (j < kAhead), act_lane points at row min(s+kAhead-1, last).
-    // A step consumes the register that holds its row and reloads THAT register with row s+kAhead, so in the unrolled
-    // part of the loop the registers simply take turns (rotating a register through a move would be a use, i.e. a
-    // wait); a single step outside it uses raw[0] and shifts the others down afterwards.
-    constexpr uint32_t kAhead = K == 2 ? 8 : 4;
-    using RawWord = std::conditional_t<K == 8, uint64_t, uint32_t>;   // one action byte per agent of the lane
-    const uint32_t last_row = p.n_steps ? p.n_steps - 1u : 0u;
-    auto load_raw = [&]() __attribute__((always_inline)) {
-        if constexpr (K == 8) return *reinterpret_cast<const uint64_t *>(act_lane);
-        else return K == 4 ? *reinterpret_cast<const uint32_t *>(act_lane) : uint32_t(*reinterpret_cast<const uint16_t *>(act_lane));
-    };
-    RawWord raw[kAhead] = {};
-    if (STREAM && p.n_steps > 0) {
-        raw[0] = load_raw();
-#pragma unroll
-        for (uint32_t j = 1; j < kAhead; ++j) {
-            act_lane += last_row >= j ? step_cells : 0u;          // clamped, not guarded: late rows are re-read
-            raw[j] = load_raw();
-        }
-    }
 #pragma unroll
     for (uint32_t j = 0; j < kAhead; ++j) asm volatile("" : "+v"(raw[j]));   // consumed here: the loop's waits are counted ones
     Words4 rng[P];
@@ -944,7 +948,7 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
         // 32 agents: four per lane, collisions through per-env occupancy bitmaps behind the table (one bit per cell) -- O(A)
         // instead of 496 pair tests per env.  64 envs per 512-thread block; 128 per 1024-thread block (four waves per SIMD)
         // once the batch gives every CU a block of that size and 128 bitmaps fit (C5's share of one GPU: 481 G against 377 G
-        // for the all-pairs form; C5 whole: profiles/r04_c5_one_bit_bitmap_ab.txt).  MAPF_LQ_K=8 / MAPF_BITMAP_PAIRS=0 keep the
+        // for the all-pairs form; C5 whole: profiles/r04_c5_one_bit_bitmap_ab.txt).  MAPF_TUNE k=8 / bitmap_pairs=0 keep the
         // all-pairs forms reachable (eight agents per lane, Q = 4, one 512-thread block per CU; four per lane below).
         const size_t per_env = bitmap_stride(args.c.n_cells);
         unsigned bitmap_block = 512u;

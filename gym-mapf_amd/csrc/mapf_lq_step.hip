@@ -536,7 +536,7 @@ bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning 
     const uint8_t *const no_scen = nullptr;
     // The BIG form (resident grid, move table in LDS): batches several times what the device holds at once
     // (profiles/r04_single_step_scaling.txt), a table that leaves room for two 1024-thread blocks per CU.
-    // MAPF_STEP_BIG=0 never, =2 whenever it fits.
+    // MAPF_TUNE step_big=0 never, =2 whenever it fits.
     const size_t big_lds = kStepMoveAt + size_t(args.c.n_cells) * kBigCols * sizeof(MoveEntry);
     int n_cu = 256, dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;

@@ -102,13 +102,20 @@ class MultiMapVecEnv:
             self._check(uniforms, np.float64, (E, A), 'uniforms')
         out = dict(out) if out else {}
         any_env = self._parts[0][1]
-        for name, dt, per_agent in _STEP_SPEC:
-            if name == 'local' and not write_local:
-                continue
-            shape = (E, A) if per_agent else (E,)
-            if name not in out:
-                out[name] = any_env._empty(shape, dt)
-            self._check(out[name], dt, shape, name)
+        ctx = self._torch_stream
+        # Everything this method allocates -- missing outputs, staging copies -- is only ever used on self.stream, so it is
+        # allocated UNDER that stream: the caching allocator then orders a later reuse of the blocks behind the work queued
+        # there (allocated on the caller's current stream they could be handed out again while self.stream still writes them).
+        # The caller's own tensors (actions, uniforms, a supplied `out`) must be produced and consumed on self.stream, or be
+        # synchronised with it (`torch.cuda.stream(env.torch_stream)` / `sync()`): the calls below only enqueue.
+        with ctx():
+            for name, dt, per_agent in _STEP_SPEC:
+                if name == 'local' and not write_local:
+                    continue
+                shape = (E, A) if per_agent else (E,)
+                if name not in out:
+                    out[name] = any_env._empty(shape, dt)
+                self._check(out[name], dt, shape, name)
         calls, copies_in, copies_out, staged_runs = [], [], [], 0
         for idx, env in self._parts:
             lo, hi = int(idx[0]), int(idx[-1]) + 1
@@ -118,7 +125,8 @@ class MultiMapVecEnv:
                 part = batch[lo:hi]
                 if self._aligned(part):
                     return part                                      # in place
-                stage = t.empty_like(part)
+                with ctx():
+                    stage = t.empty_like(part)
                 (copies_in if inputs else copies_out).append((stage, part))
                 return stage
             a = view(actions, True)
@@ -127,7 +135,6 @@ class MultiMapVecEnv:
             call, _ = env.prepare_step(a, uniforms=u, auto_reset=auto_reset, out=o, write_local=write_local)
             calls.append(call)
             staged_runs += (len(copies_in) + len(copies_out)) > n_before
-        ctx = self._torch_stream
 
         def call_all():
             if copies_in or copies_out:

@@ -93,6 +93,25 @@ typedef struct mapf_desc {
     void *stream;            /* hipStream_t to enqueue on, or NULL: the handle creates one  */
 } mapf_desc;
 
+/*
+ * Kernel-dispatch overrides (tests, A/B measurements; none is needed for correct or fast operation): ONE environment
+ * variable, MAPF_TUNE="key=value,key=value,...", read by mapf_create -- so a process can hold handles created under
+ * different settings; an unknown key or a malformed item fails mapf_create with MAPF_EINVAL.  Keys (integers):
+ *   quad_lanes=0         never the packed rollout / step layouts: the lane-group kernels take every launch
+ *   k=2|4|8              pin the packed layout's agents per lane (default: by batch -- 8 from two waves per SIMD of that form
+ *                        on, 4 from one, else 2; 32 agents on 64x64 maps: 4 with occupancy bitmaps)
+ *   quad_min_lanes=n, oct_min_lanes=n   lane counts from which four / eight agents per lane are used
+ *   mv_lds_max_bytes=n   largest full move table the rollout kernels stage into LDS (default: half of the 160 KB); above it
+ *                        8-byte / 4-byte rows, 0 = always gather from global memory
+ *   scen_table=0         never build the scenario table (<= 256 distinct (start row, goal row) pairs: one byte per env)
+ *   bitmap_pairs=0       32 agents: all agent pairs instead of the per-env LDS occupancy bitmaps
+ *   bitmap_block=512|1024, bitmap_staycol=0, bitmap_delta=0   forms of the 32-agent bitmap rollout (block size; four-column
+ *                        table with made-up STAY rows; never 4-byte delta rows)
+ *   step_big=0|1|2       the single step's resident grid with the move table in LDS: never / by batch (default) / whenever it fits
+ *   step_delta=0|1|2     ... with 4-byte delta rows (64x64 maps): never / from one full residency on (default) / whenever it fits
+ *   step_block=64|128|256|512   block size of the plain packed single step
+ */
+
 /* Replaces MapfEnv.__init__'s state setup; state = start cells, step index t = 0. */
 int mapf_create(const mapf_desc *desc, mapf_handle_t *out_handle);
 int mapf_destroy(mapf_handle_t h);

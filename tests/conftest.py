@@ -19,6 +19,21 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def set_tune(monkeypatch, **kv):
+    """MAPF_TUNE -- the library's ONE kernel-dispatch override ("key=value,...", read when a handle is created; keys in
+    include/mapf_hip.h): merge `kv` into the current string for the rest of the test; a value of None removes the key."""
+    cur = dict(item.split('=', 1) for item in os.environ.get('MAPF_TUNE', '').split(',') if item)
+    for k, v in kv.items():
+        if v is None:
+            cur.pop(k, None)
+        else:
+            cur[k] = str(v)
+    if cur:
+        monkeypatch.setenv('MAPF_TUNE', ','.join('%s=%s' % item for item in cur.items()))
+    else:
+        monkeypatch.delenv('MAPF_TUNE', raising=False)
+
+
 def load_trajectory_set(name):
     with open(os.path.join(GOLDEN, name + '.json')) as f:
         meta = json.load(f)

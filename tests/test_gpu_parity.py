@@ -7,7 +7,7 @@ import pytest
 import c_oracle
 import mapf_oracle as mo
 import philox
-from conftest import load_json
+from conftest import set_tune, load_json
 from gym_mapf_amd.envs.grid import MapfGrid
 from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv
 
@@ -337,7 +337,7 @@ def test_recorded_rollout_of_full_groups_against_c_oracle(n_agents, n_envs):
 def test_recorded_rollout_with_eight_agents_per_lane(n_agents, n_envs, monkeypatch):
     """The same passes with the packed layout pinned to eight agents per lane (its default range starts at two waves
     per SIMD, i.e. 131072 envs of 8 agents), and a split rollout starting at a step index that is not a multiple of 4."""
-    monkeypatch.setenv('MAPF_LQ_K', '8')
+    set_tune(monkeypatch, k='8')
     test_recorded_rollout_of_full_groups_against_c_oracle(n_agents, n_envs)
     if n_agents <= 16:
         test_dense_rollout_split_launches_accumulate_and_single_steps(n_agents, n_envs)
@@ -431,33 +431,33 @@ def _goal_scenario_tables(n_agents, n_envs, seed):
 
 
 @pytest.mark.parametrize('n_agents,n_envs,layout,env_vars', [
-    (4, 16384, 'lq_rollout_kernel<Q=1,K=4', {'MAPF_LQ_K': '4'}), (4, 16512, 'lq_rollout_kernel<Q=2,K=2', {'MAPF_LQ_K': '2'}),
-    (8, 8192, 'lq_rollout_kernel<Q=2,K=4', {'MAPF_LQ_K': '4'}), (8, 16448, 'lq_rollout_kernel<Q=4,K=2', {'MAPF_LQ_K': '2'}),
-    (8, 16448, 'lg_rollout_kernel<L=4,FULL,MV_LDS', {'MAPF_QUAD_LANES': '0'}),
-    (16, 4096, 'lq_rollout_kernel<Q=4,K=4', {'MAPF_LQ_K': '4'}), (16, 4128, 'lq_rollout_kernel<Q=8,K=2', {'MAPF_LQ_K': '2'}),
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL> block=', {'MAPF_LQ_K': '4', 'MAPF_BITMAP_PAIRS': '0'}),
-    # (32 agents, full table rows in LDS: occupancy bitmaps behind them -- what MAPF_LQ_K=4 or a batch of one wave per SIMD gets)
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL,BITMAP> block=', {'MAPF_LQ_K': '4'}),
-    (32, 1024, 'lq_rollout_kernel<Q=16,K=2', {'MAPF_LQ_K': '2'}),
-    (32, 1024, 'lg_rollout_kernel<L=16,FULL,MV_GLOBAL', {'MAPF_MV_LDS_MAX_BYTES': '0'}),
+    (4, 16384, 'lq_rollout_kernel<Q=1,K=4', {'k': '4'}), (4, 16512, 'lq_rollout_kernel<Q=2,K=2', {'k': '2'}),
+    (8, 8192, 'lq_rollout_kernel<Q=2,K=4', {'k': '4'}), (8, 16448, 'lq_rollout_kernel<Q=4,K=2', {'k': '2'}),
+    (8, 16448, 'lg_rollout_kernel<L=4,FULL,MV_LDS', {'quad_lanes': '0'}),
+    (16, 4096, 'lq_rollout_kernel<Q=4,K=4', {'k': '4'}), (16, 4128, 'lq_rollout_kernel<Q=8,K=2', {'k': '2'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL> block=', {'k': '4', 'bitmap_pairs': '0'}),
+    # (32 agents, full table rows in LDS: occupancy bitmaps behind them -- what MAPF_TUNE k=4 or a batch of one wave per SIMD gets)
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL,BITMAP> block=', {'k': '4'}),
+    (32, 1024, 'lq_rollout_kernel<Q=16,K=2', {'k': '2'}),
+    (32, 1024, 'lg_rollout_kernel<L=16,FULL,MV_GLOBAL', {'mv_lds_max_bytes': '0'}),
     # eight agents per lane (the default only for batches of two waves per SIMD and more)
-    (8, 8192, 'lq_rollout_kernel<Q=1,K=8', {'MAPF_LQ_K': '8'}), (16, 4096, 'lq_rollout_kernel<Q=2,K=8', {'MAPF_LQ_K': '8'}),
-    (32, 2048, 'lq_rollout_kernel<Q=4,K=8', {'MAPF_LQ_K': '8'}),
-    (32, 2048, 'lq_rollout_kernel<Q=4,K=8,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_LQ_K': '8'}),
+    (8, 8192, 'lq_rollout_kernel<Q=1,K=8', {'k': '8'}), (16, 4096, 'lq_rollout_kernel<Q=2,K=8', {'k': '8'}),
+    (32, 2048, 'lq_rollout_kernel<Q=4,K=8', {'k': '8'}),
+    (32, 2048, 'lq_rollout_kernel<Q=4,K=8,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'mv_lds_max_bytes': '2048', 'k': '8'}),
     # (a full table "too large" for the LDS budget: the 8-byte-row form of the packed kernel, 512- and 1024-thread blocks)
-    (16, 4096, 'lq_rollout_kernel<Q=4,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_PAIRS': '0'}),
+    (16, 4096, 'lq_rollout_kernel<Q=4,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'mv_lds_max_bytes': '2048'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=512', {'mv_lds_max_bytes': '2048', 'bitmap_pairs': '0'}),
     # (32 agents, 8-byte rows: collisions through per-env LDS occupancy bitmaps instead of the 496 agent pairs -- the default)
     # (five-column table where it leaves room for the bitmaps -- here it does -- else four columns and a made-up STAY row)
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP5> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_DELTA': '0'}),
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_STAYCOL': '0', 'MAPF_BITMAP_DELTA': '0'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP5> block=512', {'mv_lds_max_bytes': '2048', 'bitmap_delta': '0'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=512', {'mv_lds_max_bytes': '2048', 'bitmap_staycol': '0', 'bitmap_delta': '0'}),
     # (... in 1024-thread blocks, 128 bitmaps behind the table: what a batch that fills every CU with such a block gets)
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024', 'MAPF_BITMAP_STAYCOL': '0', 'MAPF_BITMAP_DELTA': '0'}),
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP5> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024', 'MAPF_BITMAP_DELTA': '0'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP> block=1024', {'mv_lds_max_bytes': '2048', 'bitmap_block': '1024', 'bitmap_staycol': '0', 'bitmap_delta': '0'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAP5> block=1024', {'mv_lds_max_bytes': '2048', 'bitmap_block': '1024', 'bitmap_delta': '0'}),
     # (... behind 4-byte delta rows -- the default wherever a map's neighbour ids lie within +-127 of their cell's)
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAPD> block=512', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
-    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAPD> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024'}),
-    (64, 16384, 'lq_rollout_kernel<Q=16,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=1024', {'MAPF_MV_LDS_MAX_BYTES': '2048'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAPD> block=512', {'mv_lds_max_bytes': '2048'}),
+    (32, 2048, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL,BITMAPD> block=1024', {'mv_lds_max_bytes': '2048', 'bitmap_block': '1024'}),
+    (64, 16384, 'lq_rollout_kernel<Q=16,K=4,RECORD,STREAM,MAKESPAN,COMPACT,NO_TERMINAL> block=1024', {'mv_lds_max_bytes': '2048'}),
     (8, 300, 'lg_rollout_kernel<L=4,FULL,MV_GLOBAL', {}), (5, 600, 'lg_rollout_kernel<L=4,RAGGED', {}),
     (8, 16417, 'lg_rollout_kernel<L=4,FULL,MV_LDS', {}), (6, 512, 'rollout_kernel<A=6>', {})])
 def test_goal_reaching_episodes_against_c_oracle(n_agents, n_envs, layout, env_vars, monkeypatch):
@@ -468,8 +468,7 @@ def test_goal_reaching_episodes_against_c_oracle(n_agents, n_envs, layout, env_v
     open map and are driven towards them (oracle/goal_scenarios.py -- the family the reference itself stepped for
     tests/golden/goals_*).  Every recorded step against the C oracle; each pass must actually contain both outcomes,
     and the library must report the kernel this case is meant to reach."""
-    for k, v in env_vars.items():
-        monkeypatch.setenv(k, v)
+    set_tune(monkeypatch, **env_vars)
     A, E = n_agents, n_envs
     grid, nbr, rc, start, goal = _goal_scenario_tables(A, E, 8100 + A)
     for fail_prob, crit, ocrit, auto, mode, T in (
@@ -518,18 +517,17 @@ def test_goal_reaching_episodes_against_c_oracle(n_agents, n_envs, layout, env_v
 
 
 @pytest.mark.parametrize('env_vars,want', [
-    ({'MAPF_MV_LDS_MAX_BYTES': '2048'}, 'COMPACT,NO_TERMINAL,BITMAPD> block=512'),
-    ({'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_DELTA': '0'}, 'COMPACT,NO_TERMINAL,BITMAP5> block=512'),
-    ({'MAPF_MV_LDS_MAX_BYTES': '2048', 'MAPF_BITMAP_BLOCK': '1024', 'MAPF_BITMAP_STAYCOL': '0', 'MAPF_BITMAP_DELTA': '0'}, 'COMPACT,NO_TERMINAL,BITMAP> block=1024'),
-    ({'MAPF_LQ_K': '4'}, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL,BITMAP> block='),
-    ({'MAPF_LQ_K': '4', 'MAPF_BITMAP_PAIRS': '0'}, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL> block=')])
+    ({'mv_lds_max_bytes': '2048'}, 'COMPACT,NO_TERMINAL,BITMAPD> block=512'),
+    ({'mv_lds_max_bytes': '2048', 'bitmap_delta': '0'}, 'COMPACT,NO_TERMINAL,BITMAP5> block=512'),
+    ({'mv_lds_max_bytes': '2048', 'bitmap_block': '1024', 'bitmap_staycol': '0', 'bitmap_delta': '0'}, 'COMPACT,NO_TERMINAL,BITMAP> block=1024'),
+    ({'k': '4'}, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL,BITMAP> block='),
+    ({'k': '4', 'bitmap_pairs': '0'}, 'lq_rollout_kernel<Q=8,K=4,RECORD,STREAM,MAKESPAN,NO_TERMINAL> block=')])
 def test_systolic_probability_chain_over_short_and_split_launches(env_vars, want, monkeypatch):
     """32 agents in eight lanes: the ordered probability product is a systolic chain -- one hand-over per step, the last lane
     completing a step's product seven steps later and every launch ending with seven draining rounds.  Launches SHORTER than
     the chain (1, 2, 7 steps), of its length, and longer ones, issued back to back: every recorded probability (and
     everything else) against the C oracle, slip 0.2 and 0 (all factors 1.0), episodes ending and restarting in between."""
-    for k, v in env_vars.items():
-        monkeypatch.setenv(k, v)
+    set_tune(monkeypatch, **env_vars)
     A, E = 32, 2048
     grid, nbr, rc, start, goal = _goal_scenario_tables(A, E, 8100 + A)
     for fail_prob in (0.2, 0.0):
@@ -633,7 +631,7 @@ def test_large_map_maze128_32agents_16384_envs(monkeypatch, criteria):
     14818 free cells: a 1.2 MB move table, i.e. the kernels that gather rows from GLOBAL memory -- the lane-group rollout
     <L=16,FULL,MV_GLOBAL,...,DENSE> and the packed single step <Q=8,K=4,SCEN> -- under default dispatch, every env of
     every step against the C oracle (round 3 only TIMED these instances)."""
-    monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    set_tune(monkeypatch, quad_min_lanes=None)
     grid, nbr, start, goal = _scen_tables('maze-128-128-10', [18], 32, 16384)
     assert nbr.shape[0] == 14818
     crit, ocrit = (OptimizationCriteria.SoC, mo.SOC) if criteria == 'SoC' else (OptimizationCriteria.Makespan, mo.MAKESPAN)
@@ -648,20 +646,20 @@ def test_reference_room64_maps_32agents_under_default_dispatch(monkeypatch, crit
     """32 agents on the reference's own 64x64 room maps (room-64-64-16: 3646 free cells, room-64-64-8: 3232; scenarios that
     construct with 32 agents), 8192 envs over several scenarios each: the occupancy-bitmap / systolic-chain form of the packed
     rollout under default dispatch -- the four-column table where five columns would not leave room for the bitmaps, the
-    five-column one where they do (MAPF_BITMAP_DELTA=0), or 4-byte delta rows (the default on these maps) -- and the packed
+    five-column one where they do (MAPF_TUNE bitmap_delta=0), or 4-byte delta rows (the default on these maps) -- and the packed
     single step, every env of every step against the C oracle."""
-    monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    set_tune(monkeypatch, quad_min_lanes=None)
     if not delta_rows:
-        monkeypatch.setenv('MAPF_BITMAP_DELTA', '0')
+        set_tune(monkeypatch, bitmap_delta='0')
     # 'step': the single step's LDS table of delta rows too, with the occupancy bitmaps behind it (by default only from a batch
     # that fills the device on; these 8192 envs take the scenario-table instances of it, which the per-env rows of configs[4]
-    # never reach); 'step_pairs': the same table with all agent pairs (MAPF_BITMAP_PAIRS=0)
+    # never reach); 'step_pairs': the same table with all agent pairs (MAPF_TUNE bitmap_pairs=0)
     want_step = 'lq_step_kernel<Q=8,K=4'
     if delta_rows in ('step', 'step_pairs'):
-        monkeypatch.setenv('MAPF_STEP_DELTA', '2')
+        set_tune(monkeypatch, step_delta='2')
         want_step = 'lq_step_kernel<Q=8,K=4,SCEN,NO_TERMINAL,DELTA,BITMAP> block=512'
         if delta_rows == 'step_pairs':
-            monkeypatch.setenv('MAPF_BITMAP_PAIRS', '0')
+            set_tune(monkeypatch, bitmap_pairs='0')
             want_step = 'lq_step_kernel<Q=8,K=4,SCEN,NO_TERMINAL,DELTA> block=512'
     crit, ocrit = (OptimizationCriteria.SoC, mo.SOC) if criteria == 'SoC' else (OptimizationCriteria.Makespan, mo.MAKESPAN)
     for map_name, want in (('room-64-64-16', ',BITMAP> block=512'), ('room-64-64-8', ',BITMAP5> block=512')):
@@ -704,7 +702,7 @@ def test_reference_room64_maps_32agents_under_default_dispatch(monkeypatch, crit
 def test_large_map_berlin256_4agents_65536_envs(monkeypatch, criteria):
     """Berlin_1_256 (47540 free cells, a 3.8 MB move table; the map mapf_grid_tests.py:22-32 opens), scen 11, 4 agents,
     65536 envs: packed single step <Q=1,K=4,SCEN> at V = 47540 and the lane-group rollout <L=2,FULL,MV_GLOBAL,...,DENSE>."""
-    monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    set_tune(monkeypatch, quad_min_lanes=None)
     grid, nbr, start, goal = _scen_tables('Berlin_1_256', [11], 4, 65536)
     assert nbr.shape[0] == 47540
     crit, ocrit = (OptimizationCriteria.SoC, mo.SOC) if criteria == 'SoC' else (OptimizationCriteria.Makespan, mo.MAKESPAN)
@@ -755,7 +753,7 @@ def test_config4_share_32768_envs_under_default_dispatch(monkeypatch):
     with the library's DEFAULT layout choice (as every test since round 3: layouts are forced only where a test names one)."""
     import bench
     from gym_mapf_amd import sharding
-    monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    set_tune(monkeypatch, quad_min_lanes=None)
     offset, count = sharding.split_evenly(bench.CONFIGS['c4']['envs'], 3, 8)
     assert (offset, count) == (98304, 32768)
     grid, _, nbr, start, goal = bench.workload_tables(bench.CONFIGS['c4'], count, offset)
@@ -767,7 +765,7 @@ def test_double_bench_batch_runs_eight_agents_per_lane_by_default(monkeypatch):
     """131072 room-32-32-4 envs of 8 agents -- twice the bench batch, half of BASELINE configs[3] on one GPU: from two
     waves per SIMD on, the library's default choice is the eight-agents-per-lane form of the packed rollout."""
     import bench
-    monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    set_tune(monkeypatch, quad_min_lanes=None)
     grid, _, nbr, start, goal = bench.workload_tables(bench.CONFIGS['c4'], 131072, 0)
     assert _full_size_check(grid, nbr, 8, start, goal, 0.2, OptimizationCriteria.Makespan, mo.MAKESPAN, 2, 24) > 0
     env = VecMapfEnv(grid, 8, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=42, start_local=start,
@@ -782,7 +780,7 @@ def test_config5_bench_tables_16384_envs_under_default_dispatch(monkeypatch):
     seeded distinct start / goal cells that depend on the global env id only), default layout choice."""
     import bench
     from gym_mapf_amd import sharding
-    monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    set_tune(monkeypatch, quad_min_lanes=None)
     cfg = bench.CONFIGS['c5']
     offset, count = sharding.split_evenly(cfg['envs'], 5, 8)
     grid, _, nbr, start, goal = bench.workload_tables(cfg, count, offset)
@@ -799,7 +797,7 @@ def test_config5_whole_131072_envs_under_default_dispatch(monkeypatch):
     1024-thread block, so the default dispatch is the occupancy-bitmap form with 128 bitmaps behind the (delta-row) table -- every env of
     every step against the C oracle (single steps, a streamed recorded rollout, a policy-stream rollout)."""
     import bench
-    monkeypatch.delenv('MAPF_QUAD_MIN_LANES', raising=False)
+    set_tune(monkeypatch, quad_min_lanes=None)
     cfg = bench.CONFIGS['c5']
     grid, _, nbr, start, goal = bench.workload_tables(cfg, cfg['envs'], 0)
     assert _full_size_check(grid, nbr, cfg['agents'], start, goal, cfg['fail_prob'], OptimizationCriteria.Makespan, mo.MAKESPAN, 2, 8,
@@ -811,7 +809,7 @@ def test_tall_map_keeps_eight_byte_rows_behind_the_bitmaps(monkeypatch):
     """A map whose columns are taller than 127 cells: a horizontal neighbour's id is more than 127 away from its cell's, so the
     4-byte delta rows do not apply (mapf_create looks at every neighbour) and the bitmap form stages 8-byte rows -- 32 agents
     on an open 160 x 12 map with a few walls, every env of every step against the C oracle."""
-    monkeypatch.setenv('MAPF_MV_LDS_MAX_BYTES', '2048')
+    set_tune(monkeypatch, mv_lds_max_bytes='2048')
     rs = np.random.RandomState(7)
     obst = rs.rand(160, 12) < 0.08
     grid = MapfGrid([''.join('@' if obst[r, c] else '.' for c in range(12)) for r in range(160)])
@@ -1117,6 +1115,29 @@ def test_rollout_beyond_one_launch_is_issued_in_slices(monkeypatch):
     ref2 = co.rollout(7, auto_reset=True)
     assert np.array_equal(more['episodes'], ref['episodes'] + ref2['episodes'])
     one.close(), sliced.close()
+
+
+def test_mapf_tune_is_the_one_override_and_rejects_what_it_does_not_know(monkeypatch):
+    """MAPF_TUNE="key=value,...": read at mapf_create; a typo must fail the create call, not silently measure the default."""
+    from gym_mapf_amd import _native as nat
+    grid = MapfGrid(['....', '....', '....', '....'])
+    make = lambda: VecMapfEnv(grid, 4, ((0, 0), (1, 1), (2, 2), (3, 3)), ((3, 0), (2, 1), (1, 2), (0, 3)), 0.2, -1000.0, 100.0, -1.0,
+                              OptimizationCriteria.Makespan, n_envs=4096)
+    for bad, what in (('k=4,no_such_key=1', 'unknown key'), ('k', 'malformed'), ('k=four', 'malformed')):
+        monkeypatch.setenv('MAPF_TUNE', bad)
+        with pytest.raises(nat.MapfNativeError) as err:
+            make()
+        assert what in str(err.value) and err.value.code == nat.MAPF_EINVAL, str(err.value)
+    monkeypatch.setenv('MAPF_TUNE', 'k=2,quad_min_lanes=0')
+    env = make()
+    env.rollout(4, auto_reset=True, record=True)
+    assert 'lq_rollout_kernel<Q=2,K=2' in env.last_kernel('rollout'), env.last_kernel('rollout')
+    env.close()
+    monkeypatch.setenv('MAPF_TUNE', 'quad_lanes=0')
+    env = make()
+    env.rollout(4, auto_reset=True, record=True)
+    assert env.last_kernel('rollout').startswith('lg_rollout_kernel'), env.last_kernel('rollout')
+    env.close()
 
 
 def test_out_of_range_actions_are_stay_and_device_pointers_must_be_aligned():

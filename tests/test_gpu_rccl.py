@@ -62,7 +62,7 @@ def test_bench_with_the_rccl_legs_forced_on_at_one_gpu():
     barrier, MAX all-reduce of the block times and the gather of the returns, end to end, one JSON line."""
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--dist-backend', 'nccl', '--force-dist',
            '--steps', '2', '--warmup', '1', '--repeats', '1', '--preroll-ms', '10', '--no-side-legs', '--no-cpu-baseline',
-           '--envs', '4096']
+           '--envs', '4096', '--baseline-config-steps', '2']
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420, env=_clean_env())
     assert proc.returncode == 0, proc.stderr.decode('utf-8', 'replace')[-3000:]
     lines = [l for l in proc.stdout.decode().splitlines() if l.strip()]
@@ -71,3 +71,30 @@ def test_bench_with_the_rccl_legs_forced_on_at_one_gpu():
     assert line['n_gpus'] == 1 and line['parity']['bit_exact'] is True
     assert line['gather'] == {'backend': 'nccl', 'elements': 4096, 'shards': [4096], 'collective': 'all_gather_into_tensor'}
     assert 'rehearsal' not in line and line['value'] > 0
+    # ... and the leg a driver scaling run reports BASELINE configs[3] / configs[4] from (here: whole, on the one rank)
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    entry.check_baseline_configs(line, 1)
+    assert line['baseline_configs']['configs[3]']['shards'] == [262144] and line['baseline_configs']['configs[4]']['shards'] == [131072]
+    assert 'BITMAPD> block=1024' in line['baseline_configs']['configs[4]']['kernel']
+
+
+def test_three_rank_rehearsal_shards_the_baseline_configs_in_blocks():
+    """`bench.py --gpus 3 --dist-backend gloo --share-device`: three self-launched ranks on this one GPU -- the headline leg
+    (weak scaling) and the baseline_configs leg, whose populations do not divide by three: shards of 88064 / 87040 / 87040 and
+    44032 / 44032 / 43008 envs (whole 1024-env blocks), the packed kernels on every rank, padded gathers of all returns."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '3', '--dist-backend', 'gloo', '--share-device',
+           '--steps', '2', '--warmup', '1', '--repeats', '1', '--preroll-ms', '10', '--no-side-legs', '--no-cpu-baseline',
+           '--envs', '4096', '--baseline-config-steps', '2', '--rank-timeout', '380']
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420, env=_clean_env())
+    assert proc.returncode == 0, proc.stderr.decode('utf-8', 'replace')[-3000:]
+    lines = [l for l in proc.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 3 and line.get('rehearsal') is True and line['gather']['elements'] == 3 * 4096
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    entry.check_baseline_configs(line, 3)
+    assert line['baseline_configs']['configs[3]']['shards'] == [88064, 87040, 87040]
+    assert line['baseline_configs']['configs[4]']['shards'] == [44032, 44032, 43008]
+    assert all(leg.get('rehearsal') is True for leg in line['baseline_configs'].values())

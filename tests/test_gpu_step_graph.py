@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import c_oracle
+from conftest import set_tune
 import mapf_oracle as mo
 from gym_mapf_amd import _native as nat
 from gym_mapf_amd.envs.grid import MapfGrid
@@ -127,7 +128,7 @@ def test_graph_of_rollout_and_steps_and_host_side_index_moves():
 
 @pytest.mark.parametrize('n_agents,n_envs', [(4, 512), (8, 256), (16, 256), (32, 128)])
 def test_scenario_table_step_equals_plain_rows(monkeypatch, n_agents, n_envs):
-    """The packed single step with and without the scenario table (MAPF_SCEN_TABLE=0), 5 scenarios, goals reachable so
+    """The packed single step with and without the scenario table (MAPF_TUNE scen_table=0), 5 scenarios, goals reachable so
     that episodes end and auto-reset takes the start rows from the table: both against the C oracle, and the library
     must report the intended kernel instance."""
     rs = np.random.RandomState(100 + n_agents)
@@ -144,9 +145,9 @@ def test_scenario_table_step_equals_plain_rows(monkeypatch, n_agents, n_envs):
     start, goal = np.ascontiguousarray(scen_start[which]), np.ascontiguousarray(scen_goal[which])
     for use_table in (True, False):
         if use_table:
-            monkeypatch.delenv('MAPF_SCEN_TABLE', raising=False)
+            set_tune(monkeypatch, scen_table=None)
         else:
-            monkeypatch.setenv('MAPF_SCEN_TABLE', '0')
+            set_tune(monkeypatch, scen_table='0')
         env = VecMapfEnv(grid, n_agents, None, None, 0.1, *R, OptimizationCriteria.SoC, seed=5, start_local=start, goal_local=goal)
         co = c_oracle.COracle(nbr, n_agents, start, goal, 0.1, *R, mo.SOC, seed=5)
         n_done = 0
@@ -168,13 +169,13 @@ def test_scenario_table_step_equals_plain_rows(monkeypatch, n_agents, n_envs):
 
 @pytest.mark.parametrize('big', ['2', '2k4', '0'])
 def test_single_step_at_a_batch_larger_than_the_device_holds(monkeypatch, big):
-    """393216 envs x 8 agents: more than an MI355X holds at once.  MAPF_STEP_BIG=2 forces the form the library uses from
+    """393216 envs x 8 agents: more than an MI355X holds at once.  MAPF_TUNE step_big=2 forces the form the library uses from
     1 M envs on -- a resident grid of 512 blocks of 1024 threads with the move table in LDS, walking 768 chunks (half
-    of the blocks take two) -- MAPF_STEP_BIG=0 the one-block-per-256-lanes form.  Six steps against the C oracle, the
+    of the blocks take two) -- step_big=0 the one-block-per-256-lanes form.  Six steps against the C oracle, the
     first one with the is_terminal test (a state set by the caller), then without."""
-    monkeypatch.setenv('MAPF_STEP_BIG', big[0])
+    set_tune(monkeypatch, step_big=big[0])
     if big == '2k4':
-        monkeypatch.setenv('MAPF_LQ_K', '4')                      # (the BIG form prefers eight agents per lane: pin four)
+        set_tune(monkeypatch, k='4')                      # (the BIG form prefers eight agents per lane: pin four)
     expect = {'2': 'lq_step_kernel<Q=1,K=8,SCEN', '2k4': 'lq_step_kernel<Q=2,K=4,SCEN', '0': 'lq_step_kernel<Q=2,K=4,SCEN'}[big]
     E, A = 393216, 8
     grid, _, nbr, start, goal = _c3_tables(E)
@@ -202,7 +203,7 @@ def test_big_form_of_the_single_step_at_other_team_sizes(monkeypatch, n_agents, 
     """The resident-grid / LDS-table form at 4, 16 and 32 agents (one, four and eight lanes per env), forced on small
     batches, goal-seeking actions so that episodes end; against the C oracle."""
     import goal_scenarios
-    monkeypatch.setenv('MAPF_STEP_BIG', '2')
+    set_tune(monkeypatch, step_big='2')
     A, E = n_agents, n_envs
     lines, start_loc, goal_loc = goal_scenarios.goal_scenario(A, E, 5150 + A)
     grid = MapfGrid(lines)

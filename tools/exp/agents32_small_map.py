@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """32 agents on a map whose FULL move table fits the LDS (room-32-32-4, random distinct start / goal cells): the fused
-rollout under default dispatch (occupancy bitmaps behind the full table) against the all-pairs forms (MAPF_BITMAP_PAIRS=0 /
-MAPF_LQ_K=8), at two batch sizes.
+rollout under default dispatch (occupancy bitmaps behind the full table) against the all-pairs forms (MAPF_TUNE bitmap_pairs=0 /
+MAPF_TUNE k=8), at two batch sizes.
     gpurun -- 'python tools/exp/agents32_small_map.py'"""
 import os
 import subprocess
@@ -26,9 +26,9 @@ if len(sys.argv) > 1:
     bc.measure('room-32-32-4, 32 agents [%s]' % os.environ.get('FORM', 'default'), g, s, t, 32, 0.2)
 else:
     for E in ('16384', '65536'):
-        for form in ('', 'MAPF_BITMAP_PAIRS=0', 'MAPF_LQ_K=8'):
+        for form in ('', 'MAPF_TUNE=bitmap_pairs=0', 'MAPF_TUNE=k=8'):
             env = dict(os.environ, FORM=form or 'default')
             if form:
-                k, v = form.split('=')
+                k, v = form.split('=', 1)
                 env[k] = v
             subprocess.run([sys.executable, os.path.abspath(__file__), E], env=env, check=False)

@@ -3,7 +3,7 @@
 out=$PWD/gpurun_out/side_r02; mkdir -p $out
 if [ -f $PWD/gym-mapf_amd/gym_mapf_amd/lib/variants/libmapf_hip_stamps.so ]; then   # (make stamps + copy it there first)
   export MAPF_HIP_LIB=$PWD/gym-mapf_amd/gym_mapf_amd/lib/variants/libmapf_hip_stamps.so
-  (python tools/stamp_profile.py 65536; MAPF_LQ_K=4 python tools/stamp_profile.py 32768) 2>&1 | grep -v amdgpu.ids > $out/r02_rollout_stamps.txt
+  (python tools/stamp_profile.py 65536; MAPF_TUNE=k=4 python tools/stamp_profile.py 32768) 2>&1 | grep -v amdgpu.ids > $out/r02_rollout_stamps.txt
   unset MAPF_HIP_LIB
 fi
 : > $out/r02_configs.txt

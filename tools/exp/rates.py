@@ -11,17 +11,16 @@ from gym_mapf_amd import _native as nat
 from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv
 
 CASES = {'c3': ('c3', 65536, {}), 'c3x2': ('c3', 131072, {}), 'c4s': ('c4', 32768, {}),
-         'c4s_quad': ('c4', 32768, {'MAPF_QUAD_MIN_LANES': '0'}), 'c4s_pair': ('c4', 32768, {'MAPF_QUAD_LANES': '0'}),
-         'c3_pair': ('c3', 65536, {'MAPF_QUAD_LANES': '0'}), 'c4s_k2': ('c4', 32768, {'MAPF_LQ_K': '2'}), 'c3_k2': ('c3', 65536, {'MAPF_LQ_K': '2'}),
-         'c5s_k2': ('c5', 16384, {'MAPF_LQ_K': '2'}), 'c3_k8': ('c3', 65536, {'MAPF_LQ_K': '8'}), 'c3x2_k4': ('c3', 131072, {'MAPF_LQ_K': '4'}),
-         'c4_k4': ('c4', 262144, {'MAPF_LQ_K': '4'}), 'c5_k4': ('c5', 131072, {'MAPF_LQ_K': '4'}), 'c5s_k8': ('c5', 16384, {'MAPF_LQ_K': '8'}),
+         'c4s_quad': ('c4', 32768, {'MAPF_TUNE': 'quad_min_lanes=0'}), 'c4s_pair': ('c4', 32768, {'MAPF_TUNE': 'quad_lanes=0'}),
+         'c3_pair': ('c3', 65536, {'MAPF_TUNE': 'quad_lanes=0'}), 'c4s_k2': ('c4', 32768, {'MAPF_TUNE': 'k=2'}), 'c3_k2': ('c3', 65536, {'MAPF_TUNE': 'k=2'}),
+         'c5s_k2': ('c5', 16384, {'MAPF_TUNE': 'k=2'}), 'c3_k8': ('c3', 65536, {'MAPF_TUNE': 'k=8'}), 'c3x2_k4': ('c3', 131072, {'MAPF_TUNE': 'k=4'}),
+         'c4_k4': ('c4', 262144, {'MAPF_TUNE': 'k=4'}), 'c5_k4': ('c5', 131072, {'MAPF_TUNE': 'k=4'}), 'c5s_k8': ('c5', 16384, {'MAPF_TUNE': 'k=8'}),
          'c5s': ('c5', 16384, {}), 'c5': ('c5', 131072, {}), 'c2': ('c2', 4096, {}), 'c4': ('c4', 262144, {})}
 torch.cuda.set_device(0)
 T = 256
 for case in (sys.argv[1:] or ['c3', 'c4s', 'c5s']):
     name, E, envvars = CASES[case]
-    for k in ('MAPF_QUAD_MIN_LANES', 'MAPF_QUAD_LANES', 'MAPF_MV_LDS_MAX_BYTES', 'MAPF_LQ_K'):
-        os.environ.pop(k, None)
+    os.environ.pop('MAPF_TUNE', None)
     os.environ.update(envvars)
     cfg = bench.CONFIGS[name]
     A = cfg['agents']

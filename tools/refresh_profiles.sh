@@ -27,7 +27,7 @@ for cfg in $configs; do
     c5)  flags="--config c5"; E=131072; A=32 ;;
     *) echo "unknown config $cfg"; exit 1 ;;
   esac
-  BENCH="python3 bench.py --steps 20 --warmup 5 --repeats 2 --no-cpu-baseline --no-scalar-env --no-per-gpu-shapes $flags"
+  BENCH="python3 bench.py --steps 20 --warmup 5 --repeats 2 --no-cpu-baseline --no-scalar-env --no-per-gpu-shapes --no-policy-rollout --no-transitions $flags"
   pre="$out/${tag}_${cfg}"
 
   # 1. the command under the profiler: per-kernel durations

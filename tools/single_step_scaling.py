@@ -64,11 +64,11 @@ if len(sys.argv) > 1:        # child: one (E, ring, mode) case under the environ
     raise SystemExit(0)
 for E in (4096, 16384, 65536, 131072, 262144, 524288, 1048576, 2097152, 4194304):
     run(E, 16, 'graph')
-    if E >= 262144:          # the resident-grid / LDS-table form against one block per 256 lanes (MAPF_STEP_BIG=0 / 2)
+    if E >= 262144:          # the resident-grid / LDS-table form against one block per 256 lanes (MAPF_TUNE step_big=0 / 2)
         for big in ('0', '2'):
             out = subprocess.run([sys.executable, os.path.abspath(__file__), str(E), '4' if E >= 1048576 else '16', 'graph'],
-                                 env=dict(os.environ, MAPF_STEP_BIG=big), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
-            print('   MAPF_STEP_BIG=%s: %s' % (big, out.strip().splitlines()[-1] if out.strip() else 'failed'), flush=True)
+                                 env=dict(os.environ, MAPF_TUNE='step_big=' + big), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+            print('   MAPF_TUNE step_big=%s: %s' % (big, out.strip().splitlines()[-1] if out.strip() else 'failed'), flush=True)
     if E in (65536, 1048576):
         run(E, 16, 'plain')
     if E >= 1048576:

@@ -5,7 +5,7 @@ episode counters, so this build's outputs are not valid results) and prints medi
 
     make -C gym-mapf_amd/csrc stamps
     MAPF_HIP_LIB=gym-mapf_amd/gym_mapf_amd/lib/variants/libmapf_hip_stamps.so python tools/stamp_profile.py [envs] [c3|c5]
-    (MAPF_LQ_K=2 profiles the packed layout with two agents per lane, MAPF_QUAD_LANES=0 the lane-group kernel)
+    (MAPF_TUNE=k=2 profiles the packed layout with two agents per lane, MAPF_TUNE=quad_lanes=0 the lane-group kernel)
 
 Stamps serialise the segments (a fence on each side), so read the SHARES, not the total (cdna_hip_programming.md
 section 7, in-kernel stamps).
@@ -26,7 +26,8 @@ cfg_name = sys.argv[2] if len(sys.argv) > 2 else 'c3'
 cfg = bench.CONFIGS[cfg_name]
 E, A, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 65536), cfg['agents'], 64
 # envs per wave: 64 / (lanes per env); 8 agents: 32 with four agents per lane (default), 16 with two
-pair_layout = os.environ.get('MAPF_QUAD_LANES') == '0' or os.environ.get('MAPF_LQ_K') == '2'
+_tune = dict(item.split('=', 1) for item in os.environ.get('MAPF_TUNE', '').split(',') if item)
+pair_layout = _tune.get('quad_lanes') == '0' or _tune.get('k') == '2'
 PER_WAVE = 64 * (2 if pair_layout else 4) // A
 print('layout: %s' % ('pair (2 agents per lane)' if pair_layout else 'quad (4 agents per lane)'))
 grid, _, nbr, start, goal = bench.workload_tables(cfg, E, 0)
