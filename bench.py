@@ -673,6 +673,9 @@ def main():
     ap.add_argument('--no-baseline-configs', action='store_true',
                     help='multi-rank runs: skip the baseline_configs leg (configs[3] and configs[4] sharded over the ranks)')
     ap.add_argument('--baseline-config-steps', type=int, default=10, help='launches per timed block of the baseline_configs leg')
+    ap.add_argument('--policy-actions', action='store_true',
+                    help='the headline leg with actions = NULL (in-kernel policy stream) -- the counter passes of the policy kernel '
+                         '(tools/refresh_profiles.sh c3p); the default line carries that launch as the policy_rollout side leg')
     ap.add_argument('--no-transitions', action='store_true', help='skip the transitions leg (env.P enumeration)')
     ap.add_argument('--no-policy-rollout', action='store_true', help='skip the policy_rollout leg (the same batch with actions = NULL)')
     ap.add_argument('--kernel', default='auto', choices=['auto', 'thread_per_env', 'lane_group'])
@@ -781,10 +784,12 @@ def main():
         co.reset()
         co.t = 0
         n_ro = min(8, ring)
-        res = env.rollout(n_ro, actions=actions[:n_ro], auto_reset=True, record=True)
+        res = env.rollout(n_ro, actions=None if args.policy_actions else actions[:n_ro], auto_reset=True, record=True)
         env.sync()
+        if args.policy_actions:
+            import philox
         for t in range(n_ro):
-            ref = co.step(actions[t].cpu().numpy(), auto_reset=True)
+            ref = co.step(philox.random_actions_np(SEED, offset + np.arange(E), t, A) if args.policy_actions else actions[t].cpu().numpy(), auto_reset=True)
             ok &= bool(np.array_equal(res['local'][t].cpu().numpy(), ref['local']))
             ok &= bool(np.array_equal(res['reward'][t].cpu().numpy().view(np.uint64), ref['reward'].view(np.uint64)))
             ok &= bool(np.array_equal(res['prob'][t].cpu().numpy().view(np.uint64), ref['prob'].view(np.uint64)))
@@ -866,7 +871,7 @@ def main():
     def rollout_io(slot):
         return nat.MapfRolloutIO(
             struct_size=ctypes.sizeof(nat.MapfRolloutIO), n_steps=T, step_flags=nat.MAPF_STEP_AUTO_RESET,
-            accumulate=1, actions=actions[slot * T].data_ptr(), out_returns=acc['returns'].data_ptr(),
+            accumulate=1, actions=None if args.policy_actions else actions[slot * T].data_ptr(), out_returns=acc['returns'].data_ptr(),
             out_episodes=acc['episodes'].data_ptr(), out_collisions=acc['collisions'].data_ptr(),
             rec_local=rec['local'].data_ptr(), rec_reward=rec['reward'].data_ptr(), rec_done=rec['done'].data_ptr(),
             rec_collision=rec['collision'].data_ptr(), rec_prob=rec['prob'].data_ptr())
@@ -951,10 +956,11 @@ def main():
             "scaling": scaling, "vs_baseline": None, "dtype": "u16/f64", "data": "synthetic",
             "config": {"workload": "%s: %s map, %d agents, slip=%g, %d envs %s, Makespan, auto-reset; one step = one fused "
                                    "mapf_rollout launch of %d MapfEnv.step() calls per env, every env-step's next cells / "
-                                   "reward / done / collision / prob written to HBM, actions streamed from HBM"
+                                   "reward / done / collision / prob written to HBM, actions %s"
                                    % (cfg['baseline'], cfg['map'], A, cfg['fail_prob'],
                                       E if scaling == 'weak' else total_envs,
-                                      'per GPU' if scaling == 'weak' else 'in total over %d GPU(s)' % world, T),
+                                      'per GPU' if scaling == 'weak' else 'in total over %d GPU(s)' % world, T,
+                                      'from the in-kernel policy stream' if args.policy_actions else 'streamed from HBM'),
                        "name": args.config, "envs_per_gpu": E, "envs_total": total_envs, "n_agents": A,
                        "fail_prob": cfg['fail_prob'], "seed": SEED, "env_steps_per_step": T,
                        "agent_steps_per_step": T * total_envs * A, "action_ring_env_steps": ring,
@@ -1001,7 +1007,7 @@ def main():
             # what each GPU runs of the two BASELINE configurations that are sharded over eight
             line["per_gpu_shapes"] = {"c4_share": per_gpu_shape_rate('c4', CONFIGS['c4']['envs'] // 8),
                                       "c5_share": per_gpu_shape_rate('c5', CONFIGS['c5']['envs'] // 8)}
-        if world == 1 and not args.no_side_legs and not args.no_policy_rollout and args.envs is None and args.kernel == 'auto':
+        if world == 1 and not args.no_side_legs and not args.no_policy_rollout and not args.policy_actions and args.envs is None and args.kernel == 'auto':
             # the same batch with the policy ON the device: mapf_rollout(actions = NULL), trajectory recorded
             line["policy_rollout"] = per_gpu_shape_rate(args.config, E, T=T, n_launch=20, blocks=5, policy=True)
             line["policy_rollout"]["vs_streamed_hip_events"] = line["policy_rollout"]["value"] / line["value_hip_events"]

@@ -1,14 +1,15 @@
 #!/bin/bash
 # Regenerates the measurement artefacts kept under profiles/ on a GPU box:
-#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r04 c3 c4s'
-#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r04 c5s c5'
+#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r05 c3 c3p c4s'
+#   gpurun --timeout 1200 -- 'bash tools/refresh_profiles.sh r05 c5s c5'
 # writes gpurun_out/prof_<tag>/<tag>_<config>_*; copy them into profiles/ afterwards (gpurun_out/ is scratch) and
 # run tools/derive_traffic.py / tools/derive_valu.py there is no need: the script does it and copies the two JSON files
 # next to its other outputs.  Every rocprofv3 call has the program itself right after `--`; PMC passes use
 # --kernel-trace only.  Configurations: c3 = the bench default (configs[2]); c4s = configs[3]'s share of one GPU
-# (32768 envs); c5s = configs[4]'s share (16384 envs x 32 agents); c5 = configs[4] whole on one GPU.
+# (32768 envs); c5s = configs[4]'s share (16384 envs x 32 agents); c5 = configs[4] whole on one GPU; c3p = c3 with the in-kernel
+# policy stream (actions = NULL: the policy_rollout leg's kernel).
 set -eo pipefail
-tag=${1:-r04}
+tag=${1:-r05}
 shift || true
 configs=${*:-c3}
 out=$PWD/gpurun_out/prof_$tag
@@ -22,6 +23,7 @@ rm -rf $P && mkdir -p $P
 for cfg in $configs; do
   case $cfg in
     c3)  flags=""; E=65536; A=8 ;;
+    c3p) flags="--policy-actions"; E=65536; A=8 ;;
     c4s) flags="--config c4 --envs 32768"; E=32768; A=8 ;;
     c5s) flags="--config c5 --envs 16384"; E=16384; A=32 ;;
     c5)  flags="--config c5"; E=131072; A=32 ;;
@@ -64,7 +66,7 @@ done
 # for other batches (derive_traffic.py --merge)
 args=()
 for cfg in $configs; do
-  case $cfg in c3) E=65536; A=8 ;; c4s) E=32768; A=8 ;; c5s) E=16384; A=32 ;; c5) E=131072; A=32 ;; esac
+  case $cfg in c3|c3p) E=65536; A=8 ;; c4s) E=32768; A=8 ;; c5s) E=16384; A=32 ;; c5) E=131072; A=32 ;; esac
   args+=("$(cat $P/$cfg/label)" $E $A 256 $P/$cfg/fetch256/*/*counter_collection.csv $P/$cfg/write256/*/*counter_collection.csv \
          128 $P/$cfg/fetch128/*/*counter_collection.csv $P/$cfg/write128/*/*counter_collection.csv)
 done
@@ -79,6 +81,7 @@ echo "traffic + valu done"
 for cfg in $configs; do
   case $cfg in
     c3)  flags="" ;;
+    c3p) flags="--policy-actions" ;;
     c4s) flags="--config c4 --envs 32768" ;;
     c5s) flags="--config c5 --envs 16384" ;;
     c5)  flags="--config c5" ;;

@@ -4,7 +4,8 @@ the bench batch (configs[2], 65536 envs x 8 agents) and configs[4]'s share of on
 trajectory, streamed actions, three ways:
   (a) the C ABI with everything preallocated (bench.py's own path: one ctypes call per launch);
   (b) VecMapfEnv.rollout(record=True, out=previous result)  -- the wrapper, buffers reused;
-  (c) VecMapfEnv.rollout(record=True)                        -- the wrapper allocating its eight arrays per call.
+  (c) VecMapfEnv.rollout(record=True)                        -- the wrapper allocating its eight arrays per call;
+  (d) the launches of (a) recorded into a hipGraph (16 per replay)  -- no host enqueue between the kernels.
 HIP-event time per launch (median of 5 blocks of 20 launches); a least-squares line t(T) = fixed + T * per_step through (a)
 separates the kernel's fixed cost per launch (table staging, first loads, the drain of the last step) from its step rate.
 
@@ -23,7 +24,7 @@ import bench  # noqa: E402
 from gym_mapf_amd import _native as nat  # noqa: E402
 from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv  # noqa: E402
 
-TS = (8, 16, 32, 64, 128, 256)
+TS = tuple(int(x) for x in os.environ['T_SWEEP'].split(',')) if os.environ.get('T_SWEEP') else (8, 16, 32, 64, 128, 256)
 
 
 def timed(env, fn, n=20, blocks=5):
@@ -55,14 +56,21 @@ def sweep(name, n_envs):
            'episodes': torch.zeros(E, dtype=torch.int32, device='cuda').view(torch.uint32),
            'collisions': torch.zeros(E, dtype=torch.int32, device='cuda').view(torch.uint32)}
     print('%s: %s map, %d agents, %d envs, recorded trajectory, streamed actions' % (cfg['baseline'], cfg['map'], A, E))
-    print('    T   | (a) C ABI, preallocated      | (b) rollout(out=...)         | (c) rollout() allocating     | kernel')
-    rows = []
+    print('    T   | (a) C ABI, preallocated      | (b) rollout(out=...)         | (c) rollout() allocating     | (d) hipGraph replay of (a)   | kernel')
+    rows, rows_d = [], []
     for T in TS:
         io = nat.MapfRolloutIO(struct_size=ctypes.sizeof(nat.MapfRolloutIO), n_steps=T, step_flags=nat.MAPF_STEP_AUTO_RESET, accumulate=1,
                                actions=actions.data_ptr(), out_returns=acc['returns'].data_ptr(), out_episodes=acc['episodes'].data_ptr(),
                                out_collisions=acc['collisions'].data_ptr(), rec_local=rec['local'].data_ptr(), rec_reward=rec['reward'].data_ptr(),
                                rec_done=rec['done'].data_ptr(), rec_collision=rec['collision'].data_ptr(), rec_prob=rec['prob'].data_ptr())
         a = timed(env, lambda: nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(io))))
+        # (d) the same launch recorded into a hipGraph, 16 per replay: the host is out of the loop, what is left is the kernel
+        env.graph_begin()
+        for _ in range(16):
+            nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(io)))
+        graph = env.graph_end()
+        d = timed(env, lambda: graph.launch(1), n=4) / 16.0
+        graph.close()
         acts = actions[:T]
         res = env.rollout(T, actions=acts, auto_reset=True, record=True)
         b = timed(env, lambda: env.rollout(T, actions=acts, auto_reset=True, record=True, out=res))
@@ -71,12 +79,19 @@ def sweep(name, n_envs):
         rate = lambda ms: T * E * A / (ms * 1e-3) / 1e9
         frac = lambda ms: T * E * A * bench.bytes_per_agent_step(A) / (ms * 1e-3) / 1e9 / bench.HBM_PEAK_GBS
         rows.append((T, a))
-        print('  %4d   | %8.2f us %6.1f G  %.3f | %8.2f us %6.1f G  %.3f | %8.2f us %6.1f G  %.3f | %s' % (
-            T, a * 1e3, rate(a), frac(a), b * 1e3, rate(b), frac(b), c * 1e3, rate(c), frac(c), env.last_kernel('rollout')[:60]), flush=True)
+        rows_d.append((T, d))
+        print('  %4d   | %8.2f us %6.1f G  %.3f | %8.2f us %6.1f G  %.3f | %8.2f us %6.1f G  %.3f | %8.2f us %6.1f G  %.3f | %s' % (
+            T, a * 1e3, rate(a), frac(a), b * 1e3, rate(b), frac(b), c * 1e3, rate(c), frac(c), d * 1e3, rate(d), frac(d),
+            env.last_kernel('rollout')[:44]), flush=True)
     t = np.array([r[0] for r in rows], float)
     y = np.array([r[1] for r in rows], float) * 1e3
     per_step, fixed = np.polyfit(t, y, 1)
     print('  (a) as a line: %.2f us fixed per launch + %.3f us per env-step  ->  the fixed part is %.0f %% of a T = 32 launch, %.0f %% at T = 256'
+          % (fixed, per_step, 100 * fixed / (fixed + 32 * per_step), 100 * fixed / (fixed + 256 * per_step)))
+    t = np.array([r[0] for r in rows_d], float)
+    y = np.array([r[1] for r in rows_d], float) * 1e3
+    per_step, fixed = np.polyfit(t, y, 1)
+    print('  (d) as a line: %.2f us fixed per launch + %.3f us per env-step  ->  %.0f %% of a T = 32 launch, %.0f %% at T = 256  (the kernel alone: no host enqueue)'
           % (fixed, per_step, 100 * fixed / (fixed + 32 * per_step), 100 * fixed / (fixed + 256 * per_step)))
     env.close()
     del rec, acc, actions
@@ -84,6 +99,9 @@ def sweep(name, n_envs):
 
 
 if __name__ == '__main__':
-    sweep('c3', 65536)
-    sweep('c5', 16384)
-    sweep('c4', 32768)
+    if len(sys.argv) > 2:
+        sweep(sys.argv[1], int(sys.argv[2]))       # one batch: python tools/rollout_T_sweep.py c3 65536   (T_SWEEP=1,2,4 picks the lengths)
+    else:
+        sweep('c3', 65536)
+        sweep('c5', 16384)
+        sweep('c4', 32768)

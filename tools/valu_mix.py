@@ -9,7 +9,7 @@ hardware (SQ_INSTS_VALU_INT64 / _MUL_F64 / _ADD_F64) and are left out here.  Wri
 instance's template arguments as rocprofv3 prints them, with the hash of the kernel sources; tools/derive_valu.py prices a
 launch's counted vector instructions with it.
 
-    python tools/valu_mix.py          # ~1 minute (three translation units)
+    python tools/valu_mix.py          # ~5 minutes (two translation units)
 """
 import json
 import os
@@ -43,13 +43,19 @@ def classify(line):
     return 'ordinary'
 
 
+_LISTINGS = {}
+
+
 def mix_of(unit_flags, instance_re):
-    with tempfile.TemporaryDirectory() as tmp:
-        out = os.path.join(tmp, 'k.s')
-        subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
-                               '-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only'] + unit_flags +
-                              [os.path.join(CSRC, 'mapf_lq_rollout.hip'), '-o', out], stderr=subprocess.DEVNULL)
-        text = open(out).read()
+    key = tuple(unit_flags)
+    if key not in _LISTINGS:                                     # one hipcc -S per translation unit, not per instance
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, 'k.s')
+            subprocess.check_call(['hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+                                   '-I' + os.path.join(ROOT, 'include'), '-S', '--cuda-device-only'] + unit_flags +
+                                  [os.path.join(CSRC, 'mapf_lq_rollout.hip'), '-o', out], stderr=subprocess.DEVNULL)
+            _LISTINGS[key] = open(out).read()
+    text = _LISTINGS[key]
     m = re.search(r'^(_ZN4mapf\S*lq_rollout_kernel' + instance_re + r'\S*):', text, re.M)
     body = text[m.end():text.index('.Lfunc_end', m.end())].split('\n')
     counts = {'fast': 0, 'ordinary': 0, 'wide': 0}
@@ -65,6 +71,7 @@ def main():
     # (rocprofv3's spelling of the instance, -D flags of its translation unit, mangled template arguments)
     instances = [
         ('lq_rollout_kernel<2, 4, true, true, false, false, false, 0>', ['-DMAPF_LQ_K=4', '-DMAPF_LQ_RECORD=1'], 'ILi2ELi4ELb1ELb1ELb0ELb0ELb0ELi0E'),
+        ('lq_rollout_kernel<2, 4, true, false, false, false, false, 0>', ['-DMAPF_LQ_K=4', '-DMAPF_LQ_RECORD=1'], 'ILi2ELi4ELb1ELb0ELb0ELb0ELb0ELi0E'),   # ... with the in-kernel policy
         ('lq_rollout_kernel<8, 4, true, true, false, true, false, 2>', ['-DMAPF_LQ_K=4', '-DMAPF_LQ_RECORD=1'], 'ILi8ELi4ELb1ELb1ELb0ELb1ELb0ELi2E'),
         ('lq_rollout_kernel<8, 4, true, true, false, true, false, 1>', ['-DMAPF_LQ_K=4', '-DMAPF_LQ_RECORD=1'], 'ILi8ELi4ELb1ELb1ELb0ELb1ELb0ELi1E'),
         ('lq_rollout_kernel<8, 4, true, true, false, true, false, 3>', ['-DMAPF_LQ_K=4', '-DMAPF_LQ_RECORD=1'], 'ILi8ELi4ELb1ELb1ELb0ELb1ELb0ELi3E'),
