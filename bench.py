@@ -97,7 +97,7 @@ _CSRC_HASH = None
 
 def csrc_hash():
     """Identity of the kernel sources a committed counter profile belongs to: sha256 (first 16 hex digits) over
-    gym-mapf_amd/csrc/*.hip, *.hpp and include/mapf_hip.h with comments and white space removed.  profiles/traffic.json
+    gym-mapf_amd/csrc/*.hip (but mapf_transitions.hip), *.hpp and include/mapf_hip.h with comments and white space removed.  profiles/traffic.json
     and profiles/valu.json entries carry it (tools/derive_traffic.py, tools/derive_valu.py); an entry made from other
     sources than the ones in this tree is NOT used -- `roofline.traffic` / `valu_frac` then print null instead of a stale
     number that merely shares the kernel's label."""
@@ -107,7 +107,10 @@ def csrc_hash():
         import hashlib
         import re
         csrc = os.path.join(ROOT, 'gym-mapf_amd', 'csrc')
-        files = sorted(glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.hpp'))) + [os.path.join(ROOT, 'include', 'mapf_hip.h')]
+        # (mapf_transitions.hip holds the env.P kernels only -- no traffic / valu entry describes them -- so editing it does not
+        # orphan the rollout / step kernels' counter profiles)
+        files = sorted(f for f in glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.hpp'))
+                       if os.path.basename(f) != 'mapf_transitions.hip') + [os.path.join(ROOT, 'include', 'mapf_hip.h')]
         h = hashlib.sha256()
         for path in files:
             with open(path) as f:

@@ -164,9 +164,15 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
     constexpr uint32_t kQueryBytes = kQueryHeader + uint32_t(MAXA) * 3u * kRecord;
     const uint32_t QW = 1u << qw_log2;                             // queries per wave (>= 4: the prefix array stays 16-byte aligned)
     const uint32_t lane = threadIdx.x & 63u;
-    unsigned char *const wave_lds = lds_dyn + (threadIdx.x >> 6) * (QW * (kQueryBytes + 4u));
+    // COOP (the 6- and 8-agent instances): a query's set-up is spread over the G = 64 / QW >= 8 lanes of its group, one lane per
+    // AGENT -- done by one lane per query, four lanes of a wave working, it was 27 % of the kernel's vector instructions
+    // (profiles/r05_transitions_a8_q20000_compact.txt: ~2600 per piece against ~180 per 64 rows)
+    constexpr bool COOP = MAXA >= 6;
+    constexpr uint32_t kScratch = COOP ? uint32_t(MAXA) * 16u : 0u;    // per query: {prev, the three list cells} of every agent
+    unsigned char *const wave_lds = lds_dyn + (threadIdx.x >> 6) * (QW * (kQueryBytes + 4u + kScratch));
     uint32_t *const prefix = reinterpret_cast<uint32_t *>(wave_lds);                     // [QW] exclusive prefix of the windows' lengths
     unsigned char *const queries = wave_lds + QW * 4u;                                     // [QW] header + records
+    unsigned char *const scratch = queries + QW * kQueryBytes;                             // [QW][MAXA] uint4 (COOP)
     const uint64_t wave = (uint64_t(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
     uint64_t batch = wave;
     uint32_t piece = 0u;
@@ -183,8 +189,100 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
         if (pieces_max > 1u && piece > 0u && uint64_t(row_begin) >= end - base) return;   // (piece 0 stays: it reports the counts)
     }
 
+    uint32_t rows = 0u;                                            // the window's length, in the lane that reports it to the scan
+    if constexpr (COOP) {
+        // ---- set-up, one lane per (query, agent): group gq = lane / G owns query q0 + gq, lane r = lane % G < MAXA its agent r
+        const uint32_t g_log2 = 6u - qw_log2, G = 1u << g_log2, gq = lane >> g_log2, r = lane & (G - 1u);
+        const uint64_t q = q0 + gq;
+        const bool live = q < p.n_queries, slot = r < uint32_t(MAXA), on = live && r < A;
+        unsigned char *const mine = queries + gq * kQueryBytes;
+        uint4 *const mine_scratch = reinterpret_cast<uint4 *>(scratch + gq * kScratch);
+        // group reductions over the G lanes of a query (G = 8 or 16: xor shuffles stay inside the group)
+        auto group_or = [&](uint32_t v) __attribute__((always_inline)) {
+            for (uint32_t d = 1; d < G; d <<= 1) v |= uint32_t(__shfl_xor(int(v), int(d), 64));
+            return v;
+        };
+        auto group_sum = [&](uint32_t v) __attribute__((always_inline)) {
+            for (uint32_t d = 1; d < G; d <<= 1) v += uint32_t(__shfl_xor(int(v), int(d), 64));
+            return v;
+        };
+        auto group_product = [&](uint32_t v) __attribute__((always_inline)) {
+            for (uint32_t d = 1; d < G; d <<= 1) v *= uint32_t(__shfl_xor(int(v), int(d), 64));
+            return v;
+        };
+        uint32_t prev = 0x10000u + r, goal = 0x10000u + r, act = 0u, n = 1u, cell[3];
+        double pr[3] = {1.0, 1.0, 1.0};                             // (x * 1.0 is exact: absent agents leave the product alone)
+        MoveEntry entry{0u, 0u, 0u, 7u * uint32_t(sizeof(SlipRow))};
+        if (on) {
+            const uint64_t env = p.env_index ? p.env_index[q] : 0;
+            prev = p.local[q * A + r];
+            goal = p.goal[(p.goal_broadcast ? 0 : env * A) + r];
+            const uint32_t a = p.actions[q * A + r];
+            act = a > 4u ? 0u : a;
+            entry = move_entry(p.mv, p.c.n_cells, prev, act);
+            const SlipRow &row = slip[entry_code(entry)];
+            n = row.n;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pr[k] = row.q[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const uint32_t c = on ? entry_cell(entry, uint32_t(k)) : prev;
+            if (slot) *reinterpret_cast<uint4 *>(mine + kQueryHeader + (3u * r + uint32_t(k)) * kRecord) =
+                make_uint4((c & 0xFFFFu) | (c != goal ? 0x10000u : 0u), 0u, uint32_t(__double2loint(pr[k])), uint32_t(__double2hiint(pr[k])));
+            cell[k] = uint32_t(k) < n ? c : 0x20000u + 3u * r + uint32_t(k);   // an entry past the list's end: a cell nothing can equal
+        }
+        if (slot) mine_scratch[r] = make_uint4(prev, cell[0], cell[1], cell[2]);
+        const uint32_t radix_all = group_or(slot ? n << (2u * r) : 0u);
+        uint32_t count = group_product(n);
+        const uint32_t goal_acc = group_or(prev ^ goal);
+        const int stayed = int(group_sum((on && prev == goal && act == 0u) ? 1u : 0u));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // my agent's entries against every entry of every LATER agent: vertex (same next cell) or swap (each moves onto the
+        // other's current cell) -- _is_collision_transition_from_local_states, mapf_env.py:378-389; integer tests (t == 0 <=> hit)
+        uint32_t mask[3] = {0u, 0u, 0u}, dup = 0u;
+#pragma unroll
+        for (int j = 1; j < MAXA; ++j) {
+            const uint4 other = mine_scratch[j];                   // {prev_j, c_j[0..2]}
+            const uint32_t later = uint32_t(j) > r ? 1u : 0u;
+            dup |= (((prev ^ other.x) - 1u) >> 31) & later;         // is_terminal: two agents share a cell (mapf_env.py:210-223)
+            const uint32_t cj[3] = {other.y, other.z, other.w};
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int kj = 0; kj < 3; ++kj) {
+                    const uint32_t t = min(cell[k] ^ cj[kj], (prev ^ cj[kj]) | (other.x ^ cell[k]));
+                    mask[k] |= (((t - 1u) >> 31) & later) << (3 * j + kj);
+                }
+        }
+        const bool terminal = group_or(dup) != 0u || goal_acc == 0u;
+        if (terminal) count = 1u;
+        if (slot) {
+            if (terminal) {   // the single branch ((1.0, False), s, 0, True): every agent's one entry is its own cell, probability 1.0
+                *reinterpret_cast<uint4 *>(mine + kQueryHeader + (3u * r) * kRecord) =
+                    make_uint4((prev & 0xFFFFu) | (prev != goal ? 0x10000u : 0u), 0u, 0u, 0x3FF00000u);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) *reinterpret_cast<uint32_t *>(mine + kQueryHeader + (3u * r + uint32_t(k)) * kRecord + 4) = mask[k];
+            }
+        }
+        if (r == 0u) {                                              // the group's first lane: header, counts, the window's length
+            QueryHeader hdr{};
+            if (live) {
+                uint32_t lo;
+                rows = window_rows(count, p.first_branch, p.max_branches, lo);
+                if (p.out_count && piece == 0u) p.out_count[q] = count;
+                hdr.first = lo;
+                hdr.terminal = terminal ? 1u : 0u;
+                hdr.living = p.c.criteria == 1u ? __dmul_rn(double(int(A) - stayed), p.c.r_living) : p.c.r_living;
+                hdr.radix = terminal ? (0x55555555u >> (32 - 2 * MAXA)) : radix_all;
+            }
+            *reinterpret_cast<QueryHeader *>(mine) = hdr;
+        }
+    } else
     // ---- set-up: lane l < QW owns query q0 + l
-    uint32_t rows = 0u;
     if (lane < QW) {
         const uint64_t q = q0 + lane;
         unsigned char *const mine = queries + lane * kQueryBytes;
@@ -266,11 +364,15 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
         *reinterpret_cast<QueryHeader *>(mine) = hdr;
     }
     const uint32_t incl = wave_inclusive_scan(rows, lane);
-    if (lane < QW) prefix[lane] = incl - rows;
+    // (COOP: a query's length sits in its group's first lane, the other lanes contribute zero)
+    const uint32_t g_shift = COOP ? 6u - qw_log2 : 0u;
+    const bool reports = COOP ? (lane & ((1u << g_shift) - 1u)) == 0u : lane < QW;
+    const uint32_t my_query = lane >> g_shift;
+    if (reports) prefix[my_query] = incl - rows;
     const uint32_t total = uint32_t(__shfl(int(incl), 63, 64));
     // compacted rows: the wave's queries are consecutive, so their rows are one contiguous range from the first one's offset
     const bool compact = p.compact;
-    if (compact && piece == 0u && p.out_offset && lane < QW && q0 + lane < p.n_queries) p.out_offset[q0 + lane] = base + (incl - rows);
+    if (compact && piece == 0u && p.out_offset && reports && q0 + my_query < p.n_queries) p.out_offset[q0 + my_query] = base + (incl - rows);
     // (the wave's lanes wrote the records / prefix sums the others read below: same wave, LDS operations execute in order)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -541,14 +643,19 @@ static hipError_t launch_rows(const TransitionsArgs &args, hipStream_t stream) {
     uint32_t qw_log2 = 6;
     while (qw_log2 > 2 && 4u * (kQueryBytes + 4u) * (1u << qw_log2) > 36u * 1024u) --qw_log2;
     while (qw_log2 > (MAXA >= 8 ? 2u : 3u) && (args.n_queries >> qw_log2) < 16384u) --qw_log2;
-    // rows per wave: a batch's windows can hold QW x min(3^A, max_branches) rows; beyond 4096 (64 sweeps; 1024 while the
-    // queries are few) they are cut into pieces -- which needs the scan, as compacted rows do
+    if (MAXA >= 6 && qw_log2 > 3u) qw_log2 = 3u;                     // (cooperative set-up: a query's group has a lane per agent)
+    // rows per wave: a batch's windows can hold QW x min(3^A, max_branches) rows; beyond two pieces' worth they are cut into
+    // pieces -- which needs the scan, as compacted rows do.  Pieces of 1024 rows (16 sweeps) while the call is small, so that it
+    // still makes ~24 K waves' worth of work (a room map fills about a fifth of the rows a query can have), up to 4096 for large
+    // calls, where fewer set-ups per row count (profiles/r05_transitions_launch_shapes.txt: 20000 queries of 8 agents 0.43 of the
+    // roofline with 1024-row pieces, 0.37 with 4096; 200000 queries 0.54 against 0.60-0.68)
     uint64_t most = 1;
     for (uint32_t i = 0; i < args.n_agents && most < args.max_branches; ++i) most *= 3u;
     if (most > args.max_branches) most = args.max_branches;
+    const uint64_t est_rows = args.n_queries * most / 5u;
+    uint32_t rows_per_wave = 1024u;
+    while (rows_per_wave < 4096u && est_rows / (2u * rows_per_wave) >= 24576u) rows_per_wave *= 2u;
     most <<= qw_log2;
-    const uint32_t rows_per_wave = args.n_queries >= 16384u ? 4096u : 1024u;
-
     const uint32_t pieces_max = most > 2u * rows_per_wave ? uint32_t((most + rows_per_wave - 1) / rows_per_wave) : 1u;
     if (args.compact || pieces_max > 1u) {
         if (hipError_t e = launch_transitions_offsets(args, stream)) return e;
@@ -561,10 +668,11 @@ static hipError_t launch_rows(const TransitionsArgs &args, hipStream_t stream) {
     const unsigned wpb = MAXA >= 6 ? 1u : 4u;
     const uint64_t grid64 = (waves + wpb - 1) / wpb;
     if (grid64 > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    const size_t lds = wpb * size_t(kQueryBytes + 4u) * (size_t(1) << qw_log2);
+    const size_t lds = wpb * size_t(kQueryBytes + 4u + (MAXA >= 6 ? MAXA * 16u : 0u)) * (size_t(1) << qw_log2);
     const bool all_out = args.out_next && args.out_prob && args.out_reward && args.out_done && args.out_collision;
     note_kernel("transitions_rows_kernel<%d> %u agents, %u queries per wave%s, %s rows", MAXA, args.n_agents, 1u << qw_log2,
-                pieces_max > 1u ? (rows_per_wave == 4096u ? " in pieces of 4096 rows" : " in pieces of 1024 rows") : "", args.compact ? "compacted" : "reserved");
+                pieces_max > 1u ? (rows_per_wave == 4096u ? " in pieces of 4096 rows" : (rows_per_wave == 2048u ? " in pieces of 2048 rows" : " in pieces of 1024 rows")) : "",
+                args.compact ? "compacted" : "reserved");
     if (all_out) hipLaunchKernelGGL((transitions_rows_kernel<MAXA, true>), dim3(unsigned(grid64)), dim3(64 * wpb), lds, stream, args, qw_log2, pieces_max, rows_per_wave);
     else hipLaunchKernelGGL((transitions_rows_kernel<MAXA, false>), dim3(unsigned(grid64)), dim3(64 * wpb), lds, stream, args, qw_log2, pieces_max, rows_per_wave);
     return hipGetLastError();
