@@ -656,7 +656,8 @@ static hipError_t launch_rows(const TransitionsArgs &args, hipStream_t stream) {
     uint32_t rows_per_wave = 1024u;
     while (rows_per_wave < 4096u && est_rows / (2u * rows_per_wave) >= 24576u) rows_per_wave *= 2u;
     most <<= qw_log2;
-    const uint32_t pieces_max = most > 2u * rows_per_wave ? uint32_t((most + rows_per_wave - 1) / rows_per_wave) : 1u;
+    // (the small teams' batches -- at most 64 x 81 rows, set up by one lane per query -- stay whole: their waves all do the same work)
+    const uint32_t pieces_max = (MAXA >= 6 && most > 2u * rows_per_wave) ? uint32_t((most + rows_per_wave - 1) / rows_per_wave) : 1u;
     if (args.compact || pieces_max > 1u) {
         if (hipError_t e = launch_transitions_offsets(args, stream)) return e;
     }
