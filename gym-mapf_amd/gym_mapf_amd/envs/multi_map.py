@@ -15,7 +15,11 @@ Two modes, as ``VecMapfEnv``:
     that starts at a multiple of 16 envs) the run's handle reads and writes the caller's tensors IN PLACE; other runs go
     through per-run staging tensors and device-to-device copies on the same stream.
 
-There is no CPU implementation behind it either.
+``UnionMapVecEnv`` (below) is the ONE-LAUNCH form of the same thing: the batch's distinct maps become one move table -- their
+disjoint union, a block-diagonal neighbour table: no move leads from one map into another -- behind a single handle, so a
+step / rollout of the whole mixed batch is one kernel launch whatever the order of the maps (at most 65536 free cells in total).
+
+There is no CPU implementation behind either.
 """
 import numpy as np
 
@@ -226,3 +230,138 @@ class MultiMapVecEnv:
         for _, env in reversed(self._parts):            # (the first handle owns the shared stream: it goes last)
             env.close()
         self._parts = []
+
+
+class UnionGrid:
+    """The disjoint union of several ``MapfGrid`` s as ONE table: the free cells of grid k get the ids ``base[k] .. base[k] +
+    V_k - 1`` (each grid's own column-major order, reference mapf_env.py:142), ``nbr`` is block-diagonal.  Only what
+    ``VecMapfEnv`` asks of a grid: ``tables()``."""
+
+    def __init__(self, grids):
+        self.grids = list(grids)
+        self.base, valid, rows = [], [], []
+        for g in self.grids:
+            v, _, nbr = g.tables()
+            self.base.append(len(valid))
+            rows.append(nbr.astype(np.int64) + len(valid))
+            valid.extend(v)
+        if len(valid) > 65536:
+            raise ValueError('the maps of one batch have %d free cells together: local ids are uint16 (at most 65536)' % len(valid))
+        self._tables = (valid, None, np.concatenate(rows).astype(np.uint16))
+
+    def tables(self):
+        return self._tables
+
+
+class UnionMapVecEnv:
+    """A batch whose envs live on different maps, stepped by ONE launch (``MultiMapVecEnv``: one per run of same-map envs).
+
+    Every reference env owns its grid (gym_mapf/envs/mapf_env.py:127).  Here the distinct grids of the batch are laid side by
+    side in one move table (``UnionGrid``) behind a single ``VecMapfEnv`` handle; an env's cells are its own map's local ids
+    plus the map's base, which this wrapper adds on the way in (``set_state``) and takes off on the way out -- callers see each
+    env's cells in ITS map's numbering, exactly as from ``MultiMapVecEnv`` or from one ``VecMapfEnv`` per env.  Env e keeps
+    the global id ``env_id_offset + e``, so it draws what it would draw alone.  Same constructor arguments as
+    ``MultiMapVecEnv``; host mode (numpy) or ``device_arrays=True`` (torch CUDA tensors, everything on the handle's stream)."""
+
+    def __init__(self, grids, n_agents, start_locations, goal_locations, fail_prob, reward_of_collision, reward_of_goal,
+                 reward_of_living, optimization_criteria, *, seed=42, env_id_offset=0, device=0, device_arrays=False,
+                 stream=None):
+        self.n_envs, self.n_agents = len(grids), int(n_agents)
+        self.device_arrays = bool(device_arrays)
+        if len(start_locations) != self.n_envs or len(goal_locations) != self.n_envs:
+            raise ValueError('one start / goal row per env')
+        distinct, which = [], np.empty(self.n_envs, np.int64)
+        for e, g in enumerate(grids):
+            for k, d in enumerate(distinct):
+                if g is d or g == d:
+                    which[e] = k
+                    break
+            else:
+                which[e] = len(distinct)
+                distinct.append(g)
+        self.grids = distinct
+        self.union = UnionGrid(distinct)
+        base = np.asarray(self.union.base, np.int64)[which]
+        l2i = [g.tables()[1] for g in distinct]
+        A = self.n_agents
+
+        def to_union(locations, what):
+            out = np.empty((self.n_envs, A), np.int64)
+            for e in range(self.n_envs):
+                locs = locations[e]
+                if len(locs) != A:
+                    raise AssertionError('%r locations number is different than the number of agents %d' % (locs, A))
+                out[e] = [l2i[which[e]][(int(l[0]), int(l[1]))] for l in locs]      # KeyError: obstacle / out-of-map cell
+            return (out + base[:, None]).astype(np.uint16)
+        self._base_host = base.astype(np.uint16).reshape(-1, 1)
+        self._env = VecMapfEnv(self.union, A, None, None, fail_prob, reward_of_collision, reward_of_goal, reward_of_living,
+                               optimization_criteria, seed=seed, env_id_offset=env_id_offset, device=device,
+                               device_arrays=self.device_arrays, stream=stream,
+                               start_local=to_union(start_locations, 'start'), goal_local=to_union(goal_locations, 'goal'))
+        self._torch = self._env._torch
+        self._base = self._base_host
+        if self.device_arrays:
+            t = self._torch
+            self._base = t.from_numpy(self._base_host.view(np.int16)).to(self._env._tdev)     # (int16 bits: torch has no uint16 arithmetic)
+
+    n_handles = 1
+
+    @property
+    def stream(self):
+        return self._env.stream
+
+    def _on_stream(self):
+        t = self._torch
+        return t.cuda.stream(t.cuda.ExternalStream(self._env.stream))
+
+    def _own(self, local):
+        """union ids -> each env's own map's ids (any leading step axis)"""
+        if self.device_arrays:
+            t = self._torch
+            with self._on_stream():
+                return (local.view(t.int16) - self._base).view(t.uint16)        # (mod 2^16: the same bits as unsigned subtraction)
+        return (local - self._base_host).astype(np.uint16)
+
+    def _union(self, local):
+        if self.device_arrays:
+            t = self._torch
+            with self._on_stream():
+                return (local.view(t.int16) + self._base).view(t.uint16)
+        return (np.asarray(local, np.uint16) + self._base_host).astype(np.uint16)
+
+    # -------------------------------------------------------------------------- API (as VecMapfEnv / MultiMapVecEnv)
+    def reset(self, mask=None):
+        self._env.reset(mask)
+
+    def step(self, actions, uniforms=None, auto_reset=False):
+        """One ``MapfEnv.step()`` per env in ONE launch; cells are local ids OF EACH ENV'S OWN MAP."""
+        local, reward, done, info = self._env.step(actions, uniforms=uniforms, auto_reset=auto_reset)
+        return self._own(local), reward, done, info
+
+    def rollout(self, n_steps, actions=None, auto_reset=True, record=False):
+        res = self._env.rollout(n_steps, actions=actions, auto_reset=auto_reset, record=record)
+        if record:
+            res['local'] = self._own(res['local'])
+        return res
+
+    def set_policy(self, policy='random'):
+        self._env.set_policy(policy)
+
+    def get_state(self):
+        local, t = self._env.get_state()
+        return self._own(local), t
+
+    def set_state(self, local=None, t=None):
+        self._env.set_state(None if local is None else self._union(local), t)
+
+    def query_terminal(self):
+        return self._env.query_terminal()
+
+    def last_kernel(self, which='rollout'):
+        return self._env.last_kernel(which)
+
+    def sync(self):
+        self._env.sync()
+
+    def close(self):
+        self._env.close()

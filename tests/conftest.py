@@ -12,6 +12,11 @@ for p in (os.path.join(ROOT, 'gym-mapf_amd'), os.path.join(ROOT, 'oracle'), ROOT
     if p not in sys.path:
         sys.path.insert(0, p)
 
+try:    # torch wheels bundle their own HIP runtime: it has to be in the process BEFORE libmapf_hip.so pulls in the system one,
+    import torch  # noqa: F401    # or a later device-mode test reports "No HIP GPUs" -- whichever test file happens to run first
+except ImportError:
+    pass
+
 TRAJECTORY_SETS = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith('.npz'))
 
 

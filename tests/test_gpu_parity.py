@@ -1086,6 +1086,86 @@ def test_mixed_map_batch_keeps_every_envs_own_stream():
     env.close()
 
 
+def test_mixed_map_batch_in_one_launch_through_the_union_table():
+    """UnionMapVecEnv: the batch's distinct maps side by side in ONE move table (block-diagonal neighbour table) behind one
+    handle -- a step / rollout of the mixed batch is one launch.  Every env against its own pure-Python oracle (cells in its
+    OWN map's numbering, the uniforms of its global id), then a 4096-env batch on three 16x16 maps in an interleaved order
+    against MultiMapVecEnv (one handle per run), host and device mode."""
+    from gym_mapf_amd.envs.multi_map import MultiMapVecEnv, UnionMapVecEnv
+    rs = np.random.RandomState(17)
+    maps = [['....', '.@..', '....'], ['.....', '..@..', '.....', '.....'], ['...', '...', '...']]
+    A, E, off = 3, 14, 1000
+    pick = [0, 0, 0, 1, 1, 2, 2, 2, 2, 0, 1, 1, 0, 2]
+    grids = [MapfGrid(m) for m in maps]
+    starts, goals, oracles = [], [], []
+    for e in range(E):
+        valid = grids[pick[e]].tables()[0]
+        s = [valid[i] for i in rs.choice(len(valid), A, replace=False)]
+        g = [valid[i] for i in rs.choice(len(valid), A, replace=False)]
+        starts.append(s), goals.append(g)
+        oracles.append(mo.OracleEnv(maps[pick[e]], A, s, g, 0.3, -10.0, 5.0, -1.0, mo.SOC))
+    env = UnionMapVecEnv([grids[k] for k in pick], A, starts, goals, 0.3, -10.0, 5.0, -1.0, OptimizationCriteria.SoC, seed=8, env_id_offset=off)
+    assert env.n_handles == 1 and len(env.grids) == 3
+    ids = off + np.arange(E)
+    for t in range(40):
+        acts = philox.random_actions_np(8, ids, t, A)
+        u = philox.slip_uniforms_np(8, ids, t, A)
+        local, reward, done, info = env.step(acts, auto_reset=True)
+        for e, o in enumerate(oracles):
+            nxt, r, d, c, p, wt = o.step(acts[e].tolist(), u[e].tolist())
+            assert list(nxt) == local[e].tolist() and _bits(r) == _bits(reward[e]) and _bits(p) == _bits(info['prob'][e]), (t, e)
+            assert (d, c, wt) == (bool(done[e]), bool(info['collision'][e]), bool(info['was_terminal'][e])), (t, e)
+            if d:
+                o.reset()
+    res = env.rollout(25, auto_reset=True, record=True)            # in-kernel policy stream; recorded cells in each map's own ids
+    for e, o in enumerate(oracles):
+        for k, t in enumerate(range(40, 65)):
+            a = philox.random_actions_np(8, [off + e], t, A)[0].tolist()
+            nxt, r, d, c, p, wt = o.step(a, philox.slip_uniforms_np(8, [off + e], t, A)[0].tolist())
+            assert list(nxt) == res['local'][k, e].tolist() and _bits(r) == _bits(res['reward'][k, e]), (e, t)
+            if d:
+                o.reset()
+    state, t_now = env.get_state()
+    assert t_now == 65 and all(state[e].tolist() == list(o.local) for e, o in enumerate(oracles))
+    env.set_state(state, t=65)                                     # (round trip through the union numbering)
+    assert np.array_equal(env.get_state()[0], state)
+    env.close()
+    # a batch large enough for the packed kernels, maps interleaved in runs of 32 envs: one launch against one per run
+    rs = np.random.RandomState(23)
+    big = [MapfGrid([''.join('@' if rs.rand() < 0.15 else '.' for _ in range(16)) for _ in range(16)]) for _ in range(3)]
+    E, A = 4096, 4
+    order = [big[(e // 32) % 3] for e in range(E)]
+    starts, goals = [], []
+    for e in range(E):
+        valid = order[e].tables()[0]
+        cells = rs.choice(len(valid), 2 * A, replace=False)
+        starts.append([valid[i] for i in cells[:A]]), goals.append([valid[i] for i in cells[A:]])
+    args = (order, A, starts, goals, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan)
+    one, many = UnionMapVecEnv(*args, seed=5), MultiMapVecEnv(*args, seed=5)
+    assert many.n_handles == 128
+    acts = rs.randint(0, 5, size=(6, E, A)).astype(np.uint8)
+    for t in range(6):
+        a, b = one.step(acts[t], auto_reset=True), many.step(acts[t], auto_reset=True)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(_bits(a[1]), _bits(b[1])) and np.array_equal(a[2], b[2]), t
+        assert np.array_equal(_bits(a[3]['prob']), _bits(b[3]['prob'])) and np.array_equal(a[3]['collision'], b[3]['collision']), t
+    ra, rb = one.rollout(20, auto_reset=True), many.rollout(20, auto_reset=True)
+    assert np.array_equal(_bits(ra['returns']), _bits(rb['returns'])) and np.array_equal(ra['episodes'], rb['episodes'])
+    assert np.array_equal(one.get_state()[0], many.get_state()[0]) and int(ra['episodes'].sum()) > 0
+    assert one.last_kernel('rollout').startswith('lq_rollout_kernel'), one.last_kernel('rollout')
+    one.close(), many.close()
+    import torch
+    dev = UnionMapVecEnv(*args, seed=5, device_arrays=True)
+    ref = MultiMapVecEnv(*args, seed=5)
+    with torch.cuda.stream(torch.cuda.ExternalStream(dev.stream)):
+        acts_t = torch.from_numpy(acts).cuda()
+    for t in range(3):
+        a = dev.step(acts_t[t], auto_reset=True)
+        dev.sync()
+        b = ref.step(acts[t], auto_reset=True)
+        assert np.array_equal(a[0].cpu().numpy(), b[0]) and np.array_equal(_bits(a[1].cpu().numpy()), _bits(b[1])), t
+    dev.close(), ref.close()
+
+
 def test_rollout_beyond_one_launch_is_issued_in_slices(monkeypatch):
     """The C ABI rejects a launch whose largest array exceeds 4 GiB or that has more than 65535 steps; VecMapfEnv.rollout
     then issues the steps as several launches over consecutive slices of the same arrays.  Forced here with a limit of
