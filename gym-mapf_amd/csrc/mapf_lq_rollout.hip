@@ -121,24 +121,51 @@ __global__ void __launch_bounds__((K == 8 || (COMPACT && BITMAP == 1 && !STREAM)
     // steps are shorter): the loaded-HBM round trip, with the trajectory stores of the same wave queued in front of it
     // (vmcnt counts loads and stores in order), is longer than two steps -- fetched two ahead, the two-agents-per-lane
     // form ran 23 % slower than with L2-resident actions, the wait for the action word being the largest stall left.
-    // Invariant at the top of step s: raw[j] holds row s+j (j < kAhead), act_lane points at row min(s+kAhead-1, last).
-    // A step consumes the register that holds its row and reloads THAT register with row s+kAhead, so in the unrolled
-    // part of the loop the registers simply take turns (rotating a register through a move would be a use, i.e. a
-    // wait); a single step outside it uses raw[0] and shifts the others down afterwards.
+    // A step consumes the register that holds its row and reloads THAT register with row s+kAhead: a register is never
+    // moved while its load is in flight (a move is a use, i.e. a wait for the round trip just requested).
+    // kAhead == 4 (WORD_SLOTS): raw[k] holds the row of the next step whose index t has t & 3 == k -- the slip stream's word
+    // index, which every step body knows statically; the launch's head steps (head_steps: h of them) have registers of
+    // their own.  Invariant at the top of step s >= h: raw[(t_first+s+j) & 3] holds row min(s+j, last) (j < 4), act_lane
+    // points at row min(s+3, last).
+    // Otherwise (two agents per lane: kAhead == 8): raw[j] holds row s+j at the top of step s, act_lane points at row min(s+kAhead-1, last); a single step
+    // outside the unrolled loop uses raw[0] and shifts the others down afterwards.
     constexpr uint32_t kAhead = K == 2 ? 8 : 4;
+    // (Streamed actions only: an in-kernel policy has no action registers to keep still, and its instances -- the policy words of
+    // four steps live across the loop -- spill under this loop's extra step bodies, whatever form the head takes: 9 to 45 of the
+    // 96 recording instances with four or eight agents per lane did, up to 157 registers.  They keep the older loop.)
+    constexpr bool WORD_SLOTS = STREAM && kAhead == 4;
     using RawWord = std::conditional_t<K == 8, uint64_t, uint32_t>;   // one action byte per agent of the lane
     const uint32_t last_row = p.n_steps ? p.n_steps - 1u : 0u;
-    auto load_raw = [&]() __attribute__((always_inline)) {
-        if constexpr (K == 8) return *reinterpret_cast<const uint64_t *>(act_lane);
-        else return K == 4 ? *reinterpret_cast<const uint32_t *>(act_lane) : uint32_t(*reinterpret_cast<const uint16_t *>(act_lane));
+    auto load_raw_at = [&](const uint8_t *at_row) __attribute__((always_inline)) {
+        if constexpr (K == 8) return *reinterpret_cast<const uint64_t *>(at_row);
+        else return K == 4 ? *reinterpret_cast<const uint32_t *>(at_row) : uint32_t(*reinterpret_cast<const uint16_t *>(at_row));
     };
+    auto load_raw = [&]() __attribute__((always_inline)) { return load_raw_at(act_lane); };
     RawWord raw[kAhead] = {};
+    RawWord raw_first = 0, raw_head[2] = {};
+    // head steps: the first one, and those up to the first word boundary of a launch that does not start at one (or is
+    // shorter than four steps) -- they have registers of their own, loaded with everything else at the kernel's start
+    auto head_steps = [](const uint32_t t0, const uint32_t n) __attribute__((always_inline)) {
+        return (t0 & 3u) == 0u ? (n >= kAhead ? 1u : n) : min(n, 4u - (t0 & 3u));
+    };
     if (STREAM && p.n_steps > 0) {
-        raw[0] = load_raw();
+        const uint64_t row_stride = uint64_t(uint32_t(p.n_envs)) * n_agents;
+        if constexpr (WORD_SLOTS) {
+            raw_first = load_raw();
+            raw_head[0] = load_raw_at(act_lane + min(1u, last_row) * row_stride);
+            raw_head[1] = load_raw_at(act_lane + min(2u, last_row) * row_stride);
+            const uint32_t h = head_steps(uint32_t(first_step_index(p)), p.n_steps);
 #pragma unroll
-        for (uint32_t j = 1; j < kAhead; ++j) {
-            act_lane += last_row >= j ? uint64_t(uint32_t(p.n_envs)) * n_agents : 0u;   // clamped, not guarded: late rows are re-read
-            raw[j] = load_raw();
+            for (uint32_t k = 0; k < kAhead; ++k)                     // clamped, not guarded: late rows are re-read
+                raw[k] = load_raw_at(act_lane + min(h + ((k - uint32_t(first_step_index(p)) - h) & 3u), last_row) * row_stride);
+            act_lane += min(h + kAhead - 1u, last_row) * row_stride;
+        } else {
+            raw[0] = load_raw();
+#pragma unroll
+            for (uint32_t j = 1; j < kAhead; ++j) {
+                act_lane += last_row >= j ? row_stride : 0u;           // clamped, not guarded: late rows are re-read
+                raw[j] = load_raw();
+            }
         }
     }
     if constexpr (COMPACT && BITMAP == 3) {
@@ -249,6 +276,7 @@ __global__ void __launch_bounds__((K == 8 || (COMPACT && BITMAP == 1 && !STREAM)
     asm volatile("" : "+v"(wide_lane), "+v"(prob_lane), "+v"(narrow_lane), "+v"(coll_lane), "+v"(rec_lane));
 #pragma unroll
     for (uint32_t j = 0; j < kAhead; ++j) asm volatile("" : "+v"(raw[j]));   // consumed here: the loop's waits are counted ones
+    asm volatile("" : "+v"(raw_first), "+v"(raw_head[0]), "+v"(raw_head[1]));
     Words4 rng[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) rng[i] = Words4{0u, 0u, 0u, 0u};
@@ -405,8 +433,9 @@ __global__ void __launch_bounds__((K == 8 || (COMPACT && BITMAP == 1 && !STREAM)
 
     // One step.  W = which word of the slip calls this step uses (t & 3) when that is a compile-time fact, -1 = generic
     // (word picked at run time, call refreshed when t is a multiple of four).  FIRST = the launch's first step: nothing
-    // is pending yet and the slip call is refreshed whatever t is.  TAIL = the action rows may run out within kAhead
-    // steps, so the prefetch address is clamped.  `raw` is the register that holds this step's action word.
+    // is pending yet and the slip call is refreshed whatever t is.  TAIL = 1: the action rows may run out within kAhead
+    // steps, so the prefetch address is clamped; 2: no prefetch (the first step of a WORD_SLOTS launch, whose register is its
+    // own).  `raw` is the register that holds this step's action word.
     // (delta rows: the slot selects a byte -- steps of one, the row's byte 2 down to 0, zeros above it)
     uint32_t pk_eights = 0x00080008u, pk_steps = BITMAP == 3 ? 0x00010001u : 0x02020202u, sel_base = BITMAP == 3 ? 0x0C0C0C02u : 0x0C0C0504u;   // sample_slot_packed's constants,
     asm volatile("" : "+v"(pk_eights), "+v"(pk_steps), "+v"(sel_base));                   // one vector register each
@@ -414,7 +443,8 @@ __global__ void __launch_bounds__((K == 8 || (COMPACT && BITMAP == 1 && !STREAM)
     asm volatile("" : "+v"(row_bytes));   // (one register for the whole loop; as an SGPR operand the assembler rejects the SDWA form)
     auto one_step = [&](const uint32_t s, RawWord &raw, auto w_tag, auto first_tag, auto tail_tag) __attribute__((always_inline)) {
         constexpr int W = decltype(w_tag)::value;
-        constexpr bool FIRST = decltype(first_tag)::value, TAIL = decltype(tail_tag)::value;
+        constexpr bool FIRST = decltype(first_tag)::value;
+        constexpr int TAIL = int(decltype(tail_tag)::value);
         constexpr bool MAYBE_TERMINAL = TERM || FIRST;   // (the launch's first step finds whatever state the last launch left)
         const uint64_t t = t_first + s;
         double qv[K];                                              // SYS: the factors of this step's chain round
@@ -442,8 +472,10 @@ __global__ void __launch_bounds__((K == 8 || (COMPACT && BITMAP == 1 && !STREAM)
             }
 #pragma unroll
             for (int k = 0; k < K; ++k) asm volatile("" : "+v"(act[k]));   // the wait for `raw` sits here
-            act_lane += (!TAIL || s + kAhead <= last_row) ? step_cells : 0u;   // row min(s + kAhead, last)
-            raw = load_raw();
+            if constexpr (TAIL != 2) {
+                act_lane += (!TAIL || s + kAhead <= last_row) ? step_cells : 0u;   // row min(s + kAhead, last)
+                raw = load_raw();
+            }
         } else if (p.policy_cells) {   // greedy policy
 #pragma unroll
             for (int k = 0; k < K; ++k) act[k] = greedy_action(p.policy_cells, p.c.n_cells, cur[k], goal_rc[k]);
@@ -504,7 +536,7 @@ __global__ void __launch_bounds__((K == 8 || (COMPACT && BITMAP == 1 && !STREAM)
                 rec_lane += step_cells;
                 // SYS: the last lane's probability rows trail by Q - 1 steps -- its pointer rests on row 0 (which the early,
                 // incomplete products overwrite until the right one arrives) while s < Q; the unrolled loop only runs beyond that
-                if (SYS && TAIL) wide_lane += (tail && s < uint32_t(Q)) ? 0u : step_rows;
+                if (SYS && TAIL != 0) wide_lane += (tail && s < uint32_t(Q)) ? 0u : step_rows;
                 else wide_lane += step_rows;
                 narrow_lane += step_rows;
                 if (Q == 1) { prob_lane += step_rows; coll_lane += step_rows; }
@@ -699,45 +731,87 @@ __global__ void __launch_bounds__((K == 8 || (COMPACT && BITMAP == 1 && !STREAM)
     using W3 = std::integral_constant<int, 3>;
     using Yes = std::true_type;
     using No = std::false_type;
+    using Skip = std::integral_constant<int, 2>;
     auto shift_raw = [&]() __attribute__((always_inline)) {   // after a single step: raw[0] was reloaded with row s + kAhead
         const RawWord newest = raw[0];
 #pragma unroll
         for (uint32_t j = 0; j + 1 < kAhead; ++j) raw[j] = raw[j + 1];
         raw[kAhead - 1] = newest;
     };
-    // a single step outside the unrolled loop: its slip word is still picked statically (one four-way branch instead of
-    // the word selects inside the step), its prefetch address is clamped
-    auto single_step = [&](const uint32_t s) __attribute__((always_inline)) {
-        switch (uint32_t(t_first + s) & 3u) {
-            case 0: one_step(s, raw[0], W0{}, No{}, Yes{}); break;
-            case 1: one_step(s, raw[0], W1{}, No{}, Yes{}); break;
-            case 2: one_step(s, raw[0], W2{}, No{}, Yes{}); break;
-            default: one_step(s, raw[0], W3{}, No{}, Yes{}); break;
-        }
-        shift_raw();
-    };
     uint32_t s = 0;
-    // the first step; single steps up to the slip stream's call boundary; kAhead steps per iteration with static word
-    // and register selection and unclamped prefetch while the action rows last; single steps for the rest
-    if (p.n_steps > 0) {
-        one_step(0u, raw[0], Generic{}, Yes{}, Yes{});
-        shift_raw();
-        s = 1;
-    }
-    for (; s < p.n_steps && (((t_first + s) & 3u) != 0u || (SYS && s < uint32_t(Q))); ++s) single_step(s);
-    for (; s + 2u * kAhead <= p.n_steps; s += kAhead) {        // the group's last step prefetches row s + 2 kAhead - 1
-        one_step(s, raw[0], W0{}, No{}, No{});
-        one_step(s + 1u, raw[1], W1{}, No{}, No{});
-        one_step(s + 2u, raw[2], W2{}, No{}, No{});
-        one_step(s + 3u, raw[3], W3{}, No{}, No{});
-        if constexpr (kAhead == 8) {
-            one_step(s + 4u, raw[4], W0{}, No{}, No{});
-            one_step(s + 5u, raw[5], W1{}, No{}, No{});
-            one_step(s + 6u, raw[6], W2{}, No{}, No{});
-            one_step(s + 7u, raw[7], W3{}, No{}, No{});
+    if constexpr (WORD_SLOTS) {
+        // The step loop.  Every step outside the first one is one of four bodies (one per slip word) with the register of its
+        // word and a clamped prefetch address, so a launch that starts at a word boundary -- t a multiple of four: every launch
+        // of a caller whose launches are multiples of four steps -- is straight-line code: the first four steps, then four
+        // steps per iteration while they last, then up to three more.  No step moves a register whose load is in flight
+        // and no join sits between two steps but the loop's own, so the waits for the action words are the counted ones
+        // (vmcnt(15): four steps of one load and three stores each).
+        // (Before, the steps before the first boundary and the last four to seven ran as single steps that shifted the
+        // registers down -- s_waitcnt vmcnt(0) / vmcnt(3) on the load just issued, +370 cycles a step: 8 of a T = 32 launch's
+        // steps, profiles/r05_rollout_short_launch_stamps.txt.)
+        // A launch that starts elsewhere takes up to three steps with the word picked at run time to the boundary first.
+        const uint32_t n = p.n_steps;
+        if (n > 0) {
+            const uint32_t h = head_steps(uint32_t(t_first), n);
+            one_step(0u, raw_first, Generic{}, Yes{}, Skip{});
+            if ((uint32_t(t_first) & 3u) == 0u && n >= kAhead) {     // started at a boundary: h = 1
+                one_step(1u, raw[1], W1{}, No{}, Yes{});
+                one_step(2u, raw[2], W2{}, No{}, Yes{});
+                one_step(3u, raw[3], W3{}, No{}, Yes{});
+                s = kAhead;
+            } else {
+                if (h > 1u) one_step(1u, raw_head[0], Generic{}, No{}, Skip{});
+                if (h > 2u) one_step(2u, raw_head[1], Generic{}, No{}, Skip{});
+                s = h;
+            }
         }
+        for (; s + kAhead <= n; s += kAhead) {
+            one_step(s, raw[0], W0{}, No{}, Yes{});
+            one_step(s + 1u, raw[1], W1{}, No{}, Yes{});
+            one_step(s + 2u, raw[2], W2{}, No{}, Yes{});
+            one_step(s + 3u, raw[3], W3{}, No{}, Yes{});
+        }
+        if (s < n) {                                               // (s is at a word boundary here)
+            one_step(s, raw[0], W0{}, No{}, Yes{});
+            if (s + 1u < n) {
+                one_step(s + 1u, raw[1], W1{}, No{}, Yes{});
+                if (s + 2u < n) one_step(s + 2u, raw[2], W2{}, No{}, Yes{});
+            }
+        }
+    } else {
+        // a single step outside the unrolled loop: its slip word is still picked statically (one four-way branch instead of
+        // the word selects inside the step), its prefetch address is clamped
+        auto single_step = [&](const uint32_t s) __attribute__((always_inline)) {
+            switch (uint32_t(t_first + s) & 3u) {
+                case 0: one_step(s, raw[0], W0{}, No{}, Yes{}); break;
+                case 1: one_step(s, raw[0], W1{}, No{}, Yes{}); break;
+                case 2: one_step(s, raw[0], W2{}, No{}, Yes{}); break;
+                default: one_step(s, raw[0], W3{}, No{}, Yes{}); break;
+            }
+            shift_raw();
+        };
+        // the first step; single steps up to the slip stream's call boundary; kAhead steps per iteration with static word
+        // and register selection and unclamped prefetch while the action rows last; single steps for the rest
+        if (p.n_steps > 0) {
+            one_step(0u, raw[0], Generic{}, Yes{}, Yes{});
+            shift_raw();
+            s = 1;
+        }
+        for (; s < p.n_steps && (((t_first + s) & 3u) != 0u || (SYS && s < uint32_t(Q))); ++s) single_step(s);
+        for (; s + 2u * kAhead <= p.n_steps; s += kAhead) {        // the group's last step prefetches row s + 2 kAhead - 1
+            one_step(s, raw[0], W0{}, No{}, No{});
+            one_step(s + 1u, raw[1], W1{}, No{}, No{});
+            one_step(s + 2u, raw[2], W2{}, No{}, No{});
+            one_step(s + 3u, raw[3], W3{}, No{}, No{});
+            if constexpr (kAhead == 8) {
+                one_step(s + 4u, raw[4], W0{}, No{}, No{});
+                one_step(s + 5u, raw[5], W1{}, No{}, No{});
+                one_step(s + 6u, raw[6], W2{}, No{}, No{});
+                one_step(s + 7u, raw[7], W3{}, No{}, No{});
+            }
+        }
+        for (; s < p.n_steps; ++s) single_step(s);
     }
-    for (; s < p.n_steps; ++s) single_step(s);
     if (p.n_steps > 0) {                                       // the last step's chain, totals and stores
         double qv[K];
         if (SYS) chain_fetch(qv);

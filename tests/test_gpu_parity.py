@@ -380,6 +380,48 @@ def test_dense_rollout_split_launches_accumulate_and_single_steps(n_agents, n_en
     one.close(), parts.close()
 
 
+@pytest.mark.parametrize('n_agents,n_envs,k', [(8, 8192, None), (16, 4096, None), (32, 2048, None), (8, 8192, '8'), (16, 4096, '8'), (4, 16384, '2')])
+def test_streamed_recorded_launches_of_every_length_and_phase(n_agents, n_envs, k, monkeypatch):
+    """The packed kernels' step loop has different code for a launch's head (the steps up to the slip stream's next call
+    boundary, with action registers of their own), its groups of four steps and its last one to three steps: a chain of
+    streamed, recorded launches whose lengths and first step indices cover every (t mod 4, length) combination up to
+    length 9 -- and a few longer ones -- every recorded step against the C oracle stepped with the same actions."""
+    if k is not None:
+        set_tune(monkeypatch, k=k)
+    rs = np.random.RandomState(4100 + n_agents)
+    grid = MapfGrid([''.join('@' if rs.rand() < 0.15 else '.' for _ in range(18)) for _ in range(18)])
+    valid, _, nbr = grid.tables()
+    V, E, A = len(valid), n_envs, n_agents
+    start = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    goal = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=21, start_local=start, goal_local=goal)
+    co = c_oracle.COracle(nbr, A, start, goal, 0.2, -1000.0, 100.0, -1.0, mo.MAKESPAN, seed=21)
+    # lengths 1..9 from each phase: after a launch of n steps from phase f the next one starts at phase (f + n) & 3
+    lengths, seen, t = [], set(), 0
+    while len(seen) < 36:
+        n = next((n for n in range(1, 10) if (t & 3, n) not in seen), None)
+        if n is None:                                             # every length seen from this phase: move on by one step
+            n = 1
+        seen.add((t & 3, n)); lengths.append(n); t += n
+    lengths += [13, 22, 17]
+    ids = np.arange(E)
+    t = 0
+    for n in lengths:
+        acts = np.stack([philox.random_actions_np(77, ids, t + j, A) for j in range(n)])
+        res = env.rollout(n, actions=acts, auto_reset=True, record=True)
+        if k is not None:
+            assert 'K=%s' % k in env.last_kernel('rollout'), env.last_kernel('rollout')
+        assert 'lq_rollout_kernel' in env.last_kernel('rollout') and 'STREAM' in env.last_kernel('rollout')
+        for j in range(n):
+            ref = co.step(acts[j], auto_reset=True)
+            assert np.array_equal(res['local'][j], ref['local']), (n, t, j)
+            assert np.array_equal(_bits(res['reward'][j]), _bits(ref['reward'])) and np.array_equal(_bits(res['prob'][j]), _bits(ref['prob'])), (n, t, j)
+            assert np.array_equal(res['done'][j], ref['done']) and np.array_equal(res['collision'][j], ref['collision']), (n, t, j)
+        t += n
+    assert np.array_equal(env.get_state()[0], co.state) and env.get_state()[1] == t
+    env.close()
+
+
 @pytest.mark.parametrize('n_agents,n_envs,kernel', [(2, 300, 'thread_per_env'), (5, 300, 'thread_per_env'), (3, 257, 'lane_group'),
                                                     (8, 8192, 'auto'), (8, 16448, 'auto'), (16, 4096, 'auto'), (7, 1000, 'auto')])
 def test_greedy_policy_rollout_against_c_oracle(n_agents, n_envs, kernel):

@@ -4,7 +4,7 @@
 episode counters, so this build's outputs are not valid results) and prints median cycles per step and segment.
 
     make -C gym-mapf_amd/csrc stamps
-    MAPF_HIP_LIB=gym-mapf_amd/gym_mapf_amd/lib/variants/libmapf_hip_stamps.so python tools/stamp_profile.py [envs] [c3|c5]
+    MAPF_HIP_LIB=gym-mapf_amd/gym_mapf_amd/lib/variants/libmapf_hip_stamps.so python tools/stamp_profile.py [envs] [c3|c5] [T=64]
     (MAPF_TUNE=k=2 profiles the packed layout with two agents per lane, MAPF_TUNE=quad_lanes=0 the lane-group kernel)
 
 Stamps serialise the segments (a fence on each side), so read the SHARES, not the total (cdna_hip_programming.md
@@ -24,7 +24,8 @@ if 'stamps' not in os.environ.get('MAPF_HIP_LIB', ''):
     raise SystemExit('set MAPF_HIP_LIB to the stamps build (see the docstring)')
 cfg_name = sys.argv[2] if len(sys.argv) > 2 else 'c3'
 cfg = bench.CONFIGS[cfg_name]
-E, A, T = (int(sys.argv[1]) if len(sys.argv) > 1 else 65536), cfg['agents'], 64
+E, A = (int(sys.argv[1]) if len(sys.argv) > 1 else 65536), cfg['agents']
+T = int(sys.argv[3]) if len(sys.argv) > 3 else 64          # env-steps per launch (short launches: where do the first steps' cycles go?)
 # envs per wave: 64 / (lanes per env); 8 agents: 32 with four agents per lane (default), 16 with two
 _tune = dict(item.split('=', 1) for item in os.environ.get('MAPF_TUNE', '').split(',') if item)
 pair_layout = _tune.get('quad_lanes') == '0' or _tune.get('k') == '2'
