@@ -798,7 +798,10 @@ __global__ void __launch_bounds__((K == 8 || (COMPACT && BITMAP == 1 && !STREAM)
             s = 1;
         }
         for (; s < p.n_steps && (((t_first + s) & 3u) != 0u || (SYS && s < uint32_t(Q))); ++s) single_step(s);
-        for (; s + 2u * kAhead <= p.n_steps; s += kAhead) {        // the group's last step prefetches row s + 2 kAhead - 1
+        // (streamed actions: the group's last step prefetches row s + 2 kAhead - 1, so the last rows are single steps; an in-kernel
+        // policy prefetches nothing and stays in the loop while whole groups are left -- a single step sits in a basic block of its
+        // own and cannot start its table reads under the step before it: +500 cycles, profiles/r05_rollout_short_launch_stamps.txt)
+        for (; s + (STREAM ? 2u : 1u) * kAhead <= p.n_steps; s += kAhead) {
             one_step(s, raw[0], W0{}, No{}, No{});
             one_step(s + 1u, raw[1], W1{}, No{}, No{});
             one_step(s + 2u, raw[2], W2{}, No{}, No{});

@@ -380,12 +380,15 @@ def test_dense_rollout_split_launches_accumulate_and_single_steps(n_agents, n_en
     one.close(), parts.close()
 
 
-@pytest.mark.parametrize('n_agents,n_envs,k', [(8, 8192, None), (16, 4096, None), (32, 2048, None), (8, 8192, '8'), (16, 4096, '8'), (4, 16384, '2')])
-def test_streamed_recorded_launches_of_every_length_and_phase(n_agents, n_envs, k, monkeypatch):
+@pytest.mark.parametrize('n_agents,n_envs,k,streamed', [(8, 8192, None, True), (16, 4096, None, True), (32, 2048, None, True), (8, 8192, '8', True),
+                                                        (16, 4096, '8', True), (4, 16384, '2', True),
+                                                        (8, 8192, None, False), (32, 2048, None, False), (16, 4096, '8', False)])
+def test_recorded_launches_of_every_length_and_phase(n_agents, n_envs, k, streamed, monkeypatch):
     """The packed kernels' step loop has different code for a launch's head (the steps up to the slip stream's next call
     boundary, with action registers of their own), its groups of four steps and its last one to three steps: a chain of
-    streamed, recorded launches whose lengths and first step indices cover every (t mod 4, length) combination up to
-    length 9 -- and a few longer ones -- every recorded step against the C oracle stepped with the same actions."""
+    recorded launches whose lengths and first step indices cover every (t mod 4, length) combination up to length 9 -- and a
+    few longer ones -- every recorded step against the C oracle stepped with the same actions; streamed actions and the
+    in-kernel policy (whose loop differs again: single steps to the boundary, groups of four to the end)."""
     if k is not None:
         set_tune(monkeypatch, k=k)
     rs = np.random.RandomState(4100 + n_agents)
@@ -407,11 +410,11 @@ def test_streamed_recorded_launches_of_every_length_and_phase(n_agents, n_envs, 
     ids = np.arange(E)
     t = 0
     for n in lengths:
-        acts = np.stack([philox.random_actions_np(77, ids, t + j, A) for j in range(n)])
-        res = env.rollout(n, actions=acts, auto_reset=True, record=True)
+        acts = np.stack([philox.random_actions_np(77 if streamed else 21, ids, t + j, A) for j in range(n)])
+        res = env.rollout(n, actions=acts if streamed else None, auto_reset=True, record=True)
         if k is not None:
             assert 'K=%s' % k in env.last_kernel('rollout'), env.last_kernel('rollout')
-        assert 'lq_rollout_kernel' in env.last_kernel('rollout') and 'STREAM' in env.last_kernel('rollout')
+        assert 'lq_rollout_kernel' in env.last_kernel('rollout') and ('STREAM' if streamed else 'POLICY') in env.last_kernel('rollout')
         for j in range(n):
             ref = co.step(acts[j], auto_reset=True)
             assert np.array_equal(res['local'][j], ref['local']), (n, t, j)
