@@ -321,6 +321,29 @@ const char *mapf_version(void) { return "mapf_hip 0.5.0 (abi 5, gfx950)"; }
 
 int mapf_abi_version(void) { return MAPF_ABI_VERSION; }
 
+int mapf_debug_rollout_plan(uint32_t n_cells, int n_agents, uint64_t n_envs, uint32_t n_steps, int streamed, int delta_rows,
+                            int n_cu, const char *tune, uint64_t out[6]) {
+    if (!out) return fail(MAPF_EINVAL, "out is null");
+    if (n_agents < 1 || n_cells < 2 || n_cu < 1) return fail(MAPF_EINVAL, "mapf_debug_rollout_plan: n_agents >= 1, n_cells >= 2, n_cu >= 1");
+    std::string tune_error;
+    const mapf::RolloutTuning t = mapf::rollout_tuning_for(n_cu, tune, &tune_error);
+    if (!tune_error.empty()) return fail(MAPF_EINVAL, tune_error);
+    // only the fields the plan reads: the shape, and which optional arrays are present (never dereferenced)
+    static const uint8_t present = 0;
+    mapf::RolloutArgs args{};
+    args.c.n_cells = n_cells;
+    args.n_envs = n_envs;
+    args.n_steps = n_steps;
+    args.actions = streamed ? &present : nullptr;
+    args.mv_delta8 = delta_rows != 0;
+    args.mv4 = delta_rows ? reinterpret_cast<const uint32_t *>(&present) : nullptr;
+    mapf::LqPlan plan;
+    const bool packed = mapf::plan_rollout_lq(n_agents, args, t, n_cu, &plan);
+    out[0] = uint64_t(plan.K); out[1] = uint64_t(plan.Q); out[2] = uint64_t(plan.form);
+    out[3] = plan.block; out[4] = plan.lds_bytes; out[5] = plan.lds_total;
+    return packed ? 1 : 0;
+}
+
 int mapf_device_count(int *out_count) {
     if (!out_count) return fail(MAPF_EINVAL, "out_count is null");
     int n = 0;

@@ -229,12 +229,26 @@ struct RolloutTuning {
     bool scen_table = true;          // scen_table=0: never build the scenario table (StepArgs::scen) -- tests compare both forms
 };
 RolloutTuning default_rollout_tuning(int device, std::string *err);   // (reads MAPF_TUNE: mapf_lg_rollout.hip)
+// ... its arithmetic: the defaults of a device with n_cu compute units, overridden by `text` ("key=value,...", may be null)
+RolloutTuning rollout_tuning_for(int n_cu, const char *text, std::string *err);
 hipError_t launch_step_lg(int n_agents, const StepArgs &args, const RolloutTuning &tune, hipStream_t stream);
 // packed layout of the single step (mapf_lq_step.hip): true when it took the launch (*err = its status)
 bool try_launch_step_lq(int n_agents, const StepArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err);
 hipError_t launch_rollout_lg(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream);
 // packed layout of the fused rollout (2 or 4 agents per lane, mapf_lq_rollout.hip): true when it took the launch (*err = its status)
 bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err);
+// What try_launch_rollout_lq decides before it launches -- pure arithmetic over the launch's shape (args.c.n_cells, n_envs, n_steps,
+// c.top_tie, actions / mv4 / mv_delta8 present or not), the tuning and the device's CU count, so it can be swept without a
+// device (mapf_debug_rollout_plan, tests/test_cabi_and_host.py): false = no packed form applies.
+struct LqPlan {
+    int K = 0, Q = 0;                // agents per lane, lanes per env
+    int form = 0;                    // 0 full 16-byte rows, 1 8-byte rows, 2 / 3 bitmaps behind four / five 8-byte columns, 4 bitmaps behind
+                                     // full rows, 5 bitmaps behind 4-byte delta rows
+    unsigned block = 0;              // threads per block
+    size_t lds_bytes = 0;            // the kernel's LDS image without the bitmaps (what the launcher is handed)
+    size_t lds_total = 0;            // ... with them: the dynamic LDS segment of the launch, <= 160 KB
+};
+bool plan_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, int n_cu, LqPlan *plan);
 int lg_group_size(int n_agents);
 
 // per-group entry points: group g holds the kernels specialised for A in 4g+1 .. 4g+4

@@ -249,15 +249,18 @@ static_assert(sizeof(SlipRow) * 8 + sizeof(OutcomeRow) * 16 <= kLdsReserve, "sta
 //   bitmap_delta, step_big, step_block, step_delta.
 // An unknown key or a malformed item is an error (*err names it): a typo must not silently measure the default.
 RolloutTuning default_rollout_tuning(int device, std::string *err) {
-    RolloutTuning t;
     int n_cu = 256;
     if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) n_cu = 256;
+    return rollout_tuning_for(n_cu, getenv("MAPF_TUNE"), err);
+}
+
+RolloutTuning rollout_tuning_for(int n_cu, const char *text, std::string *err) {
+    RolloutTuning t;
     // measured on 8 agents x 32768 envs (one wave per SIMD with four agents per lane, two with two): 517 G vs 467 G
     // agent-steps/s -- fewer, fatter waves win as long as no SIMD stays empty
     t.quad_min_lanes = uint64_t(n_cu) * 4u * 64u;        // CUs x SIMDs x lanes
     t.oct_min_lanes = uint64_t(n_cu) * 4u * 64u * 2u;    // (eight agents per lane: see try_launch_rollout_lq)
     t.mv_lds_max_bytes = (kLdsBytes - kLdsReserve) / 2;
-    const char *text = getenv("MAPF_TUNE");
     if (!text) return t;
     std::string items(text);
     size_t pos = 0;

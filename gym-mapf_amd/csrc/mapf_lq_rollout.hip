@@ -45,6 +45,7 @@
 // same arithmetic, same outputs: the parity tests run all layouts against the oracle.
 #include "mapf_lq.hpp"
 
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -983,13 +984,11 @@ static bool layout_fits(int n_agents, int K, const RolloutArgs &args, size_t lds
     return true;
 }
 
-// true when a packed layout took the launch (*err = its status); false = not applicable, use the lane-group kernel
-bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err) {
+// the dispatch decision (see LqPlan): which packed form, block size and LDS image a launch of this shape takes
+bool plan_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, const int n_cu, LqPlan *plan) {
     // top_tie: a three-entry list whose last cumulative sum rounds below 1.0 needs a third compare per agent (hi = 65535);
     // the packed sampling does two, so such a table (none arises from fail_prob / 2 splits) stays with the lane-group kernel
     if (!tune.quad_lanes || args.c.top_tie || args.n_steps > 65535u) return false;   // (per-launch counts are 16-bit)
-    const bool record = args.rec_local != nullptr;
-    const uint32_t A = uint32_t(n_agents);
     unsigned block = 0;
     int Q = 0, K = 0;
     bool compact = false, bitmap = false, stay_column = false, full_rows_bitmap = false, delta_rows = false;
@@ -1019,8 +1018,6 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
         // batch gives every CU a block of that size), four agents per lane, group sizes 4 / 8 / 16 only
         lds_bytes = kMoveAt + size_t(args.c.n_cells) * kCompactCols * kCompactEntry;
         if (tune.mv_lds_max_bytes == 0 || lds_bytes > kLdsBytes - kLdsReserve) return false;
-        int n_cu = 256, dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 256;
         const size_t bitmap_lds = kMoveAt + size_t(args.c.n_cells) * kBitmapCols * kCompactEntry;   // (no STAY column in that form)
         // 32 agents: four per lane, collisions through per-env occupancy bitmaps behind the table (one bit per cell) -- O(A)
         // instead of 496 pair tests per env.  64 envs per 512-thread block; 128 per 1024-thread block (four waves per SIMD)
@@ -1068,11 +1065,41 @@ bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutT
         }
         compact = true;
     }
+    plan->K = K;
+    plan->Q = Q;
+    plan->form = delta_rows ? 5 : (full_rows_bitmap ? 4 : (bitmap ? (stay_column ? 3 : 2) : (compact ? 1 : 0)));
+    plan->block = block;
+    plan->lds_bytes = lds_bytes;
+    plan->lds_total = lds_bytes + (bitmap ? size_t(block / unsigned(Q)) * bitmap_stride(args.c.n_cells) : 0u);   // (as launch_impl adds them)
+    return true;
+}
+
+// the device's CU count, asked once per device
+static int device_cu_count() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n == 0) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+// true when a packed layout took the launch (*err = its status); false = not applicable, use the lane-group kernel
+bool try_launch_rollout_lq(int n_agents, const RolloutArgs &args, const RolloutTuning &tune, hipStream_t stream, hipError_t *err) {
+    LqPlan plan;
+    if (!plan_rollout_lq(n_agents, args, tune, device_cu_count(), &plan)) return false;
+    const bool record = args.rec_local != nullptr;
+    const uint32_t A = uint32_t(n_agents);
+    const int K = plan.K, Q = plan.Q, form = plan.form;
+    const unsigned block = plan.block;
+    const size_t lds_bytes = plan.lds_bytes;
     if (record && !(args.rec_reward && args.rec_prob && args.rec_done && args.rec_collision)) {
         *err = hipErrorInvalidValue;
         return true;
     }
-    const int form = delta_rows ? 5 : (full_rows_bitmap ? 4 : (bitmap ? (stay_column ? 3 : 2) : (compact ? 1 : 0)));
     if (K == 8) *err = record ? launch_rollout_lq_k8_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k8_r0(Q, form, args, A, block, lds_bytes, stream);
     else if (K == 4) *err = record ? launch_rollout_lq_k4_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k4_r0(Q, form, args, A, block, lds_bytes, stream);
     else *err = record ? launch_rollout_lq_k2_r1(Q, form, args, A, block, lds_bytes, stream) : launch_rollout_lq_k2_r0(Q, form, args, A, block, lds_bytes, stream);

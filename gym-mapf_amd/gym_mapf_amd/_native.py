@@ -77,6 +77,7 @@ SIGNATURES = {
     'mapf_last_error': (c_char_p, []),
     'mapf_version': (c_char_p, []),
     'mapf_abi_version': (c_int, []),
+    'mapf_debug_rollout_plan': (c_int, [c_uint32, c_int, c_uint64, c_uint32, c_int, c_int, c_int, c_char_p, POINTER(c_uint64)]),
 }
 
 _lib = None

@@ -317,6 +317,19 @@ const char *mapf_version(void);
  * counter layouts are part of the ABI: the same seed draws other numbers under another version). */
 int mapf_abi_version(void);
 
+/* Diagnostic, no device needed and none touched: which packed rollout form (agents per lane, lanes per env, table rows,
+ * block size, LDS bytes) a mapf_rollout launch of this shape would take on a device with n_cu compute units -- the
+ * arithmetic the launcher runs before every launch (no reference counterpart: the reference has one code path).
+ * n_cells = cells of the map incl. the blocked id; streamed = actions given (1) or drawn in the kernel (0); delta_rows = the
+ * map admits 4-byte delta rows (every neighbour id within +-127 of its cell); tune = a MAPF_TUNE string or NULL for the
+ * defaults (the MAPF_TUNE environment variable is NOT read).
+ * out[0..5] = {agents per lane K, lanes per env Q, form (0 full 16-byte rows, 1 8-byte rows, 2 / 3 bitmaps behind four /
+ * five 8-byte columns, 4 bitmaps behind full rows, 5 bitmaps behind delta rows), threads per block, LDS bytes of the table
+ * image, LDS bytes of the launch}.  Returns 1 when a packed form applies, 0 when the lane-group kernel takes the launch,
+ * MAPF_EINVAL (< 0) for a malformed tune string or null out. */
+int mapf_debug_rollout_plan(uint32_t n_cells, int n_agents, uint64_t n_envs, uint32_t n_steps, int streamed, int delta_rows,
+                            int n_cu, const char *tune, uint64_t out[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -198,3 +198,69 @@ def test_packed_kernels_layout_assumptions_hold_in_the_compiled_objects(device_l
     # ... and no trap instruction stands in for these checks in the shipped kernels any more
     for unit in ('mapf_lq_step.hip', 'mapf_lq_rollout.hip'):
         assert '__builtin_trap' not in open(os.path.join(CSRC, unit)).read(), unit
+
+
+def test_packed_rollout_dispatch_never_plans_past_the_lds_or_launch_bounds():
+    """mapf_debug_rollout_plan is the arithmetic try_launch_rollout_lq runs before every packed rollout launch (no device
+    involved).  Swept over map sizes across every form's LDS boundary, agent counts, batch sizes, streamed / in-kernel policy,
+    delta rows or not, and the MAPF_TUNE overrides the tests use: whatever form is planned fits the CU's 160 KB of LDS (the limit
+    the launcher raises the kernel's dynamic segment to), fills whole blocks, and stays within its instance's launch bounds;
+    and the forms end exactly where the next cell would not fit."""
+    from gym_mapf_amd import _native
+    import ctypes
+    lib = _native.load()
+    out = (ctypes.c_uint64 * 6)()
+    LDS = 160 * 1024
+
+    def plan(n_cells, A, E, streamed, delta, tune, n_cu=256, T=64):
+        rc = lib.mapf_debug_rollout_plan(n_cells, A, E, T, streamed, delta, n_cu, tune, out)
+        assert rc in (0, 1), (rc, lib.mapf_last_error())
+        return rc, tuple(out)
+
+    cells = sorted(set(list(range(2, 200, 7)) + list(range(600, 760, 3)) + list(range(800, 1800, 11)) + list(range(1650, 1720)) +
+                       list(range(3000, 3400, 5)) + list(range(4000, 20500, 61)) + list(range(19700, 20300, 3)) + [683, 3278, 4097, 65535]))
+    tunes = [None, b'k=8', b'k=4', b'k=2', b'bitmap_block=1024', b'bitmap_block=512', b'bitmap_pairs=0', b'bitmap_delta=0',
+             b'bitmap_staycol=0', b'mv_lds_max_bytes=163840', b'mv_lds_max_bytes=0', b'quad_min_lanes=0,oct_min_lanes=0']
+    seen_forms, n_packed = set(), 0
+    for tune in tunes:
+        for A in (2, 4, 8, 16, 32, 64, 128):
+            for E in (64, 1000, 1024, 4096, 16384, 16448, 65536, 131072, 262144):
+                for streamed in (1, 0):
+                    for delta in (0, 1):
+                        for V in cells:
+                            rc, (K, Q, form, block, table, total) = plan(V, A, E, streamed, delta, tune)
+                            if not rc:
+                                continue
+                            n_packed += 1
+                            seen_forms.add(form)
+                            ctx = (tune, A, E, streamed, delta, V, K, Q, form, block, table, total)
+                            assert K in (2, 4, 8) and K * Q == A and Q in (1, 2, 4, 8, 16), ctx
+                            assert block in (64, 128, 256, 512, 1024) and E % (block // Q) == 0, ctx
+                            assert 1024 < table <= total <= LDS, ctx
+                            assert (total > table) == (form in (2, 3, 4, 5)), ctx          # bitmaps behind the table
+                            if form >= 2:
+                                assert A == 32 and K == 4 and total == table + (block // 8) * ((((V + 31) // 32) * 4 + 15) & ~15), ctx
+                            if form == 5:
+                                assert delta, ctx
+                            # launch bounds of the instances (mapf_lq_rollout.hip: 512 threads with eight agents per lane and for the
+                            # in-kernel policy behind four 8-byte columns + bitmaps, 1024 otherwise)
+                            assert block <= (512 if K == 8 or (form == 2 and not streamed) else 1024), ctx
+    assert seen_forms == {0, 1, 2, 3, 4, 5} and n_packed > 50000, (seen_forms, n_packed)
+    # the boundaries themselves (32 agents, default tuning), to the cell
+    stride = lambda V: (((V + 31) // 32) * 4 + 15) & ~15                                   # noqa: E731  (bytes of one env's bitmap)
+    for delta, streamed in ((1, 1), (0, 1), (0, 0)):
+        forms = {V: plan(V, 32, 16384, streamed, delta, None) for V in range(3000, 4200)}
+        last = max(V for V, (rc, _) in forms.items() if rc)
+        assert 1024 + last * 40 <= LDS - 1024 < 1024 + (last + 1) * 40                     # the 8-byte rows' own limit (launcher's reserve kept)
+        assert not any(rc for V, (rc, _) in forms.items() if V > last)
+        five = [V for V, (rc, o) in forms.items() if rc and o[2] == 3]                     # five columns + 64 bitmaps
+        four = [V for V, (rc, o) in forms.items() if rc and o[2] == 2]                     # four columns + 64 bitmaps
+        if delta:
+            assert not five and not four and all(o[2] == 5 for rc, o in forms.values() if rc)   # delta rows: 24 bytes a cell, fit to the end
+        else:
+            assert max(five) + 1 == min(four) and max(four) == last
+            assert 1024 + max(five) * 40 + 64 * stride(max(five)) <= LDS < 1024 + (max(five) + 1) * 40 + 64 * stride(max(five) + 1)
+            assert 1024 + last * 32 + 64 * stride(last) <= LDS
+    # a malformed override is an error, not a default
+    assert lib.mapf_debug_rollout_plan(683, 8, 65536, 64, 1, 0, 256, b'k=nine', out) < 0
+    assert lib.mapf_debug_rollout_plan(683, 8, 65536, 64, 1, 0, 256, b'no_such_key=1', out) < 0
