@@ -599,13 +599,16 @@ def baseline_config_leg(name, rank, world, dist, coll_dev, device, T=256, n_laun
             "parity": parity}
 
 
-def transitions_rate(n_agents, n_queries, reps=10, blocks=3, compact=False, seed=0):
+def transitions_rate(n_agents, n_queries, reps=10, blocks=3, compact=False, seed=0, preroll_ms=150.0):
     """`env.P[s][a]` (reference mapf_env.py:448-483) as one mapf_transitions launch over `n_queries` random
     (state, joint action) queries on room-32-32-4: distinct random cells per query, uniform joint actions, outputs reserved
     once.  The kernel reads 3A bytes per query and WRITES every branch of the joint slip distribution -- next cells u16[A],
     prob f64, reward f64, done u8, collision u8 = 2A + 18 bytes per branch, nothing re-read -- so its roofline is HBM write
     bandwidth: achieved = branches x (2A + 18) / HIP-event time per launch (median of `blocks` blocks of `reps` launches).
-    compact=True: the packed output mode (rows of all queries back to back behind an exclusive scan of the branch counts)."""
+    compact=True: the packed output mode (rows of all queries back to back behind an exclusive scan of the branch counts).
+    `preroll_ms` of untimed launches come first, as for the headline (--preroll-ms): the queries are drawn on the host while the
+    GPU idles, and 20 launches of a quarter millisecond are over before its clocks have come back -- without them the same
+    binary measured 100 or 132 G branches/s from one process to the next (profiles/r05_transitions_magic_digits_ab.txt)."""
     import torch
     from gym_mapf_amd.envs import map_name_to_files
     from gym_mapf_amd.envs.grid import MapfGrid
@@ -638,6 +641,11 @@ def transitions_rate(n_agents, n_queries, reps=10, blocks=3, compact=False, seed
         call = lambda: env.transitions(lt, at, max_branches=M, out=res)
     env.sync()
     branches = int(res['count'].to(torch.int64).sum().item())
+    t_end = time.perf_counter() + preroll_ms * 1e-3
+    while time.perf_counter() < t_end:
+        for _ in range(4):
+            call()
+        env.sync()
     ms = []
     for _ in range(blocks):
         env.sync()

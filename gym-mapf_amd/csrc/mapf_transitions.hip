@@ -27,6 +27,7 @@
 //   * transitions_kernel<A, EXACT> for 9..16 agents (48-bit choice sets do not fit the records): a group of 64 lanes owns a
 //     chunk of one query's window, query set-up per lane, all agent pairs per row.
 #include <algorithm>
+#include <type_traits>
 #include "mapf_kernels.hpp"
 #include "mapf_device.hpp"
 
@@ -139,16 +140,42 @@ __global__ void __launch_bounds__(1024) scan_block_totals_kernel(uint64_t *block
 // ---------------------------------------------------------------------------------------------------- A <= 8
 namespace {
 
-constexpr uint32_t kQueryHeader = 32, kRecord = 16;
+constexpr uint32_t kQueryHeader = 48, kRecord = 16;
 struct QueryHeader {
     uint32_t radix;        // 2 bits per agent: its list length (1 for absent agents and for every agent of a terminal state)
     uint32_t first;        // first branch of the window (<= count)
     uint32_t terminal;     // 1: the single branch ((1.0, False), s, 0, True) of a terminal state
     uint32_t pad;
     double living;         // _living_reward of the query (mapf_env.py:436-446)
-    uint64_t pad2;
+    uint8_t n[8];          // the list lengths again, a byte each, and
+    uint16_t magic[8];     // ceil(2^15 / n): x / n == (x * magic) >> 15 for x < 2^15 (a branch index is below 3^8) -- the emission's
+                           // mixed-radix digits by two 24-bit multiplies with a byte / word operand select each instead of a 32-bit
+                           // mul_hi + mul_lo, two compares and two selects: 8 agents x 20000 queries 106-110 -> 131-133 G branches/s
+    __device__ void set_divisors(int max_agents) {
+        for (int i = 0; i < 8; ++i) {
+            const uint32_t len = i < max_agents ? (radix >> (2 * i)) & 3u : 1u;
+            n[i] = uint8_t(len);
+            magic[i] = uint16_t(len == 3u ? 10923u : (32768u >> (len - 1u)));
+        }
+    }
 };
-static_assert(sizeof(QueryHeader) == kQueryHeader, "one ds_read_b128 + one ds_read_b64");
+static_assert(sizeof(QueryHeader) == kQueryHeader, "three ds_read_b128");
+
+// a * (16-bit word W of packed) and a * (byte B of packed), 24-bit multiplies with an operand select
+template <int W> __device__ __forceinline__ uint32_t mul24_word(uint32_t a, uint32_t packed) {
+    uint32_t r;
+    if constexpr (W == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(packed));
+    else asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(packed));
+    return r;
+}
+template <int B> __device__ __forceinline__ uint32_t mul24_byte(uint32_t a, uint32_t packed) {
+    uint32_t r;
+    if constexpr (B == 0) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(a), "v"(packed));
+    else if constexpr (B == 1) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(a), "v"(packed));
+    else if constexpr (B == 2) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(a), "v"(packed));
+    else asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(packed));
+    return r;
+}
 
 // ALL_OUT: every output array is given (what the Python wrapper and the bench pass): no per-array branches around the stores.
 // A batch (the QW queries of a wave) whose windows hold more than `rows_per_wave` rows is cut into PIECES, one wave each
@@ -279,6 +306,7 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
                 hdr.living = p.c.criteria == 1u ? __dmul_rn(double(int(A) - stayed), p.c.r_living) : p.c.r_living;
                 hdr.radix = terminal ? (0x55555555u >> (32 - 2 * MAXA)) : radix_all;
             }
+            hdr.set_divisors(MAXA);
             *reinterpret_cast<QueryHeader *>(mine) = hdr;
         }
     } else
@@ -361,6 +389,7 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
                     }
             }
         }
+        hdr.set_divisors(MAXA);
         *reinterpret_cast<QueryHeader *>(mine) = hdr;
     }
     const uint32_t incl = wave_inclusive_scan(rows, lane);
@@ -391,25 +420,32 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
         }
         const unsigned char *const qbase = queries + pos * kQueryBytes;
         const uint4 h = *reinterpret_cast<const uint4 *>(qbase);   // {radix, first, terminal, -}
-        const double living = *reinterpret_cast<const double *>(qbase + 16);
+        const uint4 h2 = *reinterpret_cast<const uint4 *>(qbase + 16);   // {living, the list lengths as bytes}
+        const uint4 mg = *reinterpret_cast<const uint4 *>(qbase + 32);   // the divisors' magics, a 16-bit word each
+        const double living = __hiloint2double(int(h2.y), int(h2.x));
+        const uint32_t nb[2] = {h2.z, h2.w}, mw[4] = {mg.x, mg.y, mg.z, mg.w};
         const uint32_t j = r - prefix[pos];                        // row of the query's window
         uint32_t rest = j + h.y;                                   // branch index: digits in the mixed radix, last agent fastest
         uint32_t chosen = 0u, hit = 0u, flags = 0u, cells[MAXA];
         double qv[MAXA];
-#pragma unroll
-        for (int i = MAXA - 1; i >= 0; --i) {
-            const uint32_t n = (h.x >> (2 * i)) & 3u;
-            const uint32_t third = __umulhi(rest, 0xAAAAAAABu) >> 1;
-            const uint32_t quot = n == 3u ? third : (n == 2u ? rest >> 1 : rest);
-            const uint32_t idx = 3u * uint32_t(i) + (rest - quot * n);
+        static_assert(MAXA <= 8, "3^MAXA < 2^15: the magic division is exact");
+        auto take = [&](auto tag) __attribute__((always_inline)) {
+            constexpr int I = decltype(tag)::value;
+            const uint32_t quot = mul24_word<I & 1>(rest, mw[I / 2]) >> 15;          // rest / n_I
+            const uint32_t d = rest - mul24_byte<I & 3>(quot, nb[I / 4]);            // rest % n_I: agent I's entry
             rest = quot;
-            const uint4 rec = *reinterpret_cast<const uint4 *>(qbase + kQueryHeader + idx * kRecord);
+            const uint4 rec = *reinterpret_cast<const uint4 *>(qbase + kQueryHeader + uint32_t(3 * I) * kRecord + d * kRecord);
             hit |= rec.y & chosen;                                 // my entry against the entries the later agents chose
-            chosen |= 1u << idx;
+            chosen |= (1u << (3 * I)) << d;
             flags |= rec.x;                                        // bit 16: off its goal
-            cells[i] = rec.x & 0xFFFFu;
-            qv[i] = __hiloint2double(int(rec.w), int(rec.z));
-        }
+            cells[I] = rec.x & 0xFFFFu;
+            qv[I] = __hiloint2double(int(rec.w), int(rec.z));
+        };
+        if constexpr (MAXA >= 8) { take(std::integral_constant<int, 7>{}); take(std::integral_constant<int, 6>{}); }
+        if constexpr (MAXA >= 6) { take(std::integral_constant<int, 5>{}); take(std::integral_constant<int, 4>{}); }
+        if constexpr (MAXA >= 4) { take(std::integral_constant<int, 3>{}); take(std::integral_constant<int, 2>{}); }
+        take(std::integral_constant<int, 1>{});
+        take(std::integral_constant<int, 0>{});
         double prob = qv[0];                                       // left to right: functools.reduce at mapf_env.py:467
 #pragma unroll
         for (int i = 1; i < MAXA; ++i) prob = __dmul_rn(prob, qv[i]);
