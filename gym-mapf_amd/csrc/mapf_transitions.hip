@@ -410,6 +410,22 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
     // ---- emission: one lane per row of the wave's windows
     const double r_clash = p.c.r_clash, r_goal = p.c.r_goal;
     const uint32_t row_end = (pieces_max > 1u && total - row_begin > rows_per_wave && row_begin < total) ? row_begin + rows_per_wave : total;
+    // The wave's output rows as 32-bit offsets from wave-uniform bases held in scalar registers (compacted: the batch's first row;
+    // reserved: its first query's slot): row index, capacity test and the five addresses were 64-bit vector arithmetic per row --
+    // three v_mad_u64_u32 among it -- in a loop that is bound by its vector instructions (the launch without any store takes
+    // 0.124 of its 0.19 ms: tools/exp/transitions_outputs.py).  (A reserved layout whose slots are wider than 2^20 rows keeps
+    // the 64-bit form: lane offsets of pos * max_branches rows would not fit.)
+    const bool narrow = compact || p.max_branches <= (1u << 20);
+    const uint64_t rows0_v = compact ? base : q0 * uint64_t(p.max_branches);
+    const uint64_t rows0 = (uint64_t(__builtin_amdgcn_readfirstlane(int(uint32_t(rows0_v >> 32)))) << 32) |
+                           uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(rows0_v))));
+    const uint64_t room = p.capacity > rows0 ? p.capacity - rows0 : 0u;
+    const uint32_t cap_rel = room > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(room);
+    unsigned char *const next0 = reinterpret_cast<unsigned char *>(p.out_next) + rows0 * A * 2u;
+    unsigned char *const prob0 = reinterpret_cast<unsigned char *>(p.out_prob) + rows0 * 8u;
+    unsigned char *const reward0 = reinterpret_cast<unsigned char *>(p.out_reward) + rows0 * 8u;
+    unsigned char *const done0 = reinterpret_cast<unsigned char *>(p.out_done) + rows0;
+    unsigned char *const coll0 = reinterpret_cast<unsigned char *>(p.out_collision) + rows0;
     for (uint32_t r0 = row_begin; r0 < row_end; r0 += 64u) {
         const uint32_t r = r0 + lane;
         const bool valid = r < row_end;
@@ -451,10 +467,8 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
         for (int i = 1; i < MAXA; ++i) prob = __dmul_rn(prob, qv[i]);
         const bool terminal = h.z != 0u, coll = hit != 0u, goal_next = (flags & 0x10000u) == 0u;
         const double reward = terminal ? 0.0 : (coll ? __dadd_rn(r_clash, living) : (goal_next ? __dadd_rn(r_goal, living) : living));
-        const uint64_t o = compact ? base + r : (q0 + pos) * uint64_t(p.max_branches) + j;
-        if (valid && o < p.capacity) {
+        auto store_row = [&](uint16_t *dst, double *prob_at, double *reward_at, uint8_t *done_at, uint8_t *coll_at) __attribute__((always_inline)) {
             if (ALL_OUT || p.out_next) {
-                uint16_t *dst = p.out_next + o * A;
                 if (A == uint32_t(MAXA)) {                          // a full team: one store per row (rows are 2 MAXA bytes apart)
                     if constexpr (MAXA == 8) *reinterpret_cast<uint4 *>(dst) = make_uint4(cells[0] | cells[1] << 16, cells[2] | cells[3] << 16, cells[4] | cells[5] << 16, cells[6] | cells[7] << 16);
                     else if constexpr (MAXA == 4) *reinterpret_cast<uint2 *>(dst) = make_uint2(cells[0] | cells[1] << 16, cells[2] | cells[3] << 16);
@@ -468,10 +482,19 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
                         if (uint32_t(i) < A) dst[i] = uint16_t(cells[i]);
                 }
             }
-            if (ALL_OUT || p.out_prob) p.out_prob[o] = prob;
-            if (ALL_OUT || p.out_reward) p.out_reward[o] = reward;
-            if (ALL_OUT || p.out_done) p.out_done[o] = (terminal || coll || goal_next) ? 1 : 0;
-            if (ALL_OUT || p.out_collision) p.out_collision[o] = (coll && !terminal) ? 1 : 0;
+            if (ALL_OUT || p.out_prob) *prob_at = prob;
+            if (ALL_OUT || p.out_reward) *reward_at = reward;
+            if (ALL_OUT || p.out_done) *done_at = (terminal || coll || goal_next) ? 1 : 0;
+            if (ALL_OUT || p.out_collision) *coll_at = (coll && !terminal) ? 1 : 0;
+        };
+        if (narrow) {
+            const uint32_t rel = compact ? r : pos * p.max_branches + j;   // rows from the wave's base
+            if (valid && rel < cap_rel)
+                store_row(reinterpret_cast<uint16_t *>(next0 + uint64_t(rel * (A * 2u))), reinterpret_cast<double *>(prob0 + uint64_t(rel * 8u)),
+                          reinterpret_cast<double *>(reward0 + uint64_t(rel * 8u)), done0 + uint64_t(rel), coll0 + uint64_t(rel));
+        } else {
+            const uint64_t o = (q0 + pos) * uint64_t(p.max_branches) + j;
+            if (valid && o < p.capacity) store_row(p.out_next + o * A, p.out_prob + o, p.out_reward + o, p.out_done + o, p.out_collision + o);
         }
     }
 }
