@@ -153,6 +153,65 @@ def test_rollout_out_reuses_an_earlier_calls_arrays(trajectory_set):
     a.close(), b.close()
 
 
+def test_rollout_out_in_device_mode_reuses_its_argument_block_and_follows_the_arrays():
+    """Device-array mode: rollout(out=...) keeps the argument block of the last such call and uses it again while every array
+    of the dict is the same object and the actions buffer, T and flags are the same -- each such call against a fresh call
+    of a second handle; an array swapped inside the dict, another T, another actions buffer and the in-kernel policy all
+    take effect (the block is dropped, never followed into an array the caller no longer passes)."""
+    import torch
+    rs = np.random.RandomState(77)
+    grid = MapfGrid([''.join('@' if rs.rand() < 0.12 else '.' for _ in range(16)) for _ in range(16)])
+    V, E, A, T = len(grid.tables()[0]), 4096, 8, 8
+    start = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    goal = np.argsort(rs.rand(E, V), axis=1)[:, :A].astype(np.uint16)
+    mk = lambda: VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.Makespan, seed=9,  # noqa: E731
+                            start_local=start, goal_local=goal, device_arrays=True)
+    a, b = mk(), mk()
+    acts = torch.zeros((T, E, A), dtype=torch.uint8, device='cuda')
+    def same(x, y):                                               # bit for bit; the envs run on streams of their own
+        a.sync(), b.sync()
+        return all(torch.equal(x[k].view(torch.uint8), y[k].view(torch.uint8)) for k in y)
+
+    def fill(t):                                                  # (torch's stream: finished before an env reads the buffer)
+        t.copy_(torch.from_numpy(rs.randint(0, 5, size=tuple(t.shape)).astype(np.uint8)))
+        torch.cuda.synchronize()
+    out = None
+    for i in range(4):                                            # calls 1 .. 3 run from the kept block; the buffer's CONTENTS change
+        fill(acts)
+        out = a.rollout(T, actions=acts, record=True, out=out)
+        assert i == 0 or a._rollout_io[0] is out                   # (the first call had no out= to keep a block for)
+        assert same(out, b.rollout(T, actions=acts, record=True)), i
+    # an array swapped inside the dict: the new one is written, the old one is left alone
+    old_reward = out['reward']
+    a.sync()
+    before = old_reward.clone()
+    torch.cuda.synchronize()
+    out['reward'] = torch.empty_like(old_reward)
+    fill(acts)
+    res = a.rollout(T, actions=acts, record=True, out=out)
+    assert same(res, b.rollout(T, actions=acts, record=True))
+    assert res['reward'] is out['reward'] and torch.equal(old_reward, before)
+    # another actions buffer, another T, the in-kernel policy, totals only
+    acts2 = torch.from_numpy(rs.randint(0, 5, size=(T, E, A)).astype(np.uint8)).cuda()
+    torch.cuda.synchronize()
+    assert same(a.rollout(T, actions=acts2, record=True, out=out), b.rollout(T, actions=acts2, record=True))
+    half = a.rollout(T // 2, actions=acts2[:T // 2], record=True, out=out)
+    assert tuple(half['local'].shape) == (T // 2, E, A) and same(half, b.rollout(T // 2, actions=acts2[:T // 2], record=True))
+    for _ in range(2):
+        assert same(a.rollout(T // 2, record=True, out=half), b.rollout(T // 2, record=True))
+    tot = a.rollout(T, actions=acts2, out={})
+    for _ in range(2):
+        tot = a.rollout(T, actions=acts2, out=tot)
+    for _ in range(3):
+        ref = b.rollout(T, actions=acts2)
+    assert same(tot, ref) and a.get_state()[1] == b.get_state()[1]
+    sa, sb = a.get_state()[0], b.get_state()[0]
+    a.sync(), b.sync()
+    assert torch.equal(sa.view(torch.uint8), sb.view(torch.uint8))
+    a.close(), b.close()
+    assert a._rollout_io is None
+
+
 def test_scripted_edge_cases_match_reference():
     """Hand-picked uniforms: all-False argmax, merges, swap-not-sticky, terminal no-ops, SoC rules,
     exotic fail_prob.  Driven through reset/set_state as the reference run did."""
