@@ -183,7 +183,7 @@ template <int B> __device__ __forceinline__ uint32_t mul24_byte(uint32_t a, uint
 // queries have 1 to 6561 branches, and with whole batches per wave the longest waves decided the launch's length.
 template <int MAXA, bool ALL_OUT>
 __global__ void __launch_bounds__(256) transitions_rows_kernel(const TransitionsArgs p, const uint32_t qw_log2, const uint32_t pieces_max,
-                                                               const uint32_t rows_per_wave) {
+                                                               const uint32_t rows_per_wave, const uint32_t unscanned_blocks) {
     static_assert(MAXA <= 10, "a choice set is 3 bits per agent in one 32-bit word");
     __shared__ SlipRow slip[8];
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_dyn[];
@@ -211,8 +211,29 @@ __global__ void __launch_bounds__(256) transitions_rows_kernel(const Transitions
     uint64_t base = 0;                                             // first row of the batch in the compacted arrays
     if (p.compact || pieces_max > 1u) {
         const uint64_t q1 = q0 + QW, blocks = (p.n_queries + kScanBlock - 1) / kScanBlock;
-        base = p.block_base[q0 / kScanBlock] + p.rel[q0];
-        const uint64_t end = q1 < p.n_queries ? p.block_base[q1 / kScanBlock] + p.rel[q1] : p.block_base[blocks];
+        uint64_t end;
+        if (unscanned_blocks == 0u) {                              // block_base[] holds the scanned totals (pass 2 has run)
+            base = p.block_base[q0 / kScanBlock] + p.rel[q0];
+            end = q1 < p.n_queries ? p.block_base[q1 / kScanBlock] + p.rel[q1] : p.block_base[blocks];
+        } else {
+            // a call of at most kFusedScanBlocks scan blocks (65536 queries) skips pass 2 -- a one-block launch behind pass 1, ~6 us
+            // of a call that takes 50 (8 agents x 2000 queries) to 190 us (x 20000): every wave adds up the totals below its block
+            // itself (four loads a lane at most; 32-bit sums: 256 blocks x 256 queries x 3^8 rows < 2^32)
+            const uint32_t b0 = uint32_t(q0 / kScanBlock);
+            uint32_t below = 0u;
+            for (uint32_t i = lane; i < b0; i += 64u) below += uint32_t(p.block_base[i]);
+#pragma unroll
+            for (uint32_t d = 1; d < 64u; d <<= 1) below += uint32_t(__shfl_xor(int(below), int(d), 64));
+            base = uint64_t(below) + p.rel[q0];
+            if (q1 < p.n_queries) {
+                const uint32_t b1 = uint32_t(q1 / kScanBlock);     // b0 or b0 + 1 (QW <= 64)
+                end = uint64_t(below) + (b1 > b0 ? uint32_t(p.block_base[b0]) : 0u) + p.rel[q1];
+            } else {                                               // the call's last batch: its end is the grand total
+                end = below;
+                for (uint32_t i = b0; i < unscanned_blocks; ++i) end += uint32_t(p.block_base[i]);   // (b0 is the last block or the one before)
+                if (p.compact && p.out_offset && piece == 0u && lane == 0u) p.out_offset[p.n_queries] = end;
+            }
+        }
         if (pieces_max > 1u && piece > 0u && uint64_t(row_begin) >= end - base) return;   // (piece 0 stays: it reports the counts)
     }
 
@@ -685,12 +706,14 @@ uint64_t transitions_scan_blocks(uint64_t n_queries) { return (n_queries + kScan
 
 // passes 1 and 2: args.rel / args.block_base (see TransitionsArgs), the total to args.out_offset[N] when compacting; also fills
 // args.out_count
-static hipError_t launch_transitions_offsets(const TransitionsArgs &args, hipStream_t stream) {
+constexpr uint32_t kFusedScanBlocks = 256;   // calls of up to this many scan blocks leave pass 2 to the rows kernel's waves
+static hipError_t launch_transitions_offsets(const TransitionsArgs &args, hipStream_t stream, bool scan = true) {
     const uint64_t blocks = transitions_scan_blocks(args.n_queries);
     if (blocks == 0 || blocks > 0x7FFFFFFFull) return blocks == 0 ? hipSuccess : hipErrorInvalidValue;
     hipLaunchKernelGGL(transitions_count_kernel, dim3(unsigned(blocks)), dim3(kScanBlock), 0, stream, args, args.rel, args.block_base);
-    hipLaunchKernelGGL(scan_block_totals_kernel, dim3(1), dim3(1024), 0, stream, args.block_base, uint32_t(blocks),
-                       (args.compact && args.out_offset) ? args.out_offset + args.n_queries : nullptr);
+    if (scan)
+        hipLaunchKernelGGL(scan_block_totals_kernel, dim3(1), dim3(1024), 0, stream, args.block_base, uint32_t(blocks),
+                           (args.compact && args.out_offset) ? args.out_offset + args.n_queries : nullptr);
     return hipGetLastError();
 }
 
@@ -717,8 +740,10 @@ static hipError_t launch_rows(const TransitionsArgs &args, hipStream_t stream) {
     most <<= qw_log2;
     // (the small teams' batches -- at most 64 x 81 rows, set up by one lane per query -- stay whole: their waves all do the same work)
     const uint32_t pieces_max = (MAXA >= 6 && most > 2u * rows_per_wave) ? uint32_t((most + rows_per_wave - 1) / rows_per_wave) : 1u;
+    const uint64_t scan_blocks = transitions_scan_blocks(args.n_queries);
+    const uint32_t unscanned_blocks = scan_blocks <= kFusedScanBlocks ? uint32_t(scan_blocks) : 0u;
     if (args.compact || pieces_max > 1u) {
-        if (hipError_t e = launch_transitions_offsets(args, stream)) return e;
+        if (hipError_t e = launch_transitions_offsets(args, stream, unscanned_blocks == 0u)) return e;
     }
     const uint64_t waves = ((args.n_queries + (1u << qw_log2) - 1) >> qw_log2) * pieces_max;
     // waves per block: ONE for the large teams -- their waves live for very different times (a piece that does not exist leaves
@@ -733,8 +758,8 @@ static hipError_t launch_rows(const TransitionsArgs &args, hipStream_t stream) {
     note_kernel("transitions_rows_kernel<%d> %u agents, %u queries per wave%s, %s rows", MAXA, args.n_agents, 1u << qw_log2,
                 pieces_max > 1u ? (rows_per_wave == 4096u ? " in pieces of 4096 rows" : (rows_per_wave == 2048u ? " in pieces of 2048 rows" : " in pieces of 1024 rows")) : "",
                 args.compact ? "compacted" : "reserved");
-    if (all_out) hipLaunchKernelGGL((transitions_rows_kernel<MAXA, true>), dim3(unsigned(grid64)), dim3(64 * wpb), lds, stream, args, qw_log2, pieces_max, rows_per_wave);
-    else hipLaunchKernelGGL((transitions_rows_kernel<MAXA, false>), dim3(unsigned(grid64)), dim3(64 * wpb), lds, stream, args, qw_log2, pieces_max, rows_per_wave);
+    if (all_out) hipLaunchKernelGGL((transitions_rows_kernel<MAXA, true>), dim3(unsigned(grid64)), dim3(64 * wpb), lds, stream, args, qw_log2, pieces_max, rows_per_wave, unscanned_blocks);
+    else hipLaunchKernelGGL((transitions_rows_kernel<MAXA, false>), dim3(unsigned(grid64)), dim3(64 * wpb), lds, stream, args, qw_log2, pieces_max, rows_per_wave, unscanned_blocks);
     return hipGetLastError();
 }
 

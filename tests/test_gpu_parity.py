@@ -1024,6 +1024,37 @@ def _check_compact_against_reserved(env, local, acts, env_index, res, first=0, w
         assert np.array_equal(_bits(part['prob']), _bits(cmp['prob'][:cap])) and np.array_equal(part['next'], cmp['next'][:cap])
 
 
+@pytest.mark.parametrize('n_agents', [2, 4, 8])
+def test_compacted_transitions_across_the_scan_block_boundaries(n_agents):
+    """The compacted rows' offsets come from a two-level scan: 256 queries per scan block, the blocks' totals added up by the
+    emission's waves themselves for calls of up to 256 blocks (65536 queries) and by a second pass beyond.  Query counts on
+    both sides of every boundary -- one query, a block +- 1, many blocks, 256 blocks +- 1 (small teams) -- each against the
+    reserved-row form of the same queries: offsets = the exclusive scan of the windows' lengths (the grand total in
+    offset[N]), every row in its place."""
+    rs = np.random.RandomState(31 + n_agents)
+    grid = MapfGrid([''.join('@' if rs.rand() < 0.1 else '.' for _ in range(12)) for _ in range(12)])
+    V, A = len(grid.tables()[0]), n_agents
+    goal = np.argsort(rs.rand(1, V), axis=1)[:, :A].astype(np.uint16)
+    env = VecMapfEnv(grid, A, None, None, 0.2, -1000.0, 100.0, -1.0, OptimizationCriteria.SoC, seed=1, start_local=goal[:, ::-1].copy(), goal_local=goal)
+    sizes = [1, 255, 256, 257, 2049] + ([65535, 65536, 65537, 70001] if A <= 4 else [5000])
+    M = 3 ** A if A <= 4 else 300                                 # (8 agents: a window of 300 rows keeps the reserved form small)
+    for N in sizes:
+        local = np.argsort(rs.rand(N, V), axis=1)[:, :A].astype(np.uint16)
+        local[::97] = goal[0]                                     # terminal states in between: windows of one row
+        acts = rs.randint(0, 5, size=(N, A)).astype(np.uint8)
+        res = env.transitions(local, acts, max_branches=M)
+        cmp = env.transitions_compact(local, acts, max_branches=M)
+        rows = np.minimum(res['count'].astype(np.int64), M)
+        offset = np.concatenate([[0], np.cumsum(rows)])
+        assert np.array_equal(cmp['count'], res['count']) and np.array_equal(cmp['offset'].astype(np.int64), offset), (A, N)
+        keep = np.arange(M)[None, :] < rows[:, None]              # the reserved form's live rows, query by query = the compacted rows
+        total = int(offset[N])
+        assert np.array_equal(cmp['next'][:total], res['next'][keep]), (A, N)
+        assert np.array_equal(_bits(cmp['prob'][:total]), _bits(res['prob'][keep])) and np.array_equal(_bits(cmp['reward'][:total]), _bits(res['reward'][keep])), (A, N)
+        assert np.array_equal(cmp['done'][:total], res['done'][keep]) and np.array_equal(cmp['collision'][:total], res['collision'][keep]), (A, N)
+    env.close()
+
+
 def test_transitions_of_large_teams_come_in_windows():
     """env.P for more than 8 agents (reference mapf_env.py:448-478 has no limit): the 3^A branches of a query are
     fetched window by window (mapf_transitions_window); the concatenation equals the pinned Python oracle's
