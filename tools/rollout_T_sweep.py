@@ -9,7 +9,7 @@ trajectory, streamed actions, three ways:
 HIP-event time per launch (median of 5 blocks of 20 launches); a least-squares line t(T) = fixed + T * per_step through (a)
 separates the kernel's fixed cost per launch (table staging, first loads, the drain of the last step) from its step rate.
 
-    python tools/rollout_T_sweep.py > profiles/r05_rollout_T_sweep.txt
+    python tools/rollout_T_sweep.py > profiles/r05_rollout_T_sweep.txt       (T_SWEEP_POLICY=1 ... c3 65536: the in-kernel policy)
 """
 import ctypes
 import os
@@ -25,6 +25,7 @@ from gym_mapf_amd import _native as nat  # noqa: E402
 from gym_mapf_amd.envs.vec_env import OptimizationCriteria, VecMapfEnv  # noqa: E402
 
 TS = tuple(int(x) for x in os.environ['T_SWEEP'].split(',')) if os.environ.get('T_SWEEP') else (8, 16, 32, 64, 128, 256)
+POLICY = os.environ.get('T_SWEEP_POLICY') == '1'   # actions = NULL: the in-kernel policy instead of streamed actions
 
 
 def timed(env, fn, n=20, blocks=5):
@@ -55,12 +56,12 @@ def sweep(name, n_envs):
     acc = {'returns': torch.zeros(E, dtype=torch.float64, device='cuda'),
            'episodes': torch.zeros(E, dtype=torch.int32, device='cuda').view(torch.uint32),
            'collisions': torch.zeros(E, dtype=torch.int32, device='cuda').view(torch.uint32)}
-    print('%s: %s map, %d agents, %d envs, recorded trajectory, streamed actions' % (cfg['baseline'], cfg['map'], A, E))
+    print('%s: %s map, %d agents, %d envs, recorded trajectory, %s' % (cfg['baseline'], cfg['map'], A, E, 'in-kernel policy' if POLICY else 'streamed actions'))
     print('    T   | (a) C ABI, preallocated      | (b) rollout(out=...)         | (c) rollout() allocating     | (d) hipGraph replay of (a)   | kernel')
     rows, rows_d = [], []
     for T in TS:
         io = nat.MapfRolloutIO(struct_size=ctypes.sizeof(nat.MapfRolloutIO), n_steps=T, step_flags=nat.MAPF_STEP_AUTO_RESET, accumulate=1,
-                               actions=actions.data_ptr(), out_returns=acc['returns'].data_ptr(), out_episodes=acc['episodes'].data_ptr(),
+                               actions=None if POLICY else actions.data_ptr(), out_returns=acc['returns'].data_ptr(), out_episodes=acc['episodes'].data_ptr(),
                                out_collisions=acc['collisions'].data_ptr(), rec_local=rec['local'].data_ptr(), rec_reward=rec['reward'].data_ptr(),
                                rec_done=rec['done'].data_ptr(), rec_collision=rec['collision'].data_ptr(), rec_prob=rec['prob'].data_ptr())
         a = timed(env, lambda: nat.check(env._lib.mapf_rollout(env._h, ctypes.byref(io))))
@@ -71,7 +72,7 @@ def sweep(name, n_envs):
         graph = env.graph_end()
         d = timed(env, lambda: graph.launch(1), n=4) / 16.0
         graph.close()
-        acts = actions[:T]
+        acts = None if POLICY else actions[:T]
         res = env.rollout(T, actions=acts, auto_reset=True, record=True)
         b = timed(env, lambda: env.rollout(T, actions=acts, auto_reset=True, record=True, out=res))
         c = timed(env, lambda: env.rollout(T, actions=acts, auto_reset=True, record=True))
